@@ -1,0 +1,150 @@
+"""The core BayesSim class on MI355X — counterpart of the reference's
+bayes_sim_ig/bayes_sim.py (class BayesSim: same constructor, constants,
+``run_training`` / ``predict`` / ``get_n_trajs_per_batch``).
+
+The reference's file cannot travel with this repo; this orchestrator keeps
+its behaviour (summarizer and model picked by name from ``model_cfg``, the
+hard-coded chunk schedule of bayes_sim.py:20-25, the multi-trajectory refit
+of :148-179) and drives the HIP summarizers and estimators.  ``fit`` adds the
+caller-side chunk loop of bayes_sim_main.py:157-167 for pre-recorded pairs.
+"""
+import numpy as np
+import torch
+
+from . import pdf
+from . import summarizers as _summ
+from .mdnn import MDNN
+from .mdrff import MDRFF
+from .summarizers import (pad_states_actions, summary_start, summary_waypts,  # noqa: F401
+                          summary_corr, summary_corrdiff, summary_signatory,
+                          signature_depth, cross_correlation)
+
+_SUMMARIZERS = {
+    'summary_start': summary_start, 'summary_waypts': summary_waypts,
+    'summary_corr': summary_corr, 'summary_corrdiff': summary_corrdiff,
+    'summary_signatory': summary_signatory,
+}
+_MODELS = {'MDNN': MDNN, 'MDRFF': MDRFF}
+
+
+class BayesSim(object):
+    NUM_TRAIN_TRAJ_PER_BATCH = 1000  # num trajs for each training batch
+    NUM_TRAIN_EPOCHS = 10            # num times to go over the batch
+    MINIBATCH_SIZE = 100             # minibatch size for NN training
+    NUM_GRAD_UPDATES = NUM_TRAIN_EPOCHS * NUM_TRAIN_TRAJ_PER_BATCH // MINIBATCH_SIZE
+    TEST_FRACTION = 0.2              # fraction of dataset to use as test
+
+    def __init__(self, model_cfg, obs_dim, act_dim, params_dim, params_lows,
+                 params_highs, prior, proposal=None, device='cpu'):
+        """Arguments as in the reference (bayes_sim.py:27-52).  Optional
+        ``model_cfg`` keys beyond the reference's: ``nFeat`` (RFF features,
+        default 200 as hard-coded at bayes_sim.py:81), ``sigDepth``."""
+        self.prior = prior
+        self.proposal = proposal
+        model_class = model_cfg['modelClass']
+        name = model_cfg['summarizerFxn']
+        if name not in _SUMMARIZERS:
+            raise NameError("name '%s' is not defined" % name)   # eval() in the reference
+        self.summarizer_name = name
+        self.summarizer_fxn = _SUMMARIZERS[name]
+        self._sig_depth = model_cfg.get('sigDepth', None)
+        # the reference pushes a zero trajectory through the summarizer to get
+        # the width (bayes_sim.py:57-60); the width is a closed form
+        traj_summaries_dim = _summ.summary_dim(
+            name, model_cfg['trainTrajLen'], obs_dim, act_dim,
+            self._sig_depth or 0)
+        full_covariance = bool(model_cfg.get('fullCovariance', False))
+        kwargs = {'input_dim': traj_summaries_dim, 'output_dim': params_dim,
+                  'output_lows': params_lows, 'output_highs': params_highs,
+                  'n_gaussians': model_cfg['components'],
+                  'hidden_layers': model_cfg['hiddenLayers'],
+                  'lr': model_cfg['lr'],
+                  'activation': torch.nn.Tanh,
+                  'full_covariance': full_covariance,
+                  'device': device}
+        if model_class.startswith('MDRFF'):      # "MDRFF_<kernel>_<sigma>"
+            kernel, sigma = 'RBF', 4.0
+            if '_' in model_class:
+                parts = model_class.split('_')
+                model_class, kernel = parts[0], parts[1]
+                if len(parts) > 2:
+                    sigma = float(parts[2])
+            kwargs.update({'n_feat': int(model_cfg.get('nFeat', 200)),
+                           'sigma': sigma, 'kernel': kernel})
+        if model_class not in _MODELS:
+            raise NameError("name '%s' is not defined" % model_class)
+        self.model = _MODELS[model_class](**kwargs)
+
+    @staticmethod
+    def get_n_trajs_per_batch(n_train_trajs, n_train_trajs_done):
+        n = BayesSim.NUM_TRAIN_TRAJ_PER_BATCH
+        if n_train_trajs_done + n > n_train_trajs:
+            n = n_train_trajs - n_train_trajs_done
+        return n
+
+    def _summarize(self, states, actions):
+        if self.summarizer_name == 'summary_signatory' and self._sig_depth:
+            return self.summarizer_fxn(states, actions, depth=self._sig_depth)
+        return self.summarizer_fxn(states, actions)
+
+    def run_training(self, params, traj_states, traj_actions):
+        """One chunk: summarize, then NUM_GRAD_UPDATES Adam updates of
+        MINIBATCH_SIZE (reference bayes_sim.py:91-114)."""
+        traj_summaries = self._summarize(traj_states, traj_actions)
+        return self.model.run_training(
+            x_data=traj_summaries, y_data=params,
+            n_updates=BayesSim.NUM_GRAD_UPDATES,
+            batch_size=BayesSim.MINIBATCH_SIZE,
+            test_frac=BayesSim.TEST_FRACTION)
+
+    def fit(self, params, traj_states, traj_actions):
+        """The caller-side loop of bayes_sim_main.py:157-167 over
+        pre-recorded pairs: consecutive chunks of at most
+        NUM_TRAIN_TRAJ_PER_BATCH pairs, ``run_training`` on each.
+        Returns the list of per-chunk log dicts."""
+        n, done, logs = params.shape[0], 0, []
+        while done < n:
+            m = BayesSim.get_n_trajs_per_batch(n, done)
+            logs.append(self.run_training(params[done:done + m],
+                                          traj_states[done:done + m],
+                                          traj_actions[done:done + m]))
+            done += m
+        return logs
+
+    def predict(self, states, actions, threshold=0.005):
+        """Posterior for the given real trajectories (reference
+        bayes_sim.py:116-179): the model's MoG for one trajectory; for several,
+        10^4 samples from their MoGs refitted by a fresh unconditional MDNN."""
+        xs = self._summarize(states, actions)
+        mogs = self.model.predict_MoGs(xs)
+        if self.proposal is not None:
+            for i, mog in enumerate(mogs):
+                mog.prune_negligible_components(threshold=threshold)
+                if isinstance(self.prior, pdf.Uniform):
+                    mogs[i] = mog / self.proposal
+                elif isinstance(self.prior, pdf.Gaussian):
+                    mogs[i] = (mog * self.prior) / self.proposal
+                else:
+                    raise NotImplementedError
+        if len(mogs) == 1:
+            return mogs[0]
+        mog_model = MDNN(
+            input_dim=1, output_dim=self.model.output_dim,
+            output_lows=self.model.output_lows.detach().cpu().numpy(),
+            output_highs=self.model.output_highs.detach().cpu().numpy(),
+            n_gaussians=self.model.n_gaussians, hidden_layers=(128, 128),
+            lr=self.model.lr, activation=self.model.activation,
+            full_covariance=self.model.L_size > 0, device=self.model.device)
+        tot_smpls = int(1e4)
+        per_mog = int(tot_smpls / xs.shape[0])
+        smpls = np.concatenate([m.gen(n_samples=per_mog) for m in mogs], axis=0)
+        smpls = torch.from_numpy(smpls).float().to(self.model.device)
+        if MDNN.VERBOSE:
+            print(f'Fitting posterior from {len(mogs):d} mogs')
+        batch_size = 100
+        n_updates = 5 * tot_smpls // batch_size
+        inp = torch.zeros(smpls.shape[0], 1, device=smpls.device)
+        mog_model.run_training(inp, smpls, n_updates, batch_size)
+        fitted = mog_model.predict_MoGs(inp[0:1, :])
+        assert len(fitted) == 1
+        return fitted[0]

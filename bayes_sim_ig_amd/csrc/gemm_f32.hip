@@ -1,0 +1,444 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+// fma chain at the 157 TFLOP/s vector rate; gfx950 has no xf32/TF32 path) with
+// fused epilogues.  Serves every dense contraction of the estimator:
+//   RFF projection  x @ (freqs/sigma)^T -> a*[cos|sin]     rff.py:128-132
+//   nn.Linear forward / backward of trunk and heads        mdnn.py:68-86,108-119
+// C[m,n] = epi( sum_k A(m,k) * B(n,k) ); each operand is either k-contiguous
+// (rows of a [rows, K] matrix, optionally gathered by an index vector — the
+// minibatch gather of mdnn.py:222 fused into the loader) or k-major
+// (the contraction index is the slow dimension: the transposed operands of
+// the backward products dW = dY^T X and dX = dY W).
+//
+// Tiling: BK = 32; block = WM x WN waves, each wave owns TM x TN 32x32 MFMA
+// tiles.  LDS images: k-contiguous operands as [rows][BK+4] (ds_read_b128 of
+// 4 consecutive k per lane, conflict-free at pitch 36), k-major operands as
+// [BK][rows] (ds_read_b32, 32 consecutive rows per half-wave).  Lane l of an
+// MFMA supplies row (l & 31) and k-slot (l >> 5); within an 8-wide k group the
+// half h = l>>5 takes k = 4h..4h+3, one per MFMA step — the k order is a
+// permutation of 0..7, identical for A and B.
+// Split-K (gridDim.z) writes fp32 partial slabs and a second kernel reduces
+// them in a fixed order and applies the epilogue: bitwise reproducible.
+#include "common.h"
+
+#include <algorithm>
+
+namespace bsig {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int BKP = BK + 4;
+
+struct GemmParams {
+  const float* a; int64_t lda; const int32_t* a_rows;
+  const float* b; int64_t ldb; const int32_t* b_rows;
+  float* c; int64_t ldc;
+  int m, n, k, k_chunk, splits;
+  int epilogue, act;
+  const float* bias; const float* aux; int64_t ldaux; float alpha;
+  float* partial;
+};
+
+__device__ inline float act_fwd(float v, int act) {
+  switch (act) {
+    case BSIG_ACT_TANH: return tanhf(v);
+    case BSIG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case BSIG_ACT_LEAKY_RELU: return v > 0.f ? v : 0.01f * v;
+    case BSIG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+// derivative expressed through the activation OUTPUT h
+__device__ inline float act_bwd_from_out(float h, int act) {
+  switch (act) {
+    case BSIG_ACT_TANH: return 1.f - h * h;
+    case BSIG_ACT_RELU: return h > 0.f ? 1.f : 0.f;
+    case BSIG_ACT_LEAKY_RELU: return h > 0.f ? 1.f : 0.01f;
+    case BSIG_ACT_SIGMOID: return h * (1.f - h);
+    default: return 1.f;
+  }
+}
+
+template <int EPI>
+__device__ inline void epilogue_one(const GemmParams& p, int row, int col, float v) {
+  float* dst = p.c + (int64_t)row * p.ldc + col;
+  if constexpr (EPI == BSIG_EPI_NONE) {
+    *dst = v;
+  } else if constexpr (EPI == BSIG_EPI_BIAS) {
+    *dst = v + p.bias[col];
+  } else if constexpr (EPI == BSIG_EPI_BIAS_ACT) {
+    *dst = act_fwd(v + p.bias[col], p.act);
+  } else if constexpr (EPI == BSIG_EPI_COS_SIN) {
+    float sn, cs;
+    sincosf(v, &sn, &cs);
+    dst[0] = p.alpha * cs;
+    dst[p.n] = p.alpha * sn;
+  } else if constexpr (EPI == BSIG_EPI_COS_OFF) {
+    *dst = p.alpha * cosf(v + p.bias[col]);
+  } else {
+    *dst = v * act_bwd_from_out(p.aux[(int64_t)row * p.ldaux + col], p.act);
+  }
+}
+
+__device__ inline void epilogue_store(const GemmParams& p, int row, int col, float v) {
+  switch (p.epilogue) {
+    case BSIG_EPI_NONE: epilogue_one<BSIG_EPI_NONE>(p, row, col, v); break;
+    case BSIG_EPI_BIAS: epilogue_one<BSIG_EPI_BIAS>(p, row, col, v); break;
+    case BSIG_EPI_BIAS_ACT: epilogue_one<BSIG_EPI_BIAS_ACT>(p, row, col, v); break;
+    case BSIG_EPI_COS_SIN: epilogue_one<BSIG_EPI_COS_SIN>(p, row, col, v); break;
+    case BSIG_EPI_COS_OFF: epilogue_one<BSIG_EPI_COS_OFF>(p, row, col, v); break;
+    default: epilogue_one<BSIG_EPI_MUL_DACT>(p, row, col, v); break;
+  }
+}
+
+// ---- global -> register fetch and register -> LDS commit of one operand tile
+template <int ROWS, bool KMAJOR, int VEC, int NT>
+struct TileLoader {
+  static constexpr int kItems = ROWS * BK / (NT * VEC);
+  static_assert(ROWS * BK % (NT * VEC) == 0, "tile not divisible");
+  float r[kItems][VEC];
+
+  __device__ inline void fetch(const float* __restrict__ g, int64_t ld,
+                               const int32_t* __restrict__ idx, int row0, int nrows,
+                               int k0, int kend, int tid) {
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int item = tid + it * NT;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) r[it][v] = 0.f;
+      if constexpr (!KMAJOR) {
+        constexpr int per_row = BK / VEC;
+        const int rr = item / per_row, cc = (item % per_row) * VEC;
+        const int gr = row0 + rr, gk = k0 + cc;
+        if (gr < nrows && gk < kend) {
+          const int64_t src_row = idx ? (int64_t)idx[gr] : (int64_t)gr;
+          const float* src = g + src_row * ld + gk;
+          if constexpr (VEC == 4) {
+            if (gk + 3 < kend) {
+              const float4 q = *reinterpret_cast<const float4*>(src);
+              r[it][0] = q.x; r[it][1] = q.y; r[it][2] = q.z; r[it][3] = q.w;
+            } else {
+#pragma unroll
+              for (int v = 0; v < 4; ++v) if (gk + v < kend) r[it][v] = src[v];
+            }
+          } else {
+            r[it][0] = src[0];
+          }
+        }
+      } else {
+        constexpr int per_k = ROWS / VEC;
+        const int kk = item / per_k, cc = (item % per_k) * VEC;
+        const int gk = k0 + kk, gr = row0 + cc;
+        if (gk < kend && gr < nrows) {
+          const int64_t src_row = idx ? (int64_t)idx[gk] : (int64_t)gk;
+          const float* src = g + src_row * ld + gr;
+          if constexpr (VEC == 4) {
+            if (gr + 3 < nrows) {
+              const float4 q = *reinterpret_cast<const float4*>(src);
+              r[it][0] = q.x; r[it][1] = q.y; r[it][2] = q.z; r[it][3] = q.w;
+            } else {
+#pragma unroll
+              for (int v = 0; v < 4; ++v) if (gr + v < nrows) r[it][v] = src[v];
+            }
+          } else {
+            r[it][0] = src[0];
+          }
+        }
+      }
+    }
+  }
+
+  __device__ inline void commit(float* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int item = tid + it * NT;
+      int off;
+      if constexpr (!KMAJOR) {
+        constexpr int per_row = BK / VEC;
+        off = (item / per_row) * BKP + (item % per_row) * VEC;
+      } else {
+        constexpr int per_k = ROWS / VEC;
+        off = (item / per_k) * ROWS + (item % per_k) * VEC;
+      }
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(lds + off) =
+            make_float4(r[it][0], r[it][1], r[it][2], r[it][3]);
+      } else {
+        lds[off] = r[it][0];
+      }
+    }
+  }
+};
+
+template <int ROWS, bool KMAJOR>
+constexpr int lds_floats() { return KMAJOR ? BK * ROWS : ROWS * BKP; }
+
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int AVEC, int BVEC>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int kAs = lds_floats<BM, AKM>(), kBs = lds_floats<BN, BKM>();
+  constexpr int kEpi = WM * WN * 32 * 32;  // per-wave [32][32] epilogue patches
+  __shared__ __attribute__((aligned(16))) float smem[(kAs + kBs) > kEpi ? (kAs + kBs) : kEpi];
+  float* As = smem;
+  float* Bs = smem + kAs;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * p.k_chunk;
+  const int kend = min(p.k, kbeg + p.k_chunk);
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  TileLoader<BM, AKM, AVEC, NT> la;
+  TileLoader<BN, BKM, BVEC, NT> lb;
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  if (nkt > 0) {
+    la.fetch(p.a, p.lda, p.a_rows, m0, p.m, kbeg, kend, tid);
+    lb.fetch(p.b, p.ldb, p.b_rows, n0, p.n, kbeg, kend, tid);
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    la.commit(As, tid);
+    lb.commit(Bs, tid);
+    __syncthreads();
+    if (kt + 1 < nkt) {  // prefetch the next tile into registers
+      const int k0 = kbeg + (kt + 1) * BK;
+      la.fetch(p.a, p.lda, p.a_rows, m0, p.m, k0, kend, tid);
+      lb.fetch(p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, tid);
+    }
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + l31;
+        if constexpr (!AKM) {
+          const float4 q = *reinterpret_cast<const float4*>(&As[row * BKP + kg * 8 + h * 4]);
+          af[i][0] = q.x; af[i][1] = q.y; af[i][2] = q.z; af[i][3] = q.w;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) af[i][s] = As[(kg * 8 + h * 4 + s) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 32 + l31;
+        if constexpr (!BKM) {
+          const float4 q = *reinterpret_cast<const float4*>(&Bs[col * BKP + kg * 8 + h * 4]);
+          bf[j][0] = q.x; bf[j][1] = q.y; bf[j][2] = q.z; bf[j][3] = q.w;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bf[j][s] = Bs[(kg * 8 + h * 4 + s) * BN + col];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j],
+                                                             0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // Epilogue.  C/D fragment of a 32x32 tile: col = lane & 31,
+  // row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5).  Each wave bounces one tile
+  // at a time through its private [32][32] LDS patch (the operand tiles are dead after the last
+  // barrier) so that the accumulator indices stay compile-time constants while
+  // the epilogue itself is a runtime switch.
+  float* patch = smem + wid * (32 * 32);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        patch[((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + l31] = acc[i][j][q];
+      __builtin_amdgcn_wave_barrier();
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      const int rbase = m0 + (wm * TM + i) * 32 + h;
+#pragma unroll 1
+      for (int it = 0; it < 16; ++it) {
+        const int row = rbase + 2 * it;
+        const float v = patch[(2 * it + h) * 32 + l31];
+        if (col < p.n && row < p.m) {
+          if (p.splits > 1) p.partial[((int64_t)blockIdx.z * p.m + row) * p.n + col] = v;
+          else epilogue_store(p, row, col, v);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
+  const int64_t total = (int64_t)p.m * p.n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int z = 0; z < p.splits; ++z) v += p.partial[(int64_t)z * total + e];
+    epilogue_store(p, (int)(e / p.n), (int)(e % p.n), v);
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_tile(const GemmParams& p, bool akm, bool bkm, int avec, int bvec,
+                       hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const dim3 grid(ceil_div(p.n, BN), ceil_div(p.m, BM), p.splits);
+  const dim3 block(WM * WN * 64);
+#define BSIG_GEMM_CASE(AK, BKm, AV, BV)                                            \
+  if (akm == AK && bkm == BKm && avec == AV && bvec == BV) {                       \
+    hipLaunchKernelGGL((gemm_mfma_kernel<WM, WN, TM, TN, AK, BKm, AV, BV>), grid,  \
+                       block, 0, st, p);                                           \
+    return BSIG_OK;                                                                \
+  }
+  BSIG_GEMM_CASE(false, false, 4, 4) BSIG_GEMM_CASE(false, false, 4, 1)
+  BSIG_GEMM_CASE(false, false, 1, 4) BSIG_GEMM_CASE(false, false, 1, 1)
+  BSIG_GEMM_CASE(false, true, 4, 4) BSIG_GEMM_CASE(false, true, 4, 1)
+  BSIG_GEMM_CASE(false, true, 1, 4) BSIG_GEMM_CASE(false, true, 1, 1)
+  BSIG_GEMM_CASE(true, false, 4, 4) BSIG_GEMM_CASE(true, false, 4, 1)
+  BSIG_GEMM_CASE(true, false, 1, 4) BSIG_GEMM_CASE(true, false, 1, 1)
+  BSIG_GEMM_CASE(true, true, 4, 4) BSIG_GEMM_CASE(true, true, 4, 1)
+  BSIG_GEMM_CASE(true, true, 1, 4) BSIG_GEMM_CASE(true, true, 1, 1)
+#undef BSIG_GEMM_CASE
+  set_error("gemm: no kernel for this operand layout");
+  return BSIG_EUNSUPPORTED;
+}
+
+struct GemmPlan { bool big; int splits; int k_chunk; };
+
+static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
+  GemmPlan pl;
+  const int64_t t128 = ceil_div<int64_t>(m, 128) * ceil_div<int64_t>(n, 128);
+  pl.big = (m >= 256 && n >= 128 && t128 >= 192);
+  const int64_t tiles = pl.big ? t128 : ceil_div<int64_t>(m, 64) * ceil_div<int64_t>(n, 64);
+  int64_t splits = 1;
+  if (tiles < 256) {
+    splits = ceil_div<int64_t>(512, tiles);
+    const int64_t max_by_k = k / (2 * BK) > 0 ? k / (2 * BK) : 1;
+    if (splits > max_by_k) splits = max_by_k;
+    if (splits > 64) splits = 64;
+    const int64_t max_by_ws = (int64_t)(ws_bytes / (sizeof(float) * (size_t)(m * n)));
+    if (splits > max_by_ws) splits = max_by_ws;
+    if (splits < 1) splits = 1;
+  }
+  int64_t chunk = round_up<int64_t>(ceil_div<int64_t>(k, splits), BK);
+  splits = ceil_div<int64_t>(k, chunk);
+  pl.splits = (int)splits;
+  pl.k_chunk = (int)chunk;
+  return pl;
+}
+
+static int pick_vec(const float* ptr, int64_t ld) {
+  return (ld % 4 == 0 && aligned(ptr, 16)) ? 4 : 1;
+}
+
+int gemm_f32(const float* a, int64_t lda, int a_kmajor, const int32_t* a_rows,
+             const float* b, int64_t ldb, int b_kmajor, const int32_t* b_rows, float* c,
+             int64_t ldc, int64_t m, int64_t n, int64_t k, int epilogue, int act,
+             const float* bias, const float* aux, int64_t ldaux, float alpha,
+             void* workspace, size_t workspace_bytes, hipStream_t st) {
+  BSIG_REQUIRE(a && b && c, "gemm: null pointer");
+  BSIG_REQUIRE(m >= 0 && n >= 0 && k >= 0 && m < (1 << 30) && n < (1 << 30) && k < (1 << 30),
+               "gemm: bad dims");
+  BSIG_REQUIRE(epilogue >= BSIG_EPI_NONE && epilogue <= BSIG_EPI_MUL_DACT, "gemm: bad epilogue");
+  BSIG_REQUIRE(!((epilogue == BSIG_EPI_BIAS || epilogue == BSIG_EPI_BIAS_ACT ||
+                  epilogue == BSIG_EPI_COS_OFF) && !bias), "gemm: epilogue needs bias");
+  BSIG_REQUIRE(!(epilogue == BSIG_EPI_MUL_DACT && !aux), "gemm: epilogue needs aux");
+  BSIG_REQUIRE(ldc >= (epilogue == BSIG_EPI_COS_SIN ? 2 * n : n), "gemm: ldc too small");
+  if (m == 0 || n == 0) return BSIG_OK;
+  GemmParams p;
+  p.a = a; p.lda = lda; p.a_rows = a_rows;
+  p.b = b; p.ldb = ldb; p.b_rows = b_rows;
+  p.c = c; p.ldc = ldc;
+  p.m = (int)m; p.n = (int)n; p.k = (int)k;
+  p.epilogue = epilogue; p.act = act; p.bias = bias; p.aux = aux; p.ldaux = ldaux;
+  p.alpha = alpha;
+  const GemmPlan pl = plan_gemm(m, n, k, workspace ? workspace_bytes : 0);
+  p.splits = pl.splits; p.k_chunk = pl.k_chunk;
+  p.partial = reinterpret_cast<float*>(workspace);
+  const int avec = pick_vec(a, lda), bvec = pick_vec(b, ldb);
+  int rc;
+  if (pl.big)
+    rc = launch_tile<2, 2, 2, 2>(p, a_kmajor != 0, b_kmajor != 0, avec, bvec, st);
+  else
+    rc = launch_tile<2, 2, 1, 1>(p, a_kmajor != 0, b_kmajor != 0, avec, bvec, st);
+  if (rc != BSIG_OK) return rc;
+  BSIG_CHECK_LAUNCH("gemm_mfma");
+  if (p.splits > 1) {
+    const int64_t total = m * n;
+    const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total, 256), 2048);
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    BSIG_CHECK_LAUNCH("gemm_reduce");
+  }
+  return BSIG_OK;
+}
+
+__global__ __launch_bounds__(256) void rff_coeff_kernel(const float* __restrict__ freqs,
+                                                        const float* __restrict__ sigma,
+                                                        float* __restrict__ coeff,
+                                                        int64_t m_feat, int64_t in_dim,
+                                                        int64_t ld) {
+  const int64_t total = m_feat * ld;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / ld, c = e % ld;
+    coeff[e] = c < in_dim ? freqs[r * in_dim + c] / sigma[c] : 0.f;
+  }
+}
+
+}  // namespace bsig
+
+using namespace bsig;
+
+extern "C" size_t bsig_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  const GemmPlan pl = plan_gemm(m, n, k, (size_t)1 << 40);
+  return pl.splits > 1 ? (size_t)pl.splits * (size_t)m * (size_t)n * sizeof(float) : 0;
+}
+
+extern "C" int bsig_gemm_f32(const float* a, int64_t lda, int a_kmajor,
+                             const int32_t* a_rows, const float* b, int64_t ldb,
+                             int b_kmajor, const int32_t* b_rows, float* c, int64_t ldc,
+                             int64_t m, int64_t n, int64_t k, int epilogue, int act,
+                             const float* bias, const float* aux, int64_t ldaux, float alpha,
+                             void* workspace, size_t workspace_bytes, bsig_stream_t stream) {
+  return gemm_f32(a, lda, a_kmajor, a_rows, b, ldb, b_kmajor, b_rows, c, ldc, m, n, k,
+                  epilogue, act, bias, aux, ldaux, alpha, workspace, workspace_bytes,
+                  as_stream(stream));
+}
+
+extern "C" int bsig_rff_coeff(const float* freqs, const float* sigma, float* coeff,
+                              int64_t m_feat, int64_t in_dim, int64_t ld_coeff,
+                              bsig_stream_t stream) {
+  BSIG_REQUIRE(freqs && sigma && coeff && ld_coeff >= in_dim, "rff_coeff: bad args");
+  const int64_t total = m_feat * ld_coeff;
+  if (total == 0) return BSIG_OK;
+  const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total, 256), 4096);
+  hipLaunchKernelGGL(rff_coeff_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), freqs,
+                     sigma, coeff, m_feat, in_dim, ld_coeff);
+  BSIG_CHECK_LAUNCH("rff_coeff");
+  return BSIG_OK;
+}
+
+extern "C" int bsig_rff_project(const float* x, int64_t ldx, const int32_t* x_rows,
+                                const float* coeff, int64_t ld_coeff, const float* offset,
+                                float* feats, int64_t ld_feats, int64_t batch,
+                                int64_t in_dim, int64_t m_feat, float a, int cos_only,
+                                void* workspace, size_t workspace_bytes,
+                                bsig_stream_t stream) {
+  BSIG_REQUIRE(!(cos_only && !offset), "rff_project: cos-only features need an offset");
+  return gemm_f32(x, ldx, 0, x_rows, coeff, ld_coeff, 0, nullptr, feats, ld_feats, batch,
+                  m_feat, in_dim, cos_only ? BSIG_EPI_COS_OFF : BSIG_EPI_COS_SIN, 0, offset,
+                  nullptr, 0, a, workspace, workspace_bytes, as_stream(stream));
+}

@@ -1,0 +1,502 @@
+// Mixture-density head: forward() tuple, NLL and its backward, fused.
+// Replaces bayes_sim_ig/models/mdnn.py:108-178 (softmax -> clamp -> renorm
+// weights, exp + jitter diagonals, per-component MultivariateNormal.log_prob,
+// clamp, + log clamp(w), -logsumexp, mean) and the autograd backward of that
+// graph (closed forms: SURVEY.md Appendix A.3, checked against the reference's
+// autograd in tests/test_oracle_mdn.py).
+//
+// Layout: a workgroup owns R consecutive minibatch rows; their raw head
+// outputs [R, Nh] are staged in LDS with lane-contiguous loads, thread (r, k)
+// evaluates component k of row r from LDS, the K per-component terms meet in
+// LDS for the logsumexp, gradients overwrite the staged tile in place and
+// leave with lane-contiguous stores.  Row sums (loss, jitter terms) are
+// reduced with wavefront shuffles, one partial per workgroup, summed in a
+// fixed order by the finishing kernel (bitwise reproducible, no atomics).
+#include "common.h"
+
+#include <algorithm>
+
+namespace bsig {
+
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+constexpr int kSigBlocks = 64;
+
+struct HeadArgs {
+  const float* seg_w; int64_t ld_w;    // logits (fused) or weights (tuple), K / row
+  const float* seg_mu; int64_t ld_mu;  // D*K / row
+  const float* seg_sg; int64_t ld_sg;  // pre-activation (fused) or L_d (tuple)
+  const float* seg_lo; int64_t ld_lo;  // Ls*K / row or nullptr
+  const float* y; int64_t ldy; const int32_t* y_rows;
+  int batch; float inv_norm;
+  int D, K, Ls, Nh, R;
+  int from_tuple;
+  const float* noise; uint64_t seed, stream_id;
+  const uint64_t* dyn_rng;              // device {seed, stream}: overrides (graph replay)
+  float eps_noise, min_w, ll_limit;
+  const float* sig_partials;           // [kSigBlocks] partial sums of exp(pre)
+  float* d_out; int64_t ld_dout;       // nullptr: forward only
+  float* block_lse;                    // [gridDim.x]
+  float* block_uds;                    // [gridDim.x]  sum u * dL/dsigma
+  int32_t* nonfinite;
+};
+
+__device__ inline float jitter_u(const HeadArgs& a, int row, int d, int k) {
+  const int64_t e = ((int64_t)row * a.D + d) * a.K + k;
+  if (a.noise) return a.noise[e];
+  const uint64_t seed = a.dyn_rng ? a.dyn_rng[0] : a.seed;
+  const uint64_t sid = a.dyn_rng ? a.dyn_rng[1] : a.stream_id;
+  return u01(philox4x32_10(seed, sid, (uint64_t)e).v[0]);
+}
+
+// sum_{b,d,k} exp(pre[b, d*K+k]) in kSigBlocks partials (for eps = EPS*mean(L_d),
+// mdnn.py:115)
+__global__ __launch_bounds__(256) void sigma0_sum_kernel(const float* __restrict__ pre,
+                                                         int64_t ld, int batch, int dk,
+                                                         float* __restrict__ partials) {
+  __shared__ float red[8];
+  float acc = 0.f;
+  for (int row = blockIdx.x; row < batch; row += gridDim.x)
+    for (int j = threadIdx.x; j < dk; j += blockDim.x) acc += expf(pre[(int64_t)row * ld + j]);
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+template <bool FULL>
+__global__ void mdn_nll_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D = a.D, K = a.K, Ls = a.Ls, Nh = a.Nh, R = a.R;
+  const int DK = D * K;
+  float* tile = smem;                 // [R][Nh]
+  float* ybuf = tile + R * Nh;        // [R][D]
+  float* rk = ybuf + R * D;           // [R][K]
+  float* red = rk + R * K;            // [16]
+  float* vq = red + 16;               // FULL: [2][D][blockDim.x]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int row0 = blockIdx.x * R;
+  const int nrows = min(R, a.batch - row0);
+
+  // ---- stage the R rows (four segments, each lane-contiguous) -------------
+  for (int r = 0; r < nrows; ++r) {
+    const int64_t row = row0 + r;
+    float* t = tile + r * Nh;
+    for (int j = tid; j < K; j += nt) t[j] = a.seg_w[row * a.ld_w + j];
+    for (int j = tid; j < DK; j += nt) t[K + j] = a.seg_mu[row * a.ld_mu + j];
+    for (int j = tid; j < DK; j += nt) t[K + DK + j] = a.seg_sg[row * a.ld_sg + j];
+    if (FULL)
+      for (int j = tid; j < Ls * K; j += nt) t[K + 2 * DK + j] = a.seg_lo[row * a.ld_lo + j];
+    const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row] : row;
+    for (int j = tid; j < D; j += nt) ybuf[r * D + j] = a.y[yrow * a.ldy + j];
+  }
+  // jitter scale eps = EPS_NOISE * mean(exp(pre))  (batch-global)
+  float eps = 0.f;
+  if (!a.from_tuple && a.eps_noise != 0.f) {
+    float s = (tid < kSigBlocks) ? a.sig_partials[tid] : 0.f;
+    s = block_sum(s, red);
+    eps = a.eps_noise * (s / ((float)a.batch * (float)DK));
+  }
+  __syncthreads();
+
+  const int r = tid / K, k = tid - r * K;
+  const bool active = r < nrows;
+  const int row = row0 + r;
+  float* T = tile + r * Nh;
+  const float* yv = ybuf + r * D;
+  float* v_ = vq + tid;                       // v_[i*nt]
+  float* q_ = vq + (size_t)D * nt + tid;      // q_[i*nt]
+
+  float logp = 0.f, w_k = 0.f, s_k = 0.f, csum = 1.f, mx = 0.f, den = 1.f;
+  bool bad = false;
+  if (active) {
+    if (a.from_tuple) {
+      w_k = T[k];
+    } else {  // softmax -> clamp -> renormalise, mdnn.py:109-111
+      mx = T[0];
+      for (int j = 1; j < K; ++j) mx = fmaxf(mx, T[j]);
+      den = 0.f;
+      for (int j = 0; j < K; ++j) den += expf(T[j] - mx);
+      csum = 0.f;
+      for (int j = 0; j < K; ++j)
+        csum += fminf(fmaxf(expf(T[j] - mx) / den, a.min_w), 1.0f);
+      s_k = expf(T[k] - mx) / den;
+      w_k = fminf(fmaxf(s_k, a.min_w), 1.0f) / csum;
+    }
+    bad |= !isfinite(w_k);
+    float quad = 0.f, logdet = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float mu = T[K + d * K + k];
+      const float sraw = T[K + DK + d * K + k];
+      float sg;
+      if (a.from_tuple) sg = sraw;
+      else {
+        sg = expf(sraw);
+        if (eps != 0.f) sg += jitter_u(a, row, d, k) * eps;
+      }
+      bad |= !(isfinite(mu) && isfinite(sg));
+      float res = yv[d] - mu;
+      if (FULL) {  // forward substitution with T = diag(sigma) + strict lower
+        const int base = K + 2 * DK + (d * (d - 1) / 2) * K + k;
+        for (int j = 0; j < d; ++j) {
+          const float lij = T[base + j * K];
+          bad |= !isfinite(lij);
+          res -= lij * v_[j * nt];
+        }
+        const float vi = res / sg;
+        v_[d * nt] = vi;
+        quad += vi * vi;
+      } else {
+        const float z = res / sg;
+        quad += z * z;
+      }
+      logdet += logf(sg);
+    }
+    logp = -0.5f * quad - logdet - (float)D * kHalfLog2Pi;
+    const float lp = fminf(fmaxf(logp, -a.ll_limit), a.ll_limit);   // mdnn.py:159
+    const float wc = fminf(fmaxf(w_k, a.min_w), 1.0f);              // mdnn.py:160
+    const float rv = lp + logf(wc);
+    bad |= !(isfinite(logp) && isfinite(rv));
+    rk[r * K + k] = rv;
+  }
+  __syncthreads();
+
+  float lse = 0.f;
+  if (active) {
+    const float* rr = rk + r * K;
+    float m2 = rr[0];
+    for (int j = 1; j < K; ++j) m2 = fmaxf(m2, rr[j]);
+    float se = 0.f;
+    for (int j = 0; j < K; ++j) se += expf(rr[j] - m2);
+    lse = m2 + logf(se);
+  }
+  const float lse_sum = block_sum((active && k == 0) ? lse : 0.f, red);
+  if (tid == 0) a.block_lse[blockIdx.x] = lse_sum;
+
+  float uds = 0.f, dlogit = 0.f;
+  const bool bwd = a.d_out != nullptr;
+  if (bwd && active) {
+    const float* rr = rk + r * K;
+    const float sc = -expf(rr[k] - lse) * a.inv_norm;
+    const float g_lp = (logp >= -a.ll_limit && logp <= a.ll_limit) ? sc : 0.f;
+    if (FULL) {  // q = T^{-T} v by back substitution
+      for (int i = D - 1; i >= 0; --i) {
+        float acc = v_[i * nt];
+        for (int j = i + 1; j < D; ++j)
+          acc -= T[K + 2 * DK + (j * (j - 1) / 2 + i) * K + k] * q_[j * nt];
+        const float sraw = T[K + DK + i * K + k];
+        float sg = a.from_tuple ? sraw : expf(sraw);
+        if (!a.from_tuple && eps != 0.f) sg += jitter_u(a, row, i, k) * eps;
+        q_[i * nt] = acc / sg;
+      }
+    }
+    for (int d = 0; d < D; ++d) {
+      const float mu = T[K + d * K + k];
+      const float sraw = T[K + DK + d * K + k];
+      float sg0 = 1.f, sg, u = 0.f;
+      if (a.from_tuple) sg = sraw;
+      else {
+        sg0 = expf(sraw);
+        sg = sg0;
+        if (eps != 0.f) { u = jitter_u(a, row, d, k); sg += u * eps; }
+      }
+      float dmu, dsg;
+      if (FULL) {
+        const float qi = q_[d * nt], vi = v_[d * nt];
+        dmu = g_lp * qi;
+        dsg = g_lp * (qi * vi - 1.0f / sg);
+        const int base = K + 2 * DK + (d * (d - 1) / 2) * K + k;
+        for (int j = 0; j < d; ++j) T[base + j * K] = g_lp * qi * v_[j * nt];
+      } else {
+        const float z = (yv[d] - mu) / sg;
+        dmu = g_lp * z / sg;
+        dsg = g_lp * (z * z - 1.0f) / sg;
+      }
+      uds += u * dsg;
+      T[K + d * K + k] = dmu;
+      T[K + DK + d * K + k] = dsg * sg0;
+    }
+    // mixture-weight path: second clamp, renormalisation, first clamp, softmax
+    if (a.from_tuple) {
+      const float wc = fminf(fmaxf(w_k, a.min_w), 1.0f);
+      dlogit = (w_k >= a.min_w && w_k <= 1.0f) ? sc / wc : 0.f;   // d/d weights
+    } else {
+      float s1 = 0.f;  // sum_j g_w[j] * w[j]
+      for (int j = 0; j < K; ++j) {
+        const float sj = expf(T[j] - mx) / den;
+        const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
+        const float wcj = fminf(fmaxf(wj, a.min_w), 1.0f);
+        const float scj = -expf(rr[j] - lse) * a.inv_norm;
+        const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / wcj : 0.f;
+        s1 += gwj * wj;
+      }
+      float s2 = 0.f, gs_k = 0.f;  // sum_j g_s[j] * s[j]
+      for (int j = 0; j < K; ++j) {
+        const float sj = expf(T[j] - mx) / den;
+        const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
+        const float wcj = fminf(fmaxf(wj, a.min_w), 1.0f);
+        const float scj = -expf(rr[j] - lse) * a.inv_norm;
+        const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / wcj : 0.f;
+        const float gcj = (gwj - s1) / csum;
+        const float gsj = (sj >= a.min_w && sj <= 1.0f) ? gcj : 0.f;
+        s2 += gsj * sj;
+        if (j == k) gs_k = gsj;
+      }
+      dlogit = s_k * (gs_k - s2);
+    }
+  }
+  const float uds_sum = block_sum(uds, red);  // also orders logits reads before writes
+  if (tid == 0 && a.block_uds) a.block_uds[blockIdx.x] = uds_sum;
+  if (bwd) {
+    if (active) T[k] = dlogit;
+    __syncthreads();
+    for (int r2 = 0; r2 < nrows; ++r2) {
+      float* o = a.d_out + (int64_t)(row0 + r2) * a.ld_dout;
+      const float* t = tile + r2 * Nh;
+      for (int j = tid; j < Nh; j += nt) o[j] = t[j];
+    }
+  }
+  if (bad && a.nonfinite) atomicOr(a.nonfinite, 1);
+}
+
+// Finishing kernel: loss = -(sum of block partials) / batch; jitter-scale
+// gradient term d pre += (EPS/(B*D*K)) * sum(u * dL/dsigma) * exp(pre)
+// (the non-detached mean of mdnn.py:115).
+__global__ __launch_bounds__(256) void mdn_finish_kernel(
+    const float* __restrict__ block_lse, const float* __restrict__ block_uds, int nblocks,
+    int batch, int dk, float eps_noise, const float* __restrict__ pre, int64_t ld_pre,
+    float* __restrict__ d_pre, int64_t ld_dpre, float* __restrict__ loss,
+    const int32_t* __restrict__ loss_slot, int32_t* __restrict__ nonfinite) {
+  __shared__ float red[8];
+  if (blockIdx.x == 0 && loss) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += block_lse[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+      const float l = -s / (float)batch;
+      loss[loss_slot ? *loss_slot : 0] = l;
+      if (!isfinite(l) && nonfinite) atomicOr(nonfinite, 1);
+    }
+  }
+  if (d_pre && eps_noise != 0.f) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += block_uds[i];
+    s = block_sum(s, red);
+    const float c = eps_noise / ((float)batch * (float)dk) * s;
+    for (int row = blockIdx.x; row < batch; row += gridDim.x)
+      for (int j = threadIdx.x; j < dk; j += blockDim.x)
+        d_pre[(int64_t)row * ld_dpre + j] += c * expf(pre[(int64_t)row * ld_pre + j]);
+  }
+}
+
+// forward() tuple, mdnn.py:109-119
+__global__ __launch_bounds__(256) void mdn_outputs_kernel(
+    const float* __restrict__ o, int64_t ld, int batch, int D, int K, int Ls,
+    const float* __restrict__ noise, uint64_t seed, uint64_t stream_id, float eps_noise,
+    float min_w, const float* __restrict__ sig_partials, float* __restrict__ weights,
+    float* __restrict__ mu, float* __restrict__ l_d, float* __restrict__ lower,
+    int32_t* __restrict__ nonfinite) {
+  __shared__ float red[8];
+  const int DK = D * K, Nh = K + 2 * DK + Ls * K;
+  float eps = 0.f;
+  if (eps_noise != 0.f) {
+    float s = (threadIdx.x < kSigBlocks) ? sig_partials[threadIdx.x] : 0.f;
+    s = block_sum(s, red);
+    eps = eps_noise * (s / ((float)batch * (float)DK));
+  }
+  bool bad = false;
+  for (int row = blockIdx.x; row < batch; row += gridDim.x) {
+    const float* t = o + (int64_t)row * ld;
+    for (int j = threadIdx.x; j < Nh; j += blockDim.x) {
+      float v;
+      if (j < K) {
+        float mx = t[0];
+        for (int q = 1; q < K; ++q) mx = fmaxf(mx, t[q]);
+        float den = 0.f;
+        for (int q = 0; q < K; ++q) den += expf(t[q] - mx);
+        float csum = 0.f;
+        for (int q = 0; q < K; ++q) csum += fminf(fmaxf(expf(t[q] - mx) / den, min_w), 1.f);
+        v = fminf(fmaxf(expf(t[j] - mx) / den, min_w), 1.f) / csum;
+        weights[(int64_t)row * K + j] = v;
+      } else if (j < K + DK) {
+        v = t[j];
+        mu[(int64_t)row * DK + (j - K)] = v;
+      } else if (j < K + 2 * DK) {
+        const int e = j - K - DK;
+        v = expf(t[j]);
+        if (eps != 0.f) {
+          const int64_t ne = (int64_t)row * DK + e;  // [B, D, K] flat == d*K+k
+          const float u = noise ? noise[ne] : u01(philox4x32_10(seed, stream_id, (uint64_t)ne).v[0]);
+          v += u * eps;
+        }
+        l_d[(int64_t)row * DK + e] = v;
+      } else {
+        v = t[j];
+        lower[(int64_t)row * Ls * K + (j - K - 2 * DK)] = v;
+      }
+      bad |= !isfinite(v);
+    }
+  }
+  if (bad && nonfinite) atomicOr(nonfinite, 1);
+}
+
+// ---------------------------------------------------------------- host side
+struct HeadGeom { int D, K, Ls, Nh, R, threads; size_t lds; int blocks; };
+
+static int head_geom(const bsig_head_dims* d, int64_t batch, HeadGeom* g) {
+  BSIG_REQUIRE(d && d->out_dim >= 1 && d->n_comp >= 1, "mdn head: bad dims");
+  BSIG_REQUIRE(d->n_comp <= 64, "mdn head: at most 64 components");
+  g->D = d->out_dim; g->K = d->n_comp;
+  g->Ls = d->full_cov ? d->out_dim * (d->out_dim - 1) / 2 : 0;
+  g->Nh = g->K + 2 * g->D * g->K + g->Ls * g->K;
+  const int rmax = 256 / g->K;
+  int R = (int)std::min<int64_t>(rmax, std::max<int64_t>(1, ceil_div<int64_t>(batch, 128)));
+  for (;; --R) {
+    const int threads = (int)round_up(R * g->K, 64);
+    const size_t lds = ((size_t)R * (g->Nh + g->D + g->K) + 16 +
+                        (g->Ls ? (size_t)2 * g->D * threads : 0)) * sizeof(float);
+    if (lds <= 96 * 1024 || R == 1) {
+      g->R = R; g->threads = threads; g->lds = lds;
+      break;
+    }
+  }
+  if (g->lds > 150 * 1024) {
+    set_error("mdn head: a single row needs %zu B of LDS", g->lds);
+    return BSIG_EUNSUPPORTED;
+  }
+  g->blocks = (int)ceil_div<int64_t>(batch, g->R);
+  return BSIG_OK;
+}
+
+// workspace floats: [sig partials kSigBlocks][block_lse nblk][block_uds nblk]
+static size_t head_ws_floats(const HeadGeom& g) { return kSigBlocks + 2 * (size_t)g.blocks; }
+
+int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t ld_w,
+                        const float* seg_mu, int64_t ld_mu, const float* seg_sg,
+                        int64_t ld_sg, const float* seg_lo, int64_t ld_lo, int from_tuple,
+                        const float* y, int64_t ldy, const int32_t* y_rows, int64_t batch,
+                        int64_t norm_batch, const float* noise, uint64_t seed,
+                        uint64_t stream_id, const uint64_t* dyn_rng, float* loss,
+                        const int32_t* loss_slot,
+                        float* d_out, int64_t ld_dout, int32_t* nonfinite, void* workspace,
+                        size_t workspace_bytes, hipStream_t st) {
+  HeadGeom g;
+  BSIG_TRY(head_geom(dims, batch, &g));
+  BSIG_REQUIRE(batch >= 1 && batch < (1 << 30), "mdn head: bad batch");
+  BSIG_REQUIRE(workspace && workspace_bytes >= head_ws_floats(g) * sizeof(float),
+               "mdn head: workspace too small (%zu < %zu)", workspace_bytes,
+               head_ws_floats(g) * sizeof(float));
+  BSIG_REQUIRE(!(g.Ls > 0 && !seg_lo), "mdn head: full covariance needs lower entries");
+  float* ws = reinterpret_cast<float*>(workspace);
+  float* sig_partials = ws;
+  float* block_lse = ws + kSigBlocks;
+  float* block_uds = block_lse + g.blocks;
+  const int DK = g.D * g.K;
+  const bool jitter = !from_tuple && dims->eps_noise != 0.f;
+  if (jitter) {
+    hipLaunchKernelGGL(sigma0_sum_kernel, dim3(kSigBlocks), dim3(256), 0, st, seg_sg, ld_sg,
+                       (int)batch, DK, sig_partials);
+    BSIG_CHECK_LAUNCH("sigma0_sum");
+  }
+  HeadArgs a;
+  a.seg_w = seg_w; a.ld_w = ld_w; a.seg_mu = seg_mu; a.ld_mu = ld_mu;
+  a.seg_sg = seg_sg; a.ld_sg = ld_sg; a.seg_lo = seg_lo; a.ld_lo = ld_lo;
+  a.y = y; a.ldy = ldy; a.y_rows = y_rows;
+  a.batch = (int)batch; a.inv_norm = 1.0f / (float)norm_batch;
+  a.D = g.D; a.K = g.K; a.Ls = g.Ls; a.Nh = g.Nh; a.R = g.R;
+  a.from_tuple = from_tuple;
+  a.noise = noise; a.seed = seed; a.stream_id = stream_id; a.dyn_rng = dyn_rng;
+  a.eps_noise = from_tuple ? 0.f : dims->eps_noise;
+  a.min_w = dims->min_weight; a.ll_limit = dims->ll_limit;
+  a.sig_partials = sig_partials;
+  a.d_out = d_out; a.ld_dout = ld_dout;
+  a.block_lse = block_lse; a.block_uds = block_uds; a.nonfinite = nonfinite;
+  if (g.Ls > 0)
+    hipLaunchKernelGGL(mdn_nll_kernel<true>, dim3(g.blocks), dim3(g.threads), g.lds, st, a);
+  else
+    hipLaunchKernelGGL(mdn_nll_kernel<false>, dim3(g.blocks), dim3(g.threads), g.lds, st, a);
+  BSIG_CHECK_LAUNCH("mdn_nll");
+  const bool correct = jitter && d_out != nullptr;
+  const int fblocks = correct ? (int)std::min<int64_t>(batch, 512) : 1;
+  hipLaunchKernelGGL(mdn_finish_kernel, dim3(fblocks), dim3(256), 0, st, block_lse, block_uds,
+                     g.blocks, (int)batch, DK, correct ? dims->eps_noise : 0.f, seg_sg, ld_sg,
+                     correct ? d_out + g.K + DK : nullptr, ld_dout, loss, loss_slot,
+                     nonfinite);
+  BSIG_CHECK_LAUNCH("mdn_finish");
+  return BSIG_OK;
+}
+
+}  // namespace bsig
+
+using namespace bsig;
+
+extern "C" int64_t bsig_head_width(const bsig_head_dims* d) {
+  if (!d) return -1;
+  const int64_t ls = d->full_cov ? (int64_t)d->out_dim * (d->out_dim - 1) / 2 : 0;
+  return d->n_comp + 2 * (int64_t)d->out_dim * d->n_comp + ls * d->n_comp;
+}
+
+extern "C" size_t bsig_head_workspace_bytes(const bsig_head_dims* d, int64_t batch) {
+  HeadGeom g;
+  if (batch < 1) batch = 1;
+  if (head_geom(d, batch, &g) != BSIG_OK) return 0;
+  return head_ws_floats(g) * sizeof(float);
+}
+
+extern "C" int bsig_mdn_head_outputs(const bsig_head_dims* dims, const float* head_out,
+                                     int64_t ld, int64_t batch, const float* noise,
+                                     uint64_t seed, uint64_t stream_id, float* weights,
+                                     float* mu, float* l_d, float* lower, int32_t* nonfinite,
+                                     void* workspace, size_t workspace_bytes,
+                                     bsig_stream_t stream) {
+  BSIG_REQUIRE(dims && head_out && weights && mu && l_d, "head_outputs: null pointer");
+  BSIG_REQUIRE(batch >= 1, "head_outputs: empty batch");
+  const int D = dims->out_dim, K = dims->n_comp;
+  const int Ls = dims->full_cov ? D * (D - 1) / 2 : 0;
+  BSIG_REQUIRE(!(Ls > 0 && !lower), "head_outputs: full covariance needs `lower`");
+  BSIG_REQUIRE(ld >= bsig_head_width(dims), "head_outputs: ld too small");
+  BSIG_REQUIRE(workspace && workspace_bytes >= kSigBlocks * sizeof(float),
+               "head_outputs: workspace too small");
+  float* sig_partials = reinterpret_cast<float*>(workspace);
+  hipStream_t st = as_stream(stream);
+  if (dims->eps_noise != 0.f) {
+    hipLaunchKernelGGL(sigma0_sum_kernel, dim3(kSigBlocks), dim3(256), 0, st,
+                       head_out + K + D * K, ld, (int)batch, D * K, sig_partials);
+    BSIG_CHECK_LAUNCH("sigma0_sum");
+  }
+  hipLaunchKernelGGL(mdn_outputs_kernel, dim3((int)std::min<int64_t>(batch, 2048)), dim3(256),
+                     0, st, head_out, ld, (int)batch, D, K, Ls, noise, seed, stream_id,
+                     dims->eps_noise, dims->min_weight, sig_partials, weights, mu, l_d, lower,
+                     nonfinite);
+  BSIG_CHECK_LAUNCH("mdn_outputs");
+  return BSIG_OK;
+}
+
+extern "C" int bsig_mdn_nll_from_tuple(const bsig_head_dims* dims, const float* weights,
+                                       const float* mu, const float* l_d, const float* lower,
+                                       const float* y, int64_t ldy, int64_t batch, float* loss,
+                                       int32_t* nonfinite, void* workspace,
+                                       size_t workspace_bytes, bsig_stream_t stream) {
+  BSIG_REQUIRE(dims && weights && mu && l_d && y && loss, "nll_from_tuple: null pointer");
+  const int64_t D = dims->out_dim, K = dims->n_comp;
+  const int64_t Ls = dims->full_cov ? D * (D - 1) / 2 : 0;
+  return mdn_head_nll_launch(dims, weights, K, mu, D * K, l_d, D * K, lower, Ls * K, 1, y,
+                             ldy, nullptr, batch, batch, nullptr, 0, 0, nullptr, loss, nullptr,
+                             nullptr, 0, nonfinite, workspace, workspace_bytes,
+                             as_stream(stream));
+}
+
+extern "C" int bsig_mdn_head_nll(const bsig_head_dims* dims, const float* head_out,
+                                 int64_t ld, const float* y, int64_t ldy,
+                                 const int32_t* y_rows, int64_t batch, int64_t norm_batch,
+                                 const float* noise, uint64_t seed, uint64_t stream_id,
+                                 float* loss, float* d_head_out, int32_t* nonfinite,
+                                 void* workspace, size_t workspace_bytes,
+                                 bsig_stream_t stream) {
+  BSIG_REQUIRE(dims && head_out && y, "head_nll: null pointer");
+  BSIG_REQUIRE(ld >= bsig_head_width(dims), "head_nll: ld too small");
+  BSIG_REQUIRE(norm_batch >= 1, "head_nll: norm_batch must be >= 1");
+  const int64_t D = dims->out_dim, K = dims->n_comp;
+  return mdn_head_nll_launch(dims, head_out, ld, head_out + K, ld, head_out + K + D * K, ld,
+                             dims->full_cov ? head_out + K + 2 * D * K : nullptr, ld, 0, y,
+                             ldy, y_rows, batch, norm_batch, noise, seed, stream_id, nullptr,
+                             loss, nullptr, d_head_out, ld, nonfinite, workspace, workspace_bytes,
+                             as_stream(stream));
+}

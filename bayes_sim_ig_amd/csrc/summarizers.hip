@@ -1,0 +1,384 @@
+// Trajectory summarizers as HBM-streaming HIP kernels (gfx950).
+// Replaces the PyTorch op sequences of bayes_sim_ig/utils/summarizers.py
+// (reference file:line cited per kernel).  One workgroup per trajectory;
+// all global traffic is lane-contiguous.
+#include "common.h"
+
+namespace bsig {
+
+// ------------------------------------------------------------------ K1
+// summary_start / summary_waypts: summarizers.py:65-87 after the crop/pad of
+// :20-62.  out[n, t*(sd+ad)+c] = c<sd ? s[n,min(t,Ts-1),c] : a[n,min(t,Ta-1),c-sd]
+// Algorithmic bytes / trajectory: 2 * 4 * W*(sd+ad).
+template <int UNROLL_T>
+__global__ __launch_bounds__(256) void summary_start_kernel(
+    const float* __restrict__ states, const float* __restrict__ actions,
+    float* __restrict__ out, int64_t n, int ts, int ta, int sd, int ad, int w,
+    int64_t ld_out) {
+  const int width = sd + ad;
+  for (int64_t traj = blockIdx.x; traj < n; traj += gridDim.x) {
+    const float* s = states + traj * (int64_t)ts * sd;
+    const float* a = actions + traj * (int64_t)ta * ad;
+    float* o = out + traj * ld_out;
+    for (int t0 = 0; t0 < w; t0 += UNROLL_T) {
+      for (int c = threadIdx.x; c < width; c += blockDim.x) {
+        float v[UNROLL_T];
+#pragma unroll
+        for (int u = 0; u < UNROLL_T; ++u) {
+          const int t = t0 + u;
+          if (t < w) {
+            v[u] = (c < sd) ? s[(int64_t)min(t, ts - 1) * sd + c]
+                            : a[(int64_t)min(t, ta - 1) * ad + (c - sd)];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL_T; ++u) {
+          const int t = t0 + u;
+          if (t < w) o[(int64_t)t * width + c] = v[u];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K2
+// cross_correlation: summarizers.py:90-122.
+//   sf[t*(sd-1)+c] = s[t,c+1]-s[t,c]  (corrdiff, :105-106)  or  s[t,c] (:108)
+//   af[t*ad+c]     = a[t,c]
+//   out[i*A + j]   = sf[i]*af[j]      (bmm outer product, :112-113)
+//   out[S*A]       = mean(sf), out[S*A+1] = unbiased std(sf)   (:114-119)
+// Algorithmic bytes / trajectory: 4*(W*(sd+ad) + S*A + 2); write-bound.
+__global__ __launch_bounds__(256) void crosscorr_kernel(
+    const float* __restrict__ states, const float* __restrict__ actions,
+    float* __restrict__ out, int64_t n, int ts, int ta, int sd, int ad, int w,
+    int use_diff, int64_t ld_out, int vec4, int32_t* __restrict__ nonfinite) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int sfeat = sd - 1;
+  const int S = w * sfeat, A = w * ad;
+  float* sf = smem;            // [S]
+  float* af = smem + S;        // [A]
+  float* red = af + A;         // [8]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int64_t traj = blockIdx.x; traj < n; traj += gridDim.x) {
+    const float* s = states + traj * (int64_t)ts * sd;
+    const float* a = actions + traj * (int64_t)ta * ad;
+    float* o = out + traj * ld_out;
+    __syncthreads();
+    // state features: iterate (t, c) without integer division
+    for (int t = 0; t < w; ++t) {
+      const float* srow = s + (int64_t)t * sd;
+      for (int c = tid; c < sfeat; c += nt)
+        sf[t * sfeat + c] = use_diff ? (srow[c + 1] - srow[c]) : srow[c];
+      // actions beyond their own length repeat the last step (pad, :52-58)
+      const float* arow = a + (int64_t)min(t, ta - 1) * ad;
+      for (int c = tid; c < ad; c += nt) af[t * ad + c] = arow[c];
+    }
+    __syncthreads();
+    // mean and unbiased std (two passes, like torch.std)
+    float part = 0.f;
+    for (int i = tid; i < S; i += nt) part += sf[i];
+    const float mean = block_sum(part, red) / (float)S;
+    part = 0.f;
+    for (int i = tid; i < S; i += nt) {
+      const float d = sf[i] - mean;
+      part += d * d;
+    }
+    const float ss = block_sum(part, red);
+    const float sdev = (S < 2) ? 0.f : sqrtf(ss / (float)(S - 1));
+    // streaming outer product
+    const int64_t total = (int64_t)S * A;
+    bool bad = false;
+    if (vec4) {
+      // rows are 16-B aligned (ld_out % 4 == 0): one float4 per lane
+      const int64_t nvec = total >> 2;
+      const int step_i = (4 * nt) / A, step_j = (4 * nt) % A;
+      int64_t e = 4 * (int64_t)tid;
+      int i = (int)(e / A), j = (int)(e % A);
+      for (int64_t q = tid; q < nvec; q += nt) {
+        float4 v;
+        int ii = i, jj = j;
+        v.x = sf[ii] * af[jj]; if (++jj == A) { jj = 0; ++ii; }
+        v.y = sf[ii] * af[jj]; if (++jj == A) { jj = 0; ++ii; }
+        v.z = sf[ii] * af[jj]; if (++jj == A) { jj = 0; ++ii; }
+        v.w = sf[ii] * af[jj];
+        bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+        *reinterpret_cast<float4*>(o + 4 * q) = v;
+        i += step_i; j += step_j;
+        if (j >= A) { j -= A; ++i; }
+      }
+      for (int64_t e2 = (nvec << 2) + tid; e2 < total; e2 += nt) {
+        const float v = sf[e2 / A] * af[e2 % A];
+        bad |= !isfinite(v);
+        o[e2] = v;
+      }
+    } else {
+      const int step_i = nt / A, step_j = nt % A;
+      int i = tid / A, j = tid % A;
+      for (int64_t e = tid; e < total; e += nt) {
+        const float v = sf[i] * af[j];
+        bad |= !isfinite(v);
+        o[e] = v;
+        i += step_i; j += step_j;
+        if (j >= A) { j -= A; ++i; }
+      }
+    }
+    if (tid == 0) {
+      o[total] = mean;
+      o[total + 1] = sdev;
+      bad |= !(isfinite(mean) && isfinite(sdev));
+    }
+    if (bad && nonfinite) atomicOr(nonfinite, 1);
+  }
+}
+
+// ------------------------------------------------------------------ K3
+// summary_signatory: summarizers.py:144-168.  Path X_l = [l+1 | s_l | a_l]
+// (:152-155), signature levels 1..depth in signatory's layout.  Chen's
+// identity per segment, Horner form:
+//   S3[i,j,k] += (S2[i,j] + (S1[i] + D[i]/3) * D[j]/2) * D[k]
+//   S2[i,j]   += (S1[i] + D[i]/2) * D[j]
+//   S1[i]      = X_l[i] - X_0[i]
+// One thread per (i,j) pair keeps S2[i,j] and the S3[i,j,:] row in registers
+// for the whole path; the result is staged in LDS and stored lane-contiguous.
+// Algorithmic bytes / trajectory: 4*(L*d + d + d^2 + d^3).
+template <int DMAX>
+__global__ void signature3_kernel(const float* __restrict__ states,
+                                  const float* __restrict__ actions,
+                                  float* __restrict__ out, int64_t n, int length,
+                                  int sd, int ad, int64_t ld_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int d = 1 + sd + ad;
+  float* path = smem;                  // [length * d]
+  float* stage = smem + length * d;    // [d*d*d]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int npairs = d * d;
+  const int i = tid / d, j = tid % d;
+  const bool active = tid < npairs;
+  for (int64_t traj = blockIdx.x; traj < n; traj += gridDim.x) {
+    const float* s = states + traj * (int64_t)length * sd;
+    const float* a = actions + traj * (int64_t)length * ad;
+    float* o = out + traj * ld_out;
+    __syncthreads();
+    for (int l = 0; l < length; ++l) {
+      float* row = path + l * d;
+      if (tid == 0) row[0] = (float)(l + 1);
+      for (int c = tid; c < sd; c += nt) row[1 + c] = s[(int64_t)l * sd + c];
+      for (int c = tid; c < ad; c += nt) row[1 + sd + c] = a[(int64_t)l * ad + c];
+    }
+    __syncthreads();
+    float s2 = 0.f;
+    float s3[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) s3[k] = 0.f;
+    if (active) {
+      const float x0i = path[i];
+      for (int l = 0; l + 1 < length; ++l) {
+        const float* p0 = path + l * d;
+        const float* p1 = p0 + d;
+        const float di = p1[i] - p0[i];
+        const float dj = p1[j] - p0[j];
+        const float s1i = p0[i] - x0i;
+        const float coef = s2 + (s1i + di * (1.0f / 3.0f)) * dj * 0.5f;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k)
+          if (k < d) s3[k] = fmaf(coef, p1[k] - p0[k], s3[k]);
+        s2 = fmaf(s1i + di * 0.5f, dj, s2);
+      }
+#pragma unroll
+      for (int k = 0; k < DMAX; ++k)
+        if (k < d) stage[tid * d + k] = s3[k];
+      o[d + tid] = s2;                                   // level 2
+    }
+    for (int c = tid; c < d; c += nt)                    // level 1
+      o[c] = path[(length - 1) * d + c] - path[c];
+    __syncthreads();
+    float* o3 = o + d + npairs;
+    const int n3 = npairs * d;
+    for (int e = tid; e < n3; e += nt) o3[e] = stage[e];
+  }
+}
+
+// depth <= 2 for wider paths: S2[i,j] = sum_l (X_l[i]-X_0[i] + D_l[i]/2) D_l[j]
+__global__ __launch_bounds__(256) void signature12_kernel(
+    const float* __restrict__ states, const float* __restrict__ actions,
+    float* __restrict__ out, int64_t n, int length, int sd, int ad, int depth,
+    int64_t ld_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int d = 1 + sd + ad;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int64_t traj = blockIdx.x; traj < n; traj += gridDim.x) {
+    const float* s = states + traj * (int64_t)length * sd;
+    const float* a = actions + traj * (int64_t)length * ad;
+    float* o = out + traj * ld_out;
+    if (depth == 1) {  // last - first row (time channel: L-1)
+      for (int c = tid; c < d; c += nt) {
+        float v;
+        if (c == 0) v = (float)(length - 1);
+        else if (c <= sd) v = s[(int64_t)(length - 1) * sd + c - 1] - s[c - 1];
+        else v = a[(int64_t)(length - 1) * ad + c - 1 - sd] - a[c - 1 - sd];
+        o[c] = v;
+      }
+      continue;
+    }
+    float* path = smem;  // [length * d]
+    __syncthreads();
+    for (int l = 0; l < length; ++l) {
+      float* row = path + l * d;
+      if (tid == 0) row[0] = (float)(l + 1);
+      for (int c = tid; c < sd; c += nt) row[1 + c] = s[(int64_t)l * sd + c];
+      for (int c = tid; c < ad; c += nt) row[1 + sd + c] = a[(int64_t)l * ad + c];
+    }
+    __syncthreads();
+    for (int c = tid; c < d; c += nt) o[c] = path[(length - 1) * d + c] - path[c];
+    const int n2 = d * d;
+    const int step_i = nt / d, step_j = nt % d;
+    int i = tid / d, j = tid % d;
+    for (int e = tid; e < n2; e += nt) {
+      const float x0i = path[i];
+      float acc = 0.f;
+      for (int l = 0; l + 1 < length; ++l) {
+        const float* p0 = path + l * d;
+        const float* p1 = p0 + d;
+        acc = fmaf((p0[i] - x0i) + (p1[i] - p0[i]) * 0.5f, p1[j] - p0[j], acc);
+      }
+      o[d + e] = acc;
+      i += step_i; j += step_j;
+      if (j >= d) { j -= d; ++i; }
+    }
+  }
+}
+
+static int grid_for(int64_t n) {
+  // one workgroup per trajectory, capped; the kernels grid-stride
+  const int64_t cap = 256 * 64;
+  return (int)(n < cap ? n : cap);
+}
+
+static int ref_signature_depth(int64_t d) {  // summarizers.py:133-141
+  for (int depth = 3; depth >= 0; --depth) {
+    int64_t p = 1;
+    for (int q = 0; q < depth; ++q) p *= d;
+    if (p <= 110 * 110) return depth;
+  }
+  return 1;
+}
+
+}  // namespace bsig
+
+using namespace bsig;
+
+extern "C" int64_t bsig_summary_dim(int kind, int traj_len, int sd, int ad, int depth) {
+  if (kind == 0) return 10 * (int64_t)(sd + ad);
+  if (kind == 1 || kind == 2) {
+    int w = sd > 50 ? 5 : 10;
+    if (traj_len <= w) w = traj_len;
+    return (int64_t)w * (sd - 1) * w * ad + 2;
+  }
+  if (kind == 3) {
+    const int64_t d = 1 + sd + ad;
+    if (depth <= 0) depth = ref_signature_depth(d);
+    int64_t tot = 0, p = 1;
+    for (int q = 1; q <= depth; ++q) { p *= d; tot += p; }
+    return tot;
+  }
+  return -1;
+}
+
+extern "C" int bsig_summary_start(const float* states, const float* actions, float* out,
+                                  int64_t n, int t_states, int t_actions, int sd, int ad,
+                                  int max_t, int64_t ld_out, bsig_stream_t stream) {
+  if (n == 0) return BSIG_OK;
+  BSIG_REQUIRE(states && actions && out, "summary_start: null pointer");
+  BSIG_REQUIRE(n >= 0 && t_states >= 1 && t_actions >= 1 && sd >= 1 && ad >= 1 && max_t >= 1,
+               "summary_start: bad dims n=%lld ts=%d ta=%d sd=%d ad=%d max_t=%d",
+               (long long)n, t_states, t_actions, sd, ad, max_t);
+  BSIG_REQUIRE(ld_out >= (int64_t)max_t * (sd + ad), "summary_start: ld_out too small");
+  if (n == 0) return BSIG_OK;
+  const int width = sd + ad;
+  const int threads = width >= 192 ? 256 : (width >= 96 ? 128 : 64);
+  hipLaunchKernelGGL((summary_start_kernel<5>), dim3(grid_for(n)), dim3(threads), 0,
+                     as_stream(stream), states, actions, out, n, t_states, t_actions, sd,
+                     ad, max_t, ld_out);
+  BSIG_CHECK_LAUNCH("summary_start");
+  return BSIG_OK;
+}
+
+extern "C" int bsig_crosscorr(const float* states, const float* actions, float* out,
+                              int64_t n, int t_states, int t_actions, int sd, int ad,
+                              int use_state_diff, int64_t ld_out, int32_t* nonfinite,
+                              bsig_stream_t stream) {
+  if (n == 0) return BSIG_OK;
+  BSIG_REQUIRE(states && actions && out, "crosscorr: null pointer");
+  BSIG_REQUIRE(n >= 0 && sd >= 2 && ad >= 1, "crosscorr: bad dims sd=%d ad=%d", sd, ad);
+  BSIG_REQUIRE(t_states > 1, "crosscorr: traj_len must be > 1 (summarizers.py:94)");
+  BSIG_REQUIRE(t_actions >= 1, "crosscorr: no actions");
+  int w = sd > 50 ? 5 : 10;                       // summarizers.py:96-98
+  if (t_states <= w) w = t_states;                // :99 (only crop when longer)
+  const int64_t S = (int64_t)w * (sd - 1), A = (int64_t)w * ad;
+  BSIG_REQUIRE(ld_out >= S * A + 2, "crosscorr: ld_out too small");
+  const size_t lds = (size_t)(S + A + 8) * sizeof(float);
+  if (lds > 150 * 1024) {
+    set_error("crosscorr: %zu B of LDS needed", lds);
+    return BSIG_EUNSUPPORTED;
+  }
+  if (n == 0) return BSIG_OK;
+  const int vec4 = (ld_out % 4 == 0) && aligned(out, 16) && (4 * 256 >= A ? 1 : 1);
+  hipLaunchKernelGGL(crosscorr_kernel, dim3(grid_for(n)), dim3(256), lds, as_stream(stream),
+                     states, actions, out, n, t_states, t_actions, sd, ad, w,
+                     use_state_diff, ld_out, vec4, nonfinite);
+  BSIG_CHECK_LAUNCH("crosscorr");
+  return BSIG_OK;
+}
+
+extern "C" int bsig_signature(const float* states, const float* actions, float* out,
+                              int64_t n, int length, int sd, int ad, int depth,
+                              int64_t ld_out, bsig_stream_t stream) {
+  if (n == 0) return BSIG_OK;
+  BSIG_REQUIRE(states && actions && out, "signature: null pointer");
+  BSIG_REQUIRE(n >= 0 && length >= 2 && sd >= 1 && ad >= 1,
+               "signature: bad dims length=%d sd=%d ad=%d", length, sd, ad);
+  const int d = 1 + sd + ad;
+  if (depth <= 0) depth = ref_signature_depth(d);
+  BSIG_REQUIRE(depth >= 1 && depth <= 3, "signature: depth %d not in 1..3", depth);
+  BSIG_REQUIRE(ld_out >= bsig_summary_dim(3, length, sd, ad, depth),
+               "signature: ld_out too small");
+  if (n == 0) return BSIG_OK;
+  if (depth == 3) {
+    if (d > 32) {
+      set_error("signature: depth 3 needs path dim <= 32 (got %d)", d);
+      return BSIG_EUNSUPPORTED;
+    }
+    const size_t lds = ((size_t)length * d + (size_t)d * d * d) * sizeof(float);
+    if (lds > 150 * 1024) {
+      set_error("signature: %zu B of LDS needed", lds);
+      return BSIG_EUNSUPPORTED;
+    }
+    const int threads = (int)round_up<int64_t>((int64_t)d * d, 64);
+    if (d <= 8)
+      hipLaunchKernelGGL((signature3_kernel<8>), dim3(grid_for(n)), dim3(threads), lds,
+                         as_stream(stream), states, actions, out, n, length, sd, ad, ld_out);
+    else if (d <= 16)
+      hipLaunchKernelGGL((signature3_kernel<16>), dim3(grid_for(n)), dim3(threads), lds,
+                         as_stream(stream), states, actions, out, n, length, sd, ad, ld_out);
+    else if (d <= 24)
+      hipLaunchKernelGGL((signature3_kernel<24>), dim3(grid_for(n)), dim3(threads), lds,
+                         as_stream(stream), states, actions, out, n, length, sd, ad, ld_out);
+    else
+      hipLaunchKernelGGL((signature3_kernel<32>), dim3(grid_for(n)), dim3(threads), lds,
+                         as_stream(stream), states, actions, out, n, length, sd, ad, ld_out);
+  } else {
+    size_t lds = 0;
+    if (depth == 2) {
+      lds = (size_t)length * d * sizeof(float);
+      if (lds > 150 * 1024) {
+        set_error("signature: %zu B of LDS needed", lds);
+        return BSIG_EUNSUPPORTED;
+      }
+    }
+    hipLaunchKernelGGL(signature12_kernel, dim3(grid_for(n)), dim3(256), lds,
+                       as_stream(stream), states, actions, out, n, length, sd, ad, depth,
+                       ld_out);
+  }
+  BSIG_CHECK_LAUNCH("signature");
+  return BSIG_OK;
+}

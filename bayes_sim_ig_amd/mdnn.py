@@ -1,0 +1,441 @@
+"""Mixture Density NN estimator on MI355X — mirror of the reference's
+bayes_sim_ig/models/mdnn.py (class MDNN: same constructor keywords, methods,
+attributes, ``state_dict`` keys and error behaviour).
+
+All arithmetic runs in libbsig_hip (csrc/): the parameters live in ONE flat
+fp32 device buffer (the named ``nn.Parameter``s are views into it, so
+``state_dict`` / ``load_state_dict`` keep working), the trunk / head products
+are fp32-MFMA GEMMs, the mixture head + NLL + backward is one fused kernel,
+Adam runs over the flat buffer, and ``run_training`` replays the whole update
+from a HIP graph (csrc/estimator.hip).  There is no CPU fallback.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import pdf
+from . import dp as _dp
+
+_ACT_CODES = {nn.Tanh: _lib.ACT_TANH, nn.ReLU: _lib.ACT_RELU,
+              nn.LeakyReLU: _lib.ACT_LEAKY_RELU, nn.Sigmoid: _lib.ACT_SIGMOID,
+              nn.Identity: _lib.ACT_IDENTITY}
+
+
+class MDNN(nn.Module):
+    LL_LIMIT = 1.0e5     # limit log likelihood to avoid large gradients
+    MIN_WEIGHT = 1.0e-5  # minimum component weights to enable updates
+    EPS_NOISE = 1.e-5    # small noise e.g. for numerical stability
+    VERBOSE = True       # print the 6 train/test losses per call like the reference
+    USE_GRAPH = True     # replay the update from a HIP graph
+
+    def __init__(self, input_dim, output_dim, output_lows, output_highs,
+                 n_gaussians, full_covariance, hidden_layers, activation, lr,
+                 device='cpu', **kwargs):
+        """Same arguments as the reference (mdnn.py:26-52).  ``device`` must
+        name a GPU for anything beyond construction."""
+        super(MDNN, self).__init__()
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.output_lows = None
+        self.output_highs = None
+        if output_lows is not None:
+            self.output_lows = torch.from_numpy(np.asarray(output_lows)).float().to(device)
+            self.output_highs = torch.from_numpy(np.asarray(output_highs)).float().to(device)
+        self.n_gaussians = n_gaussians
+        self.activation = activation
+        self.lr = lr
+        self.device = device
+        if activation not in _ACT_CODES:
+            raise NotImplementedError('activation %r has no HIP epilogue' % (activation,))
+        # Same submodules, created in the same order on the CPU so that the
+        # torch-RNG initialisation matches the reference bit for bit
+        # (mdnn.py:68-86), then flattened onto the device.
+        net = OrderedDict()
+        width = input_dim
+        for l, layer_size in enumerate(hidden_layers):
+            net['fcon%d' % l] = nn.Linear(width, layer_size)
+            net['nl%d' % l] = activation()
+            width = layer_size
+        self.net = nn.Sequential(net) if len(hidden_layers) > 0 else None
+        self.pi = nn.Linear(width, n_gaussians)
+        self.mu = nn.Linear(width, output_dim * n_gaussians)
+        self.Diag = nn.Sequential(nn.Linear(width, output_dim * n_gaussians))
+        self.Lower = None
+        self.L_size = int(0.5 * output_dim * (output_dim - 1))
+        if self.L_size > 0 and full_covariance:
+            self.Lower = nn.Linear(width, self.L_size * n_gaussians)
+        self._hidden = [int(h) for h in hidden_layers]
+        self._rff_feats = int(kwargs.get('_rff_feats', 0))
+        self._rff_scale = float(kwargs.get('_rff_scale', 0.0))
+        self._plan = None
+        self._plan_key = None
+        self._bufs = {}
+        self._dp = None
+        self._flatten(device)
+
+    # ------------------------------------------------------------ plumbing
+    def _cfg(self):
+        cfg = _lib.MdnCfg()
+        cfg.input_dim = int(self.input_dim)
+        cfg.n_hidden = len(self._hidden)
+        for i, h in enumerate(self._hidden):
+            cfg.hidden[i] = h
+        cfg.activation = _ACT_CODES[self.activation]
+        cfg.rff_feats = self._rff_feats
+        cfg.rff_cos_only = 0
+        cfg.rff_scale = self._rff_scale
+        cfg.head.out_dim = int(self.output_dim)
+        cfg.head.n_comp = int(self.n_gaussians)
+        cfg.head.full_cov = 1 if self.Lower is not None else 0
+        cfg.head.eps_noise = float(type(self).EPS_NOISE)
+        cfg.head.min_weight = float(type(self).MIN_WEIGHT)
+        cfg.head.ll_limit = float(type(self).LL_LIMIT)
+        cfg.lr, cfg.beta1, cfg.beta2, cfg.adam_eps = float(self.lr), 0.9, 0.999, 1e-8
+        return cfg
+
+    def _linears(self):
+        mods = [self.net[2 * l] for l in range(len(self._hidden))]
+        mods += [self.pi, self.mu, self.Diag[0]]
+        if self.Lower is not None:
+            mods.append(self.Lower)
+        return mods
+
+    def _flatten(self, device):
+        """Move every parameter into one flat fp32 buffer (layout:
+        bsig_mdn_param_offsets) and re-point the nn.Parameters at views."""
+        lib = _lib.load()
+        cfg = self._cfg()
+        total = int(lib.bsig_mdn_param_count(C.byref(cfg)))
+        assert total > 0, lib.bsig_last_error().decode()
+        n_off = 2 * (len(self._hidden) + 4)
+        offs = (C.c_int64 * n_off)()
+        _lib.check(lib.bsig_mdn_param_offsets(C.byref(cfg), offs, n_off))
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        grads = torch.zeros(total, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for i, mod in enumerate(self._linears()):
+                for j, prm in enumerate((mod.weight, mod.bias)):
+                    o = int(offs[2 * i + j])
+                    view = flat[o:o + prm.numel()].view(prm.shape)
+                    view.copy_(prm.detach().to(dtype=torch.float32))
+                    prm.data = view
+                    prm.grad = grads[o:o + prm.numel()].view(prm.shape)
+        self._flat, self._flat_grad = flat, grads
+        self._exp_avg = torch.zeros_like(flat)
+        self._exp_avg_sq = torch.zeros_like(flat)
+        if self.output_lows is not None:
+            self.output_lows = self.output_lows.to(device)
+            self.output_highs = self.output_highs.to(device)
+        self.device = str(device) if not isinstance(device, str) else device
+        self._drop_plan()
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        prm = next(self.parameters())
+        if prm.dtype != torch.float32:
+            raise NotImplementedError('the HIP estimator computes in fp32 only')
+        self._flatten(prm.device)
+        return self
+
+    def _drop_plan(self):
+        if getattr(self, '_plan', None):
+            _lib.load().bsig_fit_destroy(self._plan)
+        self._plan, self._plan_key = None, None
+        self._bufs = {}
+
+    def __del__(self):
+        try:
+            self._drop_plan()
+        except Exception:
+            pass
+
+    def _gpu(self):
+        lib = _lib.require_gpu()
+        if not self._flat.is_cuda:
+            raise RuntimeError("MDNN was built with device=%r: the estimator runs on "
+                               "MI355X only, construct it with device='cuda:N' "
+                               "(no CPU fallback)" % (self.device,))
+        return lib
+
+    def _buf(self, name, numel, dtype=torch.float32):
+        t = self._bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty(max(int(numel), 1), dtype=dtype, device=self._flat.device)
+            self._bufs[name] = t
+        return t
+
+    def _rff_args(self):
+        return None, 0, None   # (coeff, ld_coeff, offset); MDRFF overrides
+
+    def _seed(self):
+        """A fresh Philox seed drawn from torch's global RNG (the reference
+        consumes the torch RNG for rand_like, mdnn.py:116)."""
+        if type(self).EPS_NOISE == 0.0:
+            return 0
+        return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+    # ----------------------------------------------------------- forward
+    def _head_forward(self, x):
+        lib = self._gpu()
+        cfg = self._cfg()
+        xs, ldx = _lib.as_f32_rows(x, self._flat.device)
+        assert xs.shape[1] == self.input_dim
+        b = xs.shape[0]
+        nh = int(lib.bsig_head_width(C.byref(cfg.head)))
+        out = torch.empty((b, nh), dtype=torch.float32, device=xs.device)
+        ws_bytes = int(lib.bsig_mdn_workspace_bytes(C.byref(cfg), b))
+        ws = self._buf('fwd_ws', ws_bytes // 4 + 1)
+        coeff, ldc, off = self._rff_args()
+        _lib.check(lib.bsig_mdn_head_forward(
+            C.byref(cfg), _lib.ptr(self._flat), _lib.ptr(coeff), ldc, _lib.ptr(off),
+            _lib.ptr(xs), ldx, None, b, _lib.ptr(out), nh, _lib.ptr(ws),
+            ws.numel() * 4, _lib.stream()))
+        return cfg, out
+
+    def forward(self, x, noise=None):
+        """Reference mdnn.py:89-125 -> (weights[B,K], mu[B,D,K], L_d[B,D,K],
+        L[B,L_size,K] | None).  ``noise`` injects the rand_like draw."""
+        lib = self._gpu()
+        cfg, out = self._head_forward(x)
+        b, d, k = out.shape[0], self.output_dim, self.n_gaussians
+        dev = out.device
+        weights = torch.empty((b, k), dtype=torch.float32, device=dev)
+        mu = torch.empty((b, d, k), dtype=torch.float32, device=dev)
+        l_d = torch.empty((b, d, k), dtype=torch.float32, device=dev)
+        low = None
+        if self.Lower is not None:
+            low = torch.empty((b, self.L_size, k), dtype=torch.float32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = self._buf('head_ws', 64 + int(lib.bsig_head_workspace_bytes(C.byref(cfg.head), b)) // 4)
+        nz = None if noise is None else noise.to(dev, torch.float32).contiguous()
+        _lib.check(lib.bsig_mdn_head_outputs(
+            C.byref(cfg.head), _lib.ptr(out), out.stride(0), b, _lib.ptr(nz),
+            self._seed(), 0, _lib.ptr(weights), _lib.ptr(mu), _lib.ptr(l_d),
+            _lib.ptr(low), _lib.ptr(flag), _lib.ptr(ws), ws.numel() * 4, _lib.stream()))
+        assert int(flag.item()) == 0      # isfinite asserts, mdnn.py:120-124
+        return weights, mu, l_d, low
+
+    def mdn_loss_fn(self, weights, mu, L_d, L, y):
+        """Reference mdnn.py:127-178 -> 0-dim loss tensor."""
+        lib = self._gpu()
+        cfg = self._cfg()
+        dev = self._flat.device
+        b = y.size()[0]
+        ys, ldy = _lib.as_f32_rows(y, dev)
+        w = weights.to(dev, torch.float32).contiguous()
+        m = mu.to(dev, torch.float32).contiguous()
+        s = L_d.to(dev, torch.float32).contiguous()
+        lo = None if L is None else L.to(dev, torch.float32).contiguous()
+        head = cfg.head
+        head.full_cov = 0 if lo is None else 1
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = self._buf('head_ws', 64 + int(lib.bsig_head_workspace_bytes(C.byref(head), b)) // 4)
+        _lib.check(lib.bsig_mdn_nll_from_tuple(
+            C.byref(head), _lib.ptr(w), _lib.ptr(m), _lib.ptr(s), _lib.ptr(lo),
+            _lib.ptr(ys), ldy, b, _lib.ptr(loss), _lib.ptr(flag), _lib.ptr(ws),
+            ws.numel() * 4, _lib.stream()))
+        assert int(flag.item()) == 0      # mdnn.py:172-174
+        return loss[0]
+
+    def loss_and_grad(self, x, y, rows=None, noise=None, norm_batch=None):
+        """forward + mdn_loss_fn + backward for one minibatch
+        (mdnn.py:229-233): returns the 0-dim loss; gradients land in every
+        parameter's ``.grad`` (views of the flat gradient buffer).  ``y`` is
+        already normalised."""
+        lib = self._gpu()
+        cfg = self._cfg()
+        dev = self._flat.device
+        xs, ldx = _lib.as_f32_rows(x, dev)
+        ys, ldy = _lib.as_f32_rows(y, dev)
+        ridx = None
+        b = xs.shape[0]
+        if rows is not None:
+            ridx = torch.as_tensor(rows, dtype=torch.int32, device=dev).contiguous()
+            b = ridx.numel()
+        ws_bytes = int(lib.bsig_mdn_workspace_bytes(C.byref(cfg), b))
+        ws = self._buf('grad_ws', ws_bytes // 4 + 1)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        nz = None if noise is None else noise.to(dev, torch.float32).contiguous()
+        coeff, ldc, off = self._rff_args()
+        _lib.check(lib.bsig_mdn_loss_grad(
+            C.byref(cfg), _lib.ptr(self._flat), _lib.ptr(coeff), ldc, _lib.ptr(off),
+            _lib.ptr(xs), ldx, _lib.ptr(ys), ldy, _lib.ptr(ridx), b,
+            int(norm_batch or b), _lib.ptr(nz), self._seed(), 0,
+            _lib.ptr(self._flat_grad), _lib.ptr(loss), _lib.ptr(flag), _lib.ptr(ws),
+            ws.numel() * 4, _lib.stream()))
+        assert int(flag.item()) == 0
+        return loss[0]
+
+    def adam_step(self, t):
+        """One torch.optim.Adam step (defaults) over the flat buffers; t is
+        the 1-based step number since the optimizer was created."""
+        lib = self._gpu()
+        _lib.check(lib.bsig_adam_flat(
+            _lib.ptr(self._flat), _lib.ptr(self._flat_grad), _lib.ptr(self._exp_avg),
+            _lib.ptr(self._exp_avg_sq), self._flat.numel(), float(self.lr), 0.9, 0.999,
+            1e-8, int(t), _lib.stream()))
+
+    # ---------------------------------------------------------- training
+    def enable_data_parallel(self, group=None):
+        """Shard run_training's minibatch over the ranks of ``group``: every
+        rank keeps a full replica, computes the gradient of its B/R rows and
+        the flat gradient buffer is all-reduced (RCCL) before the identical
+        Adam step.  Parameters are broadcast from rank 0."""
+        self._dp = _dp.DataParallel(group)
+        self._dp.broadcast(self._flat)
+        return self
+
+    def run_training(self, x_data, y_data, n_updates, batch_size, test_frac=0.2,
+                     ids_table=None):
+        """Reference mdnn.py:180-243.  Returns {'train_loss': [...],
+        'test_loss': [...]} with the same 6 logging points.  ``ids_table``
+        [n_updates, batch] (optional) overrides the numpy-RNG minibatch draw
+        (teacher forcing for parity tests)."""
+        assert x_data.shape[0] == y_data.shape[0]
+        lib = self._gpu()
+        self.train()
+        cfg = self._cfg()
+        dev = self._flat.device
+        d, n_tot = self.output_dim, x_data.shape[0]
+        n_train = max(int(n_tot * (1.0 - test_frac)), 1)
+        n_test = n_tot - n_train
+        xs, ldx_src = _lib.as_f32_rows(x_data, dev)
+        ys, ldy_src = _lib.as_f32_rows(y_data, dev)
+        assert xs.shape[1] == self.input_dim and ys.shape[1] == d
+        st = _lib.stream()
+        # chunk staging: fixed addresses (graph replay) and 16-B aligned rows
+        ldx, ldy = _lib.round_up(self.input_dim, 4), _lib.round_up(d, 4)
+        cap = self._bufs.get('cap_rows', 0)
+        if n_tot > cap:
+            self._bufs.pop('x_stage', None), self._bufs.pop('y_stage', None)
+            self._bufs['cap_rows'] = n_tot
+        x_stage = self._buf('x_stage', self._bufs['cap_rows'] * ldx)
+        y_stage = self._buf('y_stage', self._bufs['cap_rows'] * ldy)
+        _lib.check(lib.bsig_copy_rows(_lib.ptr(xs), ldx_src, None, _lib.ptr(x_stage), ldx,
+                                      n_tot, self.input_dim, st))
+        if self.output_lows is not None:                       # mdnn.py:204-205
+            _lib.check(lib.bsig_normalize_rows(
+                _lib.ptr(ys), ldy_src, _lib.ptr(self.output_lows),
+                _lib.ptr(self.output_highs), _lib.ptr(y_stage), ldy, n_tot, d, st))
+        else:
+            _lib.check(lib.bsig_copy_rows(_lib.ptr(ys), ldy_src, None, _lib.ptr(y_stage),
+                                          ldy, n_tot, d, st))
+        # minibatch ids in the reference's numpy-RNG order (mdnn.py:219-222)
+        if ids_table is None:
+            ids_np = np.random.randint(0, n_train, (n_updates, batch_size))
+        else:
+            ids_np = np.asarray(ids_table)
+            assert ids_np.shape == (n_updates, batch_size)
+        ids_host = torch.from_numpy(ids_np.astype(np.int32))
+        ids_dev = self._buf('ids', max(ids_host.numel(), 1), torch.int32)
+        ids_dev[:ids_host.numel()].copy_(ids_host.reshape(-1), non_blocking=True)
+        every = max(n_updates // 5, 1)
+        eval_its = [it for it in range(n_updates)
+                    if it % every == 0 or it + 1 == n_updates]
+        train_loss = self._buf('train_loss', n_updates)
+        test_loss = self._buf('test_loss', len(eval_its))
+        state = self._buf('state', 16, torch.int32)
+        # plan (graphs) keyed by everything baked into the captured kernels
+        key = (batch_size, max(n_test, self._bufs.get('cap_test', 0)), cfg.head.eps_noise,
+               cfg.lr, cfg.head.min_weight, cfg.head.ll_limit)
+        if self._plan is None or self._plan_key != key:
+            if self._plan:
+                lib.bsig_fit_destroy(self._plan)
+            handle = C.c_void_p()
+            _lib.check(lib.bsig_fit_create(C.byref(cfg), batch_size, key[1], C.byref(handle)))
+            self._plan, self._plan_key = handle, key
+            self._bufs['cap_test'] = key[1]
+        ws = self._buf('fit_ws', int(lib.bsig_fit_workspace_bytes(self._plan)) // 4 + 1)
+        coeff, ldc, off = self._rff_args()
+        fb = _lib.FitBuffers()
+        fb.params, fb.grads = self._flat.data_ptr(), self._flat_grad.data_ptr()
+        fb.exp_avg, fb.exp_avg_sq = self._exp_avg.data_ptr(), self._exp_avg_sq.data_ptr()
+        fb.rff_coeff = None if coeff is None else coeff.data_ptr()
+        fb.ld_coeff = ldc
+        fb.rff_offset = None if off is None else off.data_ptr()
+        fb.x_train, fb.ldx_train, fb.n_train = x_stage.data_ptr(), ldx, n_train
+        fb.y_train, fb.ldy_train = y_stage.data_ptr(), ldy
+        fb.x_test, fb.ldx_test, fb.n_test = x_stage.data_ptr() + 4 * n_train * ldx, ldx, n_test
+        fb.y_test, fb.ldy_test = y_stage.data_ptr() + 4 * n_train * ldy, ldy
+        fb.ids_table = ids_dev.data_ptr()
+        fb.train_loss, fb.test_loss = train_loss.data_ptr(), test_loss.data_ptr()
+        fb.state = state.data_ptr()
+        fb.workspace, fb.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        _lib.check(lib.bsig_fit_bind(self._plan, C.byref(fb), 1 if type(self).USE_GRAPH else 0))
+        world = 1 if self._dp is None else self._dp.world
+        _lib.check(lib.bsig_fit_begin(self._plan, self._seed(), batch_size * world, st))
+        if self._dp is None:
+            _lib.check(lib.bsig_fit_run(self._plan, n_updates, st))
+        else:
+            eval_set = set(eval_its)
+            _dp.run_updates(
+                n_updates, eval_set,
+                grad=lambda: _lib.check(lib.bsig_fit_grad(self._plan, st)),
+                allreduce=lambda: self._dp.allreduce_sum(self._flat_grad),
+                apply=lambda: _lib.check(lib.bsig_fit_apply(self._plan, st)),
+                evaluate=lambda: _lib.check(lib.bsig_fit_eval(self._plan, st)))
+        # single read-back per call: 6+6 losses and the isfinite flag
+        tl = train_loss[:n_updates]
+        te = test_loss[:len(eval_its)]
+        if self._dp is not None:
+            tl, te = self._dp.mean_losses(tl, te, n_test)
+        host = torch.cat([tl[eval_its] if eval_its else tl[:0], te,
+                          state[2:3].to(torch.float32)]).cpu().tolist()
+        n_e = len(eval_its)
+        train_list, test_list, bad = host[:n_e], host[n_e:2 * n_e], host[2 * n_e]
+        assert bad == 0, 'non-finite value in forward / loss (mdnn.py:120-124,162-174)'
+        if n_test == 0:
+            test_list = [float('nan')] * n_e   # mean over an empty test split
+        if type(self).VERBOSE:
+            for a, b in zip(train_list, test_list):
+                print(f'loss: train {a:0.4f} test {b:0.4f}')
+        return {'train_loss': train_list, 'test_loss': test_list}
+
+    fit = run_training   # the north-star name for the same call
+
+    def normalize_samples(self, params):
+        """Reference mdnn.py:245-248."""
+        lib = self._gpu()
+        ps, ldp = _lib.as_f32_rows(params, self._flat.device)
+        out = torch.empty_like(ps)
+        _lib.check(lib.bsig_normalize_rows(
+            _lib.ptr(ps), ldp, _lib.ptr(self.output_lows), _lib.ptr(self.output_highs),
+            _lib.ptr(out), out.stride(0), ps.shape[0], ps.shape[1], _lib.stream()))
+        return out
+
+    def predict_MoGs(self, xs, noise=None):
+        """Reference mdnn.py:250-289: one pdf.MoG per row of ``xs`` with
+        de-normalised means and [diag | strict-lower] factors.  The
+        full-covariance row indexing bug of mdnn.py:281 (``L[:, :, comp_id]``
+        instead of ``L[pt, :, comp_id]``) is not reproduced."""
+        ntest, dim = xs.size()
+        w, mu, l_d, low = self.forward(xs, noise=noise)
+        w, mu, l_d = w.cpu().numpy(), mu.cpu().numpy(), l_d.cpu().numpy()
+        low = None if low is None else low.cpu().numpy()
+        normalize = self.output_lows is not None
+        if normalize:
+            lows = self.output_lows.cpu().numpy()
+            rng = self.output_highs.cpu().numpy() - lows
+        rows, _ = np.tril_indices(self.output_dim, -1)
+        mogs = []
+        for pt in range(ntest):
+            ms, ls = [], []
+            for k in range(self.n_gaussians):
+                m = mu[pt, :, k]
+                diag = l_d[pt, :, k]
+                lower = None if low is None else low[pt, :, k]
+                if normalize:           # Rng * T: row i scaled by rng[i]
+                    m = m * rng + lows
+                    diag = diag * rng
+                    lower = None if lower is None else lower * rng[rows]
+                ms.append(m.astype(np.float32))
+                ls.append((diag if lower is None else np.concatenate([diag, lower]))
+                          .astype(np.float32))
+            mogs.append(pdf.MoG(a=w[pt, :], ms=ms, Ls=ls))
+        return mogs

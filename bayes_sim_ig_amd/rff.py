@@ -1,0 +1,153 @@
+"""Random Fourier Features on MI355X — mirror of the reference's
+bayes_sim_ig/models/rff.py (class RFF, same constructor and attributes).
+
+The frequency draw is host-side, one-off and consumes the GLOBAL numpy RNG
+exactly like the reference (rff.py:111-120, 135-184), so seeded runs get
+bit-identical frequencies.  The projection ``a*[cos|sin](x (freqs/sigma)^T)``
+(rff.py:122-132) is the fp32-MFMA GEMM with fused sincos epilogue in
+csrc/gemm_f32.hip.
+"""
+import numpy as np
+import torch
+from scipy.special import erfinv
+
+from . import _lib
+
+_STUDENT_NU = {'Laplace': 1, 'Matern12': 1, 'Matern32': 3, 'Matern52': 5}
+
+
+def _first_primes(n):
+    primes, cand = [], 2
+    while len(primes) < n:
+        if all(cand % p for p in primes if p * p <= cand):
+            primes.append(cand)
+        cand += 1
+    return primes
+
+
+def halton_points(m, d):
+    """Plain Halton sequence, points 1..m, in (0,1)^d.  The reference uses
+    ``ghalton.GeneralizedHalton(EA_PERMS)`` (rff.py:113-116) — a third-party
+    module whose permutation tables are not available here; this is a
+    documented stand-in (PARITY UNPINNED for input_dim <= 100; pass ``freqs=``
+    to inject the reference's frequencies)."""
+    out = np.empty((m, d))
+    for j, base in enumerate(_first_primes(d)):
+        for i in range(1, m + 1):
+            f, r, k = 1.0, 0.0, i
+            while k > 0:
+                f /= base
+                r += f * (k % base)
+                k //= base
+            out[i - 1, j] = r
+    return out
+
+
+def _inv_cdf(kernel, u):
+    """Spectral-density inverse CDFs, rff.py:139-184."""
+    if kernel == 'RBF':
+        return erfinv(2 * u - 1) * np.sqrt(2)
+    if kernel in ('Laplace', 'Matern12'):
+        return np.tan(np.pi * (u - 0.5))
+    if kernel == 'Matern32':
+        return (2 * u - 1) / np.sqrt(2 * u * (1 - u))
+    alpha = 4 * u * (1 - u)
+    p = 4 * np.cos(np.arccos(np.sqrt(alpha)) / 3) / np.sqrt(alpha)
+    return np.sign(u - 0.5) * np.sqrt(p - 4)
+
+
+def draw_freqs(kernel, m, d, quasi_random):
+    """rff.py:111-120."""
+    if kernel != 'RBF' and kernel not in _STUDENT_NU:
+        raise ValueError("Kernel {} is not recognised.".format(kernel))
+    if quasi_random:
+        return _inv_cdf(kernel, halton_points(m, d))
+    if kernel == 'RBF':
+        return np.random.normal(0.0, 1.0, (m, d))
+    nu = _STUDENT_NU[kernel]
+    g = np.random.normal(0, 1, (m, d))
+    return g * np.sqrt(nu / np.random.chisquare(nu, (m, d)))
+
+
+class RFF:
+    """Random Fourier Features, vanilla or quasi-random (reference rff.py:43-132).
+
+    Attributes kept from the reference: n_feat, d, sigma [1,d], freqs
+    [m,d], offset, a, device, to_features.
+    """
+
+    def __init__(self, n_feat, d, sigma, cos_only=False, quasi_random=True,
+                 kernel='RBF', device='cpu', freqs=None):
+        self.n_feat, self.d, self.device = n_feat, int(d), device
+        self.cos_only = bool(cos_only)
+        if isinstance(sigma, list):
+            assert len(sigma) == d
+            sig = np.array(sigma, dtype=np.float32)
+        else:
+            sig = np.ones(d, dtype=np.float32) * sigma
+        self.sigma = torch.from_numpy(sig).float().reshape(1, -1).to(device)
+        if kernel != 'RBF' and kernel not in _STUDENT_NU:
+            raise ValueError("Kernel {} is not recognised.".format(kernel))
+        self.offset = None
+        if cos_only:
+            f = draw_freqs(kernel, n_feat, d, quasi_random) if freqs is None else freqs
+            self.offset = torch.from_numpy(
+                2.0 * np.pi * np.random.rand(1, n_feat)).float().to(device)
+            self.a = np.sqrt(1.0 / float(n_feat))
+            self.to_features = self._to_cos_only_features
+        else:
+            assert self.n_feat % 2 == 0
+            f = draw_freqs(kernel, n_feat // 2, d, quasi_random) if freqs is None else freqs
+            self.a = np.sqrt(1.0 / float(n_feat / 2))
+            self.to_features = self._to_cos_sin_features
+        self.freqs = torch.from_numpy(np.asarray(f)).float().to(device)
+        self._coeff = None       # freqs / sigma, [m, ld] device, built lazily
+        self._ws = None
+
+    # -- device-side state -------------------------------------------------
+    @property
+    def m_feat(self):
+        return self.freqs.shape[0]
+
+    def coeff(self, sigma=None):
+        """freqs / sigma (rff.py:124,130), pitch rounded up to 4 floats."""
+        lib = _lib.require_gpu()
+        if sigma is not None or self._coeff is None:
+            dev = self.freqs.device if self.freqs.is_cuda else torch.device(
+                'cuda', torch.cuda.current_device())
+            fr = self.freqs.to(dev).contiguous()
+            sg = (self.sigma if sigma is None else sigma).to(dev).float().contiguous()
+            ld = _lib.round_up(self.d, 4)
+            co = torch.empty((self.m_feat, ld), dtype=torch.float32, device=dev)
+            _lib.check(lib.bsig_rff_coeff(_lib.ptr(fr), _lib.ptr(sg), _lib.ptr(co),
+                                          self.m_feat, self.d, ld, _lib.stream()))
+            if sigma is not None:
+                return co
+            self._coeff = co
+        return self._coeff
+
+    def _project(self, x, sigma, cos_only):
+        lib = _lib.require_gpu()
+        home = x.device
+        co = self.coeff(sigma)
+        xs, ldx = _lib.as_f32_rows(x, co.device)
+        b = xs.shape[0]
+        assert xs.shape[1] == self.d
+        feats = torch.empty((b, self.n_feat), dtype=torch.float32, device=co.device)
+        need = int(lib.bsig_gemm_workspace_bytes(b, self.m_feat, self.d))
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = torch.empty(max(need // 4 + 1, 1), dtype=torch.float32,
+                                   device=co.device)
+        off = self.offset.to(co.device).contiguous() if cos_only else None
+        _lib.check(lib.bsig_rff_project(
+            _lib.ptr(xs), ldx, None, _lib.ptr(co), co.stride(0), _lib.ptr(off),
+            _lib.ptr(feats), feats.stride(0), b, self.d, self.m_feat,
+            float(self.a), 1 if cos_only else 0, _lib.ptr(self._ws),
+            self._ws.numel() * 4, _lib.stream()))
+        return feats if home == feats.device else feats.to(home)
+
+    def _to_cos_only_features(self, x, sigma=None):
+        return self._project(x, sigma, True)
+
+    def _to_cos_sin_features(self, x, sigma=None):
+        return self._project(x, sigma, False)

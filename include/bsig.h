@@ -1,0 +1,264 @@
+/*
+ * bsig.h — C ABI of libbsig_hip.so: the MI355X (gfx950) implementation of the
+ * BayesSim posterior-estimator training path of NVlabs/bayes-sim-ig.
+ *
+ * The reference has no FFI for this path: the boundary is Python duck typing
+ * inside bayes_sim_ig/bayes_sim.py (it builds MDNN / MDRFF and a summary_*
+ * function by name, bayes_sim.py:56,82, and calls run_training / predict_MoGs,
+ * bayes_sim.py:108-113,134).  Each entry point below replaces the PyTorch op
+ * sequence at the cited reference lines; the Python mirror in
+ * bayes_sim_ig_amd/ binds them with ctypes (INTEGRATION.md shows the stub a
+ * reference maintainer would add).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 / int32 unless stated;
+ *   - `ld*` are leading dimensions in ELEMENTS (row pitch), >= the row width;
+ *   - every call is asynchronous on `stream` (a hipStream_t), never allocates,
+ *     never synchronises unless stated, and returns BSIG_OK or a negative
+ *     code; `bsig_last_error()` gives the thread-local message;
+ *   - row-major everywhere.
+ */
+#ifndef BSIG_H
+#define BSIG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bsig_stream_t; /* hipStream_t */
+
+#define BSIG_OK 0
+#define BSIG_EINVAL (-1)       /* bad argument (the reference would assert) */
+#define BSIG_ELAUNCH (-2)      /* HIP launch / runtime failure */
+#define BSIG_EUNSUPPORTED (-3) /* shape outside what the kernels cover */
+#define BSIG_ENONFINITE (-4)   /* device-side isfinite flag was raised */
+
+const char* bsig_last_error(void);
+int bsig_version(void);
+/* Number of devices visible to the library, or a negative code. */
+int bsig_device_count(void);
+
+/* ------------------------------------------------------------------ */
+/* Trajectory summarizers  (bayes_sim_ig/utils/summarizers.py)         */
+/* states [n, t_states, sd], actions [n, t_actions, ad], contiguous.   */
+/* out [n, ld_out]; only the first F columns of each row are written.  */
+/* ------------------------------------------------------------------ */
+
+/* Width F of the summary (no device work). kind: 0 start/waypts(max_t=10),
+ * 1 corr, 2 corrdiff, 3 signature with depth (0 = reference rule). */
+int64_t bsig_summary_dim(int kind, int traj_len, int sd, int ad, int depth);
+
+/* summary_start / summary_waypts, summarizers.py:65-87 (+ the crop/pad of
+ * :20-62; every trajectory repeats its own last step when shorter). */
+int bsig_summary_start(const float* states, const float* actions, float* out,
+                       int64_t n, int t_states, int t_actions, int sd, int ad,
+                       int max_t, int64_t ld_out, bsig_stream_t stream);
+
+/* cross_correlation, summarizers.py:90-122 (summary_corr: use_state_diff=0,
+ * summary_corrdiff: 1).  `nonfinite` (int32, may be NULL) is OR-ed with 1 if
+ * any feature is non-finite (the reference asserts, :120). */
+int bsig_crosscorr(const float* states, const float* actions, float* out,
+                   int64_t n, int t_states, int t_actions, int sd, int ad,
+                   int use_state_diff, int64_t ld_out, int32_t* nonfinite,
+                   bsig_stream_t stream);
+
+/* summary_signatory, summarizers.py:144-168: truncated signature (levels
+ * 1..depth, signatory layout) of the time-augmented path [l+1 | s_l | a_l].
+ * depth 1..3; depth 3 needs 1+sd+ad <= 32, depth 2 needs <= 160. */
+int bsig_signature(const float* states, const float* actions, float* out,
+                   int64_t n, int length, int sd, int ad, int depth,
+                   int64_t ld_out, bsig_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* fp32 MFMA GEMM with fused epilogues (v_mfma_f32_32x32x2_f32)        */
+/* C[m,n] = epi( sum_k A(m,k) * B(n,k) )                               */
+/*   a_kmajor = 0: A(m,k) = A[arow(m)*lda + k]   (k contiguous)        */
+/*   a_kmajor = 1: A(m,k) = A[arow(k)*lda + m]   (m contiguous)        */
+/*   arow(i) = a_rows ? a_rows[i] : i   (row gather, mdnn.py:222)      */
+/*   likewise for B.                                                   */
+/* ------------------------------------------------------------------ */
+enum {
+  BSIG_EPI_NONE = 0,
+  BSIG_EPI_BIAS = 1,      /* + bias[n]                                  */
+  BSIG_EPI_BIAS_ACT = 2,  /* act(acc + bias[n])   nn.Linear + activation */
+  BSIG_EPI_COS_SIN = 3,   /* C[m,n]=alpha*cos(acc), C[m,N+n]=alpha*sin(acc)
+                             (rff.py:128-132); ldc >= 2N                 */
+  BSIG_EPI_COS_OFF = 4,   /* alpha*cos(acc + bias[n])   (rff.py:122-126) */
+  BSIG_EPI_MUL_DACT = 5   /* acc * act'(aux[m*ldaux+n]) with aux = act output */
+};
+enum { BSIG_ACT_TANH = 0, BSIG_ACT_RELU = 1, BSIG_ACT_LEAKY_RELU = 2,
+       BSIG_ACT_SIGMOID = 3, BSIG_ACT_IDENTITY = 4 };
+
+size_t bsig_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
+
+int bsig_gemm_f32(const float* a, int64_t lda, int a_kmajor, const int32_t* a_rows,
+                  const float* b, int64_t ldb, int b_kmajor, const int32_t* b_rows,
+                  float* c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+                  int epilogue, int act, const float* bias, const float* aux,
+                  int64_t ldaux, float alpha, void* workspace, size_t workspace_bytes,
+                  bsig_stream_t stream);
+
+/* RFF projection, rff.py:128-132 / :122-126: feats = a*[cos|sin](x coeff^T)
+ * with coeff = freqs / sigma [m_feat, in_dim] precomputed by bsig_rff_coeff.
+ * x_rows gathers minibatch rows (may be NULL). cos_only uses `offset[m_feat]`. */
+int bsig_rff_coeff(const float* freqs, const float* sigma, float* coeff,
+                   int64_t m_feat, int64_t in_dim, int64_t ld_coeff,
+                   bsig_stream_t stream);
+int bsig_rff_project(const float* x, int64_t ldx, const int32_t* x_rows,
+                     const float* coeff, int64_t ld_coeff, const float* offset,
+                     float* feats, int64_t ld_feats, int64_t batch, int64_t in_dim,
+                     int64_t m_feat, float a, int cos_only, void* workspace,
+                     size_t workspace_bytes, bsig_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* Mixture-density head  (bayes_sim_ig/models/mdnn.py:108-178)         */
+/* head_out [B, ld] = [logits K | mu D*K | pre_diag D*K | lower Ls*K], */
+/* index d*K+k inside each block (mdnn.py:112-119).                    */
+/* ------------------------------------------------------------------ */
+typedef struct bsig_head_dims {
+  int32_t out_dim;   /* D */
+  int32_t n_comp;    /* K */
+  int32_t full_cov;  /* 1: Ls = D(D-1)/2 strict-lower entries per component */
+  float eps_noise;   /* MDNN.EPS_NOISE  (mdnn.py:24)  */
+  float min_weight;  /* MDNN.MIN_WEIGHT (mdnn.py:23)  */
+  float ll_limit;    /* MDNN.LL_LIMIT   (mdnn.py:22)  */
+} bsig_head_dims;
+
+int64_t bsig_head_width(const bsig_head_dims* dims);          /* Nh */
+size_t bsig_head_workspace_bytes(const bsig_head_dims* dims, int64_t batch);
+
+/* forward() tuple from raw head outputs, mdnn.py:109-119.  `noise` [B,D,K]
+ * is the injected rand_like draw (NULL: Philox noise from seed/stream_id). */
+int bsig_mdn_head_outputs(const bsig_head_dims* dims, const float* head_out,
+                          int64_t ld, int64_t batch, const float* noise,
+                          uint64_t seed, uint64_t stream_id, float* weights,
+                          float* mu, float* l_d, float* lower, int32_t* nonfinite,
+                          void* workspace, size_t workspace_bytes,
+                          bsig_stream_t stream);
+
+/* mdn_loss_fn(weights, mu, L_d, L, y), mdnn.py:127-178 -> loss[0]. */
+int bsig_mdn_nll_from_tuple(const bsig_head_dims* dims, const float* weights,
+                            const float* mu, const float* l_d, const float* lower,
+                            const float* y, int64_t ldy, int64_t batch, float* loss,
+                            int32_t* nonfinite, void* workspace,
+                            size_t workspace_bytes, bsig_stream_t stream);
+
+/* Fused forward()+mdn_loss_fn (+ autograd backward when d_head_out != NULL)
+ * on raw head outputs: loss[0] = mean NLL over `batch` rows; d_head_out
+ * [B, ld] = d(sum_b nll_b / norm_batch)/d head_out (norm_batch = batch for
+ * one rank, the global batch under data parallelism).  y rows may be gathered
+ * by y_rows. */
+int bsig_mdn_head_nll(const bsig_head_dims* dims, const float* head_out, int64_t ld,
+                      const float* y, int64_t ldy, const int32_t* y_rows,
+                      int64_t batch, int64_t norm_batch, const float* noise,
+                      uint64_t seed, uint64_t stream_id, float* loss,
+                      float* d_head_out, int32_t* nonfinite, void* workspace,
+                      size_t workspace_bytes, bsig_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* Flat-buffer helpers                                                 */
+/* ------------------------------------------------------------------ */
+/* torch.optim.Adam step (mdnn.py:203,234), t = 1-based step number. */
+int bsig_adam_flat(float* params, const float* grads, float* exp_avg,
+                   float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int64_t t, bsig_stream_t stream);
+/* out[j] = sum_i x[i*ld + j]  (bias gradients). */
+int bsig_colsum(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
+                void* workspace, size_t workspace_bytes, bsig_stream_t stream);
+/* normalize_samples, mdnn.py:245-248: out = (theta - lows) / (highs - lows). */
+int bsig_normalize_rows(const float* theta, int64_t ld_in, const float* lows,
+                        const float* highs, float* out, int64_t ld_out, int64_t rows,
+                        int64_t cols, bsig_stream_t stream);
+/* dst[i, :cols] = src[rows ? rows[i] : i, :cols]  (strided copy / gather). */
+int bsig_copy_rows(const float* src, int64_t ld_src, const int32_t* rows, float* dst,
+                   int64_t ld_dst, int64_t n_rows, int64_t cols, bsig_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* Estimator + fit engine (MDNN / MDRFF construct, forward, run_training) */
+/* ------------------------------------------------------------------ */
+#define BSIG_MAX_HIDDEN 8
+
+typedef struct bsig_mdn_cfg {
+  int32_t input_dim;               /* width of a summary row (I)            */
+  int32_t n_hidden;                /* trunk layers; 0 for MDRFF             */
+  int32_t hidden[BSIG_MAX_HIDDEN]; /* mdnn.py:68-75                         */
+  int32_t activation;              /* BSIG_ACT_*                            */
+  int32_t rff_feats;               /* 0: MDNN; else n_feat (mdrff.py:14-24) */
+  int32_t rff_cos_only;
+  float rff_scale;                 /* a = sqrt(2/n_feat)  (rff.py:107)      */
+  bsig_head_dims head;
+  float lr, beta1, beta2, adam_eps; /* torch.optim.Adam defaults, mdnn.py:203 */
+} bsig_mdn_cfg;
+
+/* Flat parameter layout, state_dict order: net.fcon{l}.weight, .bias ...,
+ * then the head block [pi | mu | Diag.0 | Lower] weights (contiguous rows:
+ * one [Nh, F] matrix), then the head biases [Nh].  offsets[2*i], [2*i+1] =
+ * start of weight/bias i (trunk layers first, then pi, mu, Diag.0, Lower). */
+int64_t bsig_mdn_param_count(const bsig_mdn_cfg* cfg);
+int bsig_mdn_param_offsets(const bsig_mdn_cfg* cfg, int64_t* offsets, int n_offsets);
+size_t bsig_mdn_workspace_bytes(const bsig_mdn_cfg* cfg, int64_t max_batch);
+
+/* head_out[B, Nh] = heads(trunk(x)) (or heads(rff(x))): mdnn.py:108-119
+ * without the softmax/exp (apply bsig_mdn_head_outputs / _head_nll). */
+int bsig_mdn_head_forward(const bsig_mdn_cfg* cfg, const float* params,
+                          const float* rff_coeff, int64_t ld_coeff,
+                          const float* rff_offset, const float* x, int64_t ldx,
+                          const int32_t* x_rows, int64_t batch, float* head_out,
+                          int64_t ld_head, void* workspace, size_t workspace_bytes,
+                          bsig_stream_t stream);
+
+/* One forward + NLL + backward over a minibatch: flat `grads` (same layout
+ * as params; fully overwritten) and loss[0].  mdnn.py:229-233. */
+int bsig_mdn_loss_grad(const bsig_mdn_cfg* cfg, const float* params,
+                       const float* rff_coeff, int64_t ld_coeff,
+                       const float* rff_offset, const float* x, int64_t ldx,
+                       const float* y, int64_t ldy, const int32_t* rows,
+                       int64_t batch, int64_t norm_batch, const float* noise,
+                       uint64_t seed, uint64_t stream_id, float* grads, float* loss,
+                       int32_t* nonfinite, void* workspace, size_t workspace_bytes,
+                       bsig_stream_t stream);
+
+/* Fit engine: MDNN.run_training's loop (mdnn.py:228-242) for one chunk,
+ * replayed from HIP graphs with no host synchronisation.  All buffers are
+ * caller-owned device memory and must stay valid while the plan is bound. */
+typedef struct bsig_fit_buffers {
+  float* params; float* grads; float* exp_avg; float* exp_avg_sq; /* [P]   */
+  const float* rff_coeff; int64_t ld_coeff; const float* rff_offset;
+  const float* x_train; int64_t ldx_train; int64_t n_train;  /* summaries  */
+  const float* y_train; int64_t ldy_train;          /* normalised theta    */
+  const float* x_test; int64_t ldx_test; int64_t n_test;
+  const float* y_test; int64_t ldy_test;
+  const int32_t* ids_table;      /* [n_updates, batch] minibatch row ids   */
+  float* train_loss;             /* [n_updates]  loss of every update      */
+  float* test_loss;              /* [n_evals]                              */
+  int32_t* state;                /* [16] int32 engine state (zeroed by begin) */
+  void* workspace; size_t workspace_bytes;
+} bsig_fit_buffers;
+
+typedef struct bsig_fit_plan bsig_fit_plan;
+
+int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t max_test_rows,
+                    bsig_fit_plan** plan);
+void bsig_fit_destroy(bsig_fit_plan* plan);
+size_t bsig_fit_workspace_bytes(const bsig_fit_plan* plan);
+/* Bind buffers (re-captures graphs only if something changed). */
+int bsig_fit_bind(bsig_fit_plan* plan, const bsig_fit_buffers* buffers, int use_graph);
+/* Reset step counter / Adam state (fresh optimizer per call, mdnn.py:203). */
+int bsig_fit_begin(bsig_fit_plan* plan, uint64_t seed, int64_t norm_batch,
+                   bsig_stream_t stream);
+/* n_updates SGD updates with a held-out evaluation every max(n_updates/5,1)
+ * updates and after the last (mdnn.py:235-242).  Single-rank: gradient and
+ * Adam fused in one graph. */
+int bsig_fit_run(bsig_fit_plan* plan, int64_t n_updates, bsig_stream_t stream);
+/* Data-parallel pieces: gradient only (all-reduce `grads` outside), then Adam. */
+int bsig_fit_grad(bsig_fit_plan* plan, bsig_stream_t stream);
+int bsig_fit_apply(bsig_fit_plan* plan, bsig_stream_t stream);
+int bsig_fit_eval(bsig_fit_plan* plan, bsig_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSIG_H */

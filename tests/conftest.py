@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    # the C-ABI library must exist for the load/symbol tests and the host
+    # logic; build it once if this checkout has not been built yet
+    lib = os.path.join(ROOT, 'bayes_sim_ig_amd', 'lib', 'libbsig_hip.so')
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(['bash', os.path.join(ROOT, 'build.sh')], check=True, cwd=ROOT)
 
 
 def golden(name):

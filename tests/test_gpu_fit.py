@@ -1,0 +1,284 @@
+"""GPU parity of the fit path: teacher-forced 100-update chunks against the
+reference-generated golden vectors (EPS_NOISE=0, same start weights, same
+minibatch id table), BayesSim end to end on the reference's own pendulum
+fixture, graph replay == direct launches, and size-independent properties at
+BASELINE sizes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def B():
+    import bayes_sim_ig_amd as pkg
+    pkg._lib.require_gpu()
+    pkg.MDNN.VERBOSE = False
+    return pkg
+
+
+@pytest.fixture(autouse=True)
+def _eps_guard():
+    import bayes_sim_ig_amd as pkg
+    old = pkg.MDNN.EPS_NOISE
+    yield
+    pkg.MDNN.EPS_NOISE = old
+    pkg.MDNN.USE_GRAPH = True
+
+
+CHUNKS = {
+    'mdnn_start': dict(cls='MDNN', summarizer='summary_start', d=2, k=10,
+                       hidden=(24, 24), full=False),
+    'mdnn_corrdiff_full': dict(cls='MDNN', summarizer='summary_corrdiff', d=3, k=3,
+                               hidden=(16, 16), full=True),
+    'mdrff_corrdiff': dict(cls='MDRFF', summarizer='summary_corrdiff', d=4, k=4,
+                           hidden=[], full=False),
+}
+
+
+def _chunk_model(B, tag, g, input_dim):
+    kw = CHUNKS[tag]
+    d = kw['d']
+    common = dict(input_dim=input_dim, output_dim=d, output_lows=np.zeros(d),
+                  output_highs=np.ones(d), n_gaussians=kw['k'],
+                  full_covariance=kw['full'], lr=float(g['lr']),
+                  activation=torch.nn.Tanh, device=DEV)
+    if kw['cls'] == 'MDRFF':
+        m = B.MDRFF(n_feat=200, sigma=4.0, freqs=g['rff.freqs'], **common)
+    else:
+        m = B.MDNN(hidden_layers=kw['hidden'], **common)
+    m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items()
+                       if k.startswith('w0.')})
+    return m
+
+
+@pytest.mark.parametrize('tag', list(CHUNKS))
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_teacher_forced_chunk_matches_reference(B, tag, use_graph):
+    g = golden('chunk_%s.npz' % tag)
+    B.MDNN.EPS_NOISE = 0.0
+    B.MDNN.USE_GRAPH = use_graph
+    states = torch.from_numpy(g['states']).to(DEV)
+    actions = torch.from_numpy(g['actions']).to(DEV)
+    theta = torch.from_numpy(g['theta']).to(DEV)
+    summ = getattr(B.summarizers, CHUNKS[tag]['summarizer'])(states, actions)
+    np.testing.assert_allclose(summ.cpu().numpy(), g['summaries'], rtol=1e-6, atol=1e-7)
+    m = _chunk_model(B, tag, g, summ.shape[1])
+    logs = m.run_training(summ, theta, int(g['n_updates']), int(g['batch']),
+                          ids_table=g['ids'])
+    # north-star tolerance: held-out NLL within 1e-4 relative
+    np.testing.assert_allclose(logs['test_loss'], g['test_loss'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(logs['train_loss'], g['train_loss'], rtol=1e-4, atol=1e-5)
+    n_train = int(states.shape[0] * 0.8)
+    mog = m.predict_MoGs(summ[n_train:n_train + 1])[0]
+    # fitted MoG weights / means / covariances within 1e-4 relative (+ tiny abs)
+    np.testing.assert_allclose(mog.a, g['mog.a'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(np.stack([c.m for c in mog.xs]), g['mog.ms'],
+                               rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(np.stack([c.S for c in mog.xs]), g['mog.Ss'],
+                               rtol=2e-4, atol=1e-7)
+    nll = -mog.eval(g['theta'][n_train:n_train + 1].astype(np.float64), log=True)
+    np.testing.assert_allclose(nll, g['mog.nll_true'], rtol=1e-4, atol=1e-5)
+
+
+def test_graph_replay_equals_direct_launches(B):
+    g = golden('chunk_mdnn_start.npz')
+    B.MDNN.EPS_NOISE = 0.0
+    states = torch.from_numpy(g['states']).to(DEV)
+    actions = torch.from_numpy(g['actions']).to(DEV)
+    theta = torch.from_numpy(g['theta']).to(DEV)
+    summ = B.summary_start(states, actions)
+    out = []
+    for use_graph in (True, False, True):
+        B.MDNN.USE_GRAPH = use_graph
+        m = _chunk_model(B, 'mdnn_start', g, summ.shape[1])
+        logs = m.run_training(summ, theta, 100, 100, ids_table=g['ids'])
+        out.append((logs, m._flat.clone()))
+    for logs, flat in out[1:]:
+        assert logs == out[0][0]                  # bitwise: same kernels, same order
+        assert torch.equal(flat, out[0][1])
+
+
+def test_second_call_uses_fresh_optimizer_and_same_plan(B):
+    """run_training twice on one model: Adam state restarts (mdnn.py:203) and
+    the result equals the oracle doing the same."""
+    from oracle import estimators as oest
+    g = golden('chunk_mdnn_start.npz')
+    B.MDNN.EPS_NOISE = 0.0
+    states, actions = torch.from_numpy(g['states']), torch.from_numpy(g['actions'])
+    theta = torch.from_numpy(g['theta'])
+    summ = B.summary_start(states.to(DEV), actions.to(DEV))
+    m = _chunk_model(B, 'mdnn_start', g, 40)
+    o = oest.OracleMDNN(input_dim=40, output_dim=2, output_lows=np.zeros(2),
+                        output_highs=np.ones(2), n_gaussians=10, full_covariance=False,
+                        hidden_layers=(24, 24), activation=torch.nn.Tanh,
+                        lr=float(g['lr']), eps_noise=0.0)
+    o.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w0.')})
+    ids2 = np.random.RandomState(3).randint(0, 200, (40, 50))
+    for ids, nu, bs in ((g['ids'], 100, 100), (ids2, 40, 50)):
+        lg = m.run_training(summ, theta.to(DEV), nu, bs, ids_table=ids)
+        lo = o.run_training(summ.cpu(), theta, nu, bs, ids_table=ids)
+        np.testing.assert_allclose(lg['test_loss'], lo['test_loss'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(lg['train_loss'], lo['train_loss'], rtol=1e-4, atol=1e-5)
+
+
+def test_numpy_rng_minibatch_stream(B):
+    """Without ids_table the global numpy RNG is consumed exactly like the
+    reference's n_updates sequential randint calls (mdnn.py:221)."""
+    g = golden('chunk_mdnn_start.npz')
+    B.MDNN.EPS_NOISE = 0.0
+    summ = B.summary_start(torch.from_numpy(g['states']).to(DEV),
+                           torch.from_numpy(g['actions']).to(DEV))
+    theta = torch.from_numpy(g['theta']).to(DEV)
+    m1 = _chunk_model(B, 'mdnn_start', g, 40)
+    np.random.seed(21 + 7)           # the seed make_golden.py used for the ids
+    l1 = m1.run_training(summ, theta, 100, 100)
+    after = np.random.randint(0, 1 << 30)
+    np.random.seed(21 + 7)
+    for _ in range(100):
+        np.random.randint(0, 200, 100)
+    assert after == np.random.randint(0, 1 << 30)
+    np.testing.assert_allclose(l1['test_loss'], g['test_loss'], rtol=1e-4, atol=1e-5)
+
+
+def test_bayessim_on_reference_pendulum_fixture(B):
+    """The reference's own regression data through BayesSim.run_training /
+    predict (regression_tests.py:46-89, one run_training call)."""
+    g = golden('pendulum_ref.npz')
+    B.MDNN.EPS_NOISE = 0.0
+    n = g['params'].shape[0]
+    sa = torch.from_numpy(g['data']).reshape(n, -1, 4).to(DEV)
+    cfg = {'modelClass': 'MDNN', 'summarizerFxn': 'summary_start', 'trainTrajLen': 10,
+           'components': 10, 'hiddenLayers': (128, 128), 'lr': 5e-4}
+    bsim = B.BayesSim(model_cfg=cfg, obs_dim=3, act_dim=1, params_dim=2,
+                      params_lows=np.array([0.01] * 2), params_highs=np.array([2.0] * 2),
+                      prior=None, proposal=None, device=DEV)
+    bsim.model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items()
+                                if k.startswith('w0.')})
+    np.random.seed(9)
+    logs = bsim.run_training(torch.from_numpy(g['params']).to(DEV), sa[:, :, :3].contiguous(),
+                             sa[:, :, 3:].contiguous())
+    np.testing.assert_allclose(logs['test_loss'], g['test_loss'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(logs['train_loss'], g['train_loss'], rtol=1e-4, atol=1e-5)
+    tsa = torch.from_numpy(g['true_data']).reshape(1, -1, 4).to(DEV)
+    mog = bsim.predict(tsa[:, :, :3].contiguous(), tsa[:, :, 3:].contiguous())
+    nll = -mog.eval(g['true_params'].reshape(1, -1).astype(np.float64), log=True)
+    np.testing.assert_allclose(nll, g['mog.nll_true'], rtol=2e-4)
+    np.testing.assert_allclose(mog.a, g['mog.a'], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(np.stack([c.m for c in mog.xs]), g['mog.ms'], rtol=2e-4, atol=2e-5)
+
+
+def test_bayessim_multi_trajectory_refit_runs(B):
+    g = golden('pendulum_ref.npz')
+    sa = torch.from_numpy(g['data'][:300]).reshape(300, -1, 4).to(DEV)
+    cfg = {'modelClass': 'MDRFF_Matern32_2.0', 'summarizerFxn': 'summary_corrdiff',
+           'trainTrajLen': 10, 'components': 3, 'hiddenLayers': (16,), 'lr': 1e-3,
+           'nFeat': 64}
+    np.random.seed(1)
+    torch.manual_seed(1)
+    bsim = B.BayesSim(model_cfg=cfg, obs_dim=3, act_dim=1, params_dim=2,
+                      params_lows=np.array([0.01] * 2), params_highs=np.array([2.0] * 2),
+                      prior=None, device=DEV, proposal=None)
+    logs = bsim.fit(torch.from_numpy(g['params'][:300]).to(DEV), sa[:, :, :3].contiguous(),
+                    sa[:, :, 3:].contiguous())
+    assert len(logs) == 1 and len(logs[0]['test_loss']) == 6
+    assert np.isfinite(logs[0]['test_loss']).all()
+    tsa = torch.from_numpy(g['true_data']).reshape(1, -1, 4).to(DEV).repeat(2, 1, 1)
+    mog = bsim.predict(tsa[:, :, :3].contiguous(), tsa[:, :, 3:].contiguous())
+    assert mog.ndim == 2 and np.isfinite(mog.eval(np.array([[1.0, 0.5]]))).all()
+
+
+def test_jitter_noise_path_is_finite_and_seeded(B):
+    """EPS_NOISE = 1e-5 (the reference default) with in-kernel Philox noise:
+    same torch seed -> identical run; different seed -> ~1e-5-level change."""
+    g = golden('chunk_mdnn_start.npz')
+    B.MDNN.EPS_NOISE = 1e-5
+    summ = B.summary_start(torch.from_numpy(g['states']).to(DEV),
+                           torch.from_numpy(g['actions']).to(DEV))
+    theta = torch.from_numpy(g['theta']).to(DEV)
+    res = []
+    for seed in (5, 5, 6):
+        torch.manual_seed(seed)
+        m = _chunk_model(B, 'mdnn_start', g, 40)
+        res.append(m.run_training(summ, theta, 100, 100, ids_table=g['ids'])['test_loss'])
+    assert res[0] == res[1]
+    assert res[0] != res[2]
+    np.testing.assert_allclose(res[0], res[2], rtol=5e-3)
+    np.testing.assert_allclose(res[0], g['test_loss'], rtol=5e-3)   # vs EPS=0 golden
+
+
+# ---- size-independent properties at BASELINE sizes ---------------------------
+def test_summary_start_full_size_rows(B):
+    n, t, sd, ad = 100_000, 11, 211, 20
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    s = torch.randn(n, t, sd, device=DEV, generator=gen)
+    a = torch.rand(n, t, ad, device=DEV, generator=gen)
+    out = B.summary_start(s, a)
+    assert out.shape == (n, 2310)
+    ref = torch.cat([s[:, :10], a[:, :10]], -1).reshape(n, -1)
+    assert torch.equal(out, ref)             # pure copy: bit-exact, every row
+
+
+def test_crosscorr_full_size_properties(B):
+    n, t, sd, ad = 20_000, 51, 60, 8          # Ant-sized rows (cfg3), 0.94 GB out
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    s = torch.randn(n, t, sd, device=DEV, generator=gen)
+    a = torch.rand(n, t, ad, device=DEV, generator=gen)
+    out = B.summary_corrdiff(s, a)
+    assert out.shape == (n, 11802)
+    sf = (s[:, :5, 1:] - s[:, :5, :-1]).reshape(n, -1)
+    af = a[:, :5].reshape(n, -1)
+    idx = torch.randint(0, n, (64,), device=DEV)
+    ref = (sf[idx].unsqueeze(2) * af[idx].unsqueeze(1)).reshape(64, -1)
+    assert torch.equal(out[idx, :-2], ref)
+    # linearity in the actions: corr(s, 2a) == 2 corr(s, a) exactly (power of 2)
+    out2 = B.summary_corrdiff(s[:1000], 2 * a[:1000])
+    assert torch.equal(out2[:, :-2], 2 * out[:1000, :-2])
+    assert torch.equal(out2[:, -2:], out[:1000, -2:])
+    torch.testing.assert_close(out[:, -2], sf.mean(1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out[:, -1], sf.std(1), rtol=1e-5, atol=1e-6)
+
+
+def test_signature_full_size_properties(B):
+    n, t, sd, ad = 50_000, 11, 17, 4          # 22 channels, depth 3 -> 11154 wide
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    s = torch.randn(n, t, sd, device=DEV, generator=gen)
+    a = torch.rand(n, t, ad, device=DEV, generator=gen)
+    out = B.summary_signatory(s, a)
+    d = 22
+    assert out.shape == (n, d + d * d + d ** 3)
+    l1 = out[:, :d]
+    l2 = out[:, d:d + d * d].reshape(n, d, d)
+    # level 1 = total increment; shuffle identity S1_i S1_j = S2_ij + S2_ji
+    torch.testing.assert_close(l1[:, 1:18], s[:, -1] - s[:, 0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(l1[:, :, None] * l1[:, None, :], l2 + l2.transpose(1, 2),
+                               rtol=1e-4, atol=2e-4)
+    # invariance to re-parametrisation is broken by the time channel, but
+    # reversing time negates odd levels of the non-time channels' level 1
+    l3 = out[:, d + d * d:].reshape(n, d, d, d)
+    sym = l3 + l3.permute(0, 1, 3, 2) + l3.permute(0, 2, 3, 1)   # ijk + ikj + kij
+    torch.testing.assert_close(l2[:, :, :, None] * l1[:, None, None, :], sym,
+                               rtol=1e-4, atol=1e-3)
+
+
+def test_rff_gemm_full_size_against_torch(B):
+    """cfg5-shaped projection at a scaled batch vs torch fp64 on sampled rows."""
+    b, i, mf = 8192, 2310, 2048
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(b, i, device=DEV, generator=gen) * 0.3
+    np.random.seed(4)
+    rff = B.RFF(2 * mf, i, 4.0, quasi_random=False, device=DEV)
+    feats = rff.to_features(x)
+    assert feats.shape == (b, 2 * mf)
+    idx = torch.randint(0, b, (32,), device=DEV)
+    inner = x[idx].double() @ (rff.freqs.double() / rff.sigma.double()).T
+    ref = rff.a * torch.cat([torch.cos(inner), torch.sin(inner)], 1)
+    torch.testing.assert_close(feats[idx].double(), ref, rtol=0, atol=5e-6)
+    # cos^2 + sin^2 = a^2 for every feature pair, every row
+    torch.testing.assert_close(feats[:, :mf] ** 2 + feats[:, mf:] ** 2,
+                               torch.full((b, mf), float(rff.a) ** 2, device=DEV),
+                               rtol=1e-5, atol=1e-8)
