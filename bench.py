@@ -1,0 +1,350 @@
+#!/usr/bin/env python3
+"""bench.py — summary-vectors/sec in fit() on MI355X (BASELINE.json metric).
+
+One "step" = one BayesSim.fit() pass over this rank's synthetic (theta,
+trajectory) pairs following the reference chunk protocol
+(bayes_sim_main.py:157-167 + bayes_sim.py:20-25): per <=1000-pair chunk the
+summarizer, then 100 Adam updates of minibatch 100 (fresh optimizer) and 6
+held-out evaluations.  Inputs are resident in HBM before the timed region.
+value = pairs processed by all ranks / wall time (max over ranks).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# (task, model, summarizer, T+1, sd, ad, D, K, hidden, n_feat) — SURVEY.md §8 table
+CONFIGS = {
+    'cfg2': dict(task='Cartpole', model='MDRFF', summarizer='summary_corrdiff', t=21, sd=4,
+                 ad=1, d=13, k=10, hidden=[], n_feat=1024, pairs=10_000),
+    'cfg3': dict(task='Ant', model='MDNN', summarizer='summary_corrdiff', t=51, sd=60, ad=8,
+                 d=17, k=5, hidden=[128, 128], n_feat=0, pairs=50_000),
+    'cfg4': dict(task='ShadowHand', model='MDNN', summarizer='summary_signatory', t=11,
+                 sd=211, ad=20, d=32, k=4, hidden=[128, 128], n_feat=0, pairs=25_000),
+    'cfg5': dict(task='ShadowHand', model='MDRFF', summarizer='summary_start', t=11, sd=211,
+                 ad=20, d=32, k=4, hidden=[], n_feat=4096, pairs=100_000),
+}
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_F32_TFLOPS = 157.3    # fp32 MFMA (= vector) peak
+
+
+def synth_pairs(cfg, n, seed, device):
+    """Seeded theta-dependent synthetic pairs: theta~U(0,1)^D,
+    a_t~U[0,1), s_0~0.1 N(0,1), s_{t+1} = 0.9 s_t + 0.1 tanh(theta W1) +
+    0.1 (a_t B) * tanh(theta W2) + 0.01 xi."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    gw = torch.Generator(device=device).manual_seed(4242)      # dynamics shared by all ranks
+    d, sd, ad, t = cfg['d'], cfg['sd'], cfg['ad'], cfg['t']
+    w1 = torch.randn(d, sd, device=device, generator=gw) / d ** 0.5
+    w2 = torch.randn(d, sd, device=device, generator=gw) / d ** 0.5
+    bm = torch.randn(ad, sd, device=device, generator=gw) / ad ** 0.5
+    theta = torch.rand(n, d, device=device, generator=g)
+    actions = torch.rand(n, t, ad, device=device, generator=g)
+    states = torch.empty(n, t, sd, device=device)
+    s = 0.1 * torch.randn(n, sd, device=device, generator=g)
+    drift, gain = 0.1 * torch.tanh(theta @ w1), 0.1 * torch.tanh(theta @ w2)
+    for i in range(t):
+        states[:, i] = s
+        s = 0.9 * s + drift + (actions[:, i] @ bm) * gain \
+            + 0.01 * torch.randn(n, sd, device=device, generator=g)
+    return theta, states, actions
+
+
+def model_cfg(cfg):
+    return {'modelClass': cfg['model'], 'summarizerFxn': cfg['summarizer'],
+            'trainTrajLen': cfg['t'], 'components': cfg['k'],
+            'hiddenLayers': cfg['hidden'], 'lr': 1e-3, 'nFeat': cfg['n_feat']}
+
+
+def build_gpu_model(pkg, cfg, device, seed):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    return pkg.BayesSim(model_cfg=model_cfg(cfg), obs_dim=cfg['sd'], act_dim=cfg['ad'],
+                        params_dim=cfg['d'], params_lows=np.zeros(cfg['d']),
+                        params_highs=np.ones(cfg['d']), prior=None, proposal=None,
+                        device=device)
+
+
+def build_oracle(cfg, in_dim, seed, eps_noise, freqs=None):
+    from oracle import estimators as oest
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    kw = dict(input_dim=in_dim, output_dim=cfg['d'], output_lows=np.zeros(cfg['d']),
+              output_highs=np.ones(cfg['d']), n_gaussians=cfg['k'], full_covariance=False,
+              lr=1e-3, activation=torch.nn.Tanh, eps_noise=eps_noise)
+    if cfg['model'] == 'MDRFF':
+        if freqs is None:
+            freqs = np.random.normal(0.0, 1.0, (cfg['n_feat'] // 2, in_dim))
+        return oest.OracleMDRFF(n_feat=cfg['n_feat'], sigma=4.0, freqs=freqs, **kw)
+    return oest.OracleMDNN(hidden_layers=cfg['hidden'], **kw)
+
+
+def cpu_baseline(cfg, theta, states, actions, budget_s=12.0, max_chunks=12):
+    """The oracle ("port" of the reference's PyTorch-CPU path) on a bounded
+    sample of the same pairs, same chunk protocol.  The thread count is
+    calibrated first (the update is ~2000 tiny ATen ops: more threads than a
+    handful only add synchronisation cost) and the best one is used and
+    reported as `cores`."""
+    from oracle import summarize as osum
+    ncpu = os.cpu_count() or 1
+    fn = osum.SUMMARIZERS[cfg['summarizer']]
+    in_dim = osum.summary_dim(cfg['summarizer'], cfg['t'], cfg['sd'], cfg['ad'])
+    th, st, ac = theta.cpu(), states.cpu(), actions.cpu()
+    m0 = min(1000, th.shape[0])
+    summ0 = fn(st[:m0], ac[:m0])
+    best_nt, best_dt = 1, float('inf')
+    for nt in (1, 2, 4, 8, 16, 32):
+        if nt > ncpu:
+            break
+        torch.set_num_threads(nt)
+        model = build_oracle(cfg, in_dim, 1234, 1e-5)
+        model.run_training(summ0, th[:m0], 2, 100)            # warm
+        t0 = time.perf_counter()
+        model.run_training(summ0, th[:m0], 8, 100)
+        dt = time.perf_counter() - t0
+        if dt < best_dt:
+            best_nt, best_dt = nt, dt
+        elif dt > 1.5 * best_dt:
+            break
+    torch.set_num_threads(best_nt)
+    model = build_oracle(cfg, in_dim, 1234, 1e-5)
+    done, chunks, n = 0, 0, th.shape[0]
+    t0 = time.perf_counter()
+    while done < n and chunks < max_chunks:
+        m = min(1000, n - done)
+        summ = fn(st[done:done + m], ac[done:done + m])
+        model.run_training(summ, th[done:done + m], 100, 100)
+        done += m
+        chunks += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {'value': done / dt, 'unit': 'pairs/s', 'cores': best_nt, 'kind': 'port',
+            'sample': '%d pairs (%d chunks of the same synthetic workload, reference chunk '
+                      'protocol) in %.1f s; torch %s CPU, %d threads (best of 1..32 by '
+                      'calibration; host has %d logical CPUs)'
+                      % (done, chunks, dt, torch.__version__, best_nt, ncpu)}
+
+
+def nll_check(pkg, cfg, theta, states, actions, device):
+    """Teacher-forced first chunk, EPS_NOISE=0: held-out NLL of the HIP path
+    vs the oracle from identical weights / minibatch ids."""
+    from oracle import summarize as osum
+    old = pkg.MDNN.EPS_NOISE
+    pkg.MDNN.EPS_NOISE = 0.0
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    try:
+        bs = build_gpu_model(pkg, cfg, device, 77)
+        m = min(1000, theta.shape[0])
+        th, st, ac = theta[:m], states[:m], actions[:m]
+        ids = np.random.RandomState(5).randint(0, max(int(m * 0.8), 1), (100, 100))
+        summ = bs._summarize(st, ac)
+        got = bs.model.run_training(summ, th, 100, 100, ids_table=ids)
+        ora = build_oracle(cfg, summ.shape[1], 77, 0.0,
+                           freqs=bs.model.rff.freqs.cpu().numpy() if cfg['model'] == 'MDRFF' else None)
+        # the oracle starts from the GPU model's start weights: rebuild them
+        bs2 = build_gpu_model(pkg, cfg, device, 77)
+        ora.load_state_dict({k: v.cpu() for k, v in bs2.model.state_dict().items()})
+        if cfg['model'] == 'MDRFF':
+            ora.rff.freqs = bs2.model.rff.freqs.cpu()
+        ref = ora.run_training(osum.SUMMARIZERS[cfg['summarizer']](st.cpu(), ac.cpu()),
+                               th.cpu(), 100, 100, ids_table=ids)
+        g, r = got['test_loss'][-1], ref['test_loss'][-1]
+        return {'heldout_nll_hip': g, 'heldout_nll_oracle': r,
+                'rel_diff': abs(g - r) / max(abs(r), 1e-12),
+                'protocol': 'first chunk, 100 updates teacher-forced, EPS_NOISE=0'}
+    finally:
+        pkg.MDNN.EPS_NOISE = old
+
+
+def time_dominant_kernel(pkg, cfg, bsim, device, reps=200):
+    """HIP-event timing of the dominant kernel of this workload, launched
+    through the C ABI with the shapes of one update, on the stream the fit
+    uses.  cfg with RFF: the projection GEMM (MFMA-bound).  Otherwise the
+    summarizer (HBM-bound)."""
+    lib = pkg._lib.load()
+    stream = torch.cuda.current_stream()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if cfg['model'] == 'MDRFF':
+        rff = bsim.model.rff
+        b, i, mf = 100, rff.d, rff.m_feat
+        x = torch.randn(1000, pkg._lib.round_up(i, 4), device=device)
+        ids = torch.randint(0, 800, (b,), device=device, dtype=torch.int32)
+        co = rff.coeff()
+        feats = torch.empty(b, 2 * mf, device=device)
+        ws = torch.empty(int(lib.bsig_gemm_workspace_bytes(b, mf, i)) // 4 + 1, device=device)
+
+        def launch():
+            pkg._lib.check(lib.bsig_rff_project(
+                pkg._lib.ptr(x), x.stride(0), pkg._lib.ptr(ids), pkg._lib.ptr(co), co.stride(0),
+                None, pkg._lib.ptr(feats), feats.stride(0), b, i, mf, float(rff.a), 0,
+                pkg._lib.ptr(ws), ws.numel() * 4, pkg._lib.stream()))
+        flops = 2.0 * b * i * mf
+        for _ in range(20):
+            launch()
+        start.record(stream)
+        for _ in range(reps):
+            launch()
+        stop.record(stream)
+        stop.synchronize()
+        us = start.elapsed_time(stop) * 1e3 / reps
+        ach = flops / (us * 1e-6) / 1e12
+        return {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel (RFF projection %dx%dx%d + split-K '
+                'reduce/sincos epilogue)' % (b, mf, i), 'achieved': ach,
+                'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
+                'traffic': None, 'avg_us': us,
+                'algorithmic': '2*B*I*M = %.3e flop per launch' % flops}
+    n = 1000
+    th, st, ac = synth_pairs(cfg, n, 999, device)
+    for _ in range(5):
+        out = bsim._summarize(st, ac)
+    start.record(stream)
+    for _ in range(reps // 4):
+        out = bsim._summarize(st, ac)
+    stop.record(stream)
+    stop.synchronize()
+    us = start.elapsed_time(stop) * 1e3 / (reps // 4)
+    sd, ad = cfg['sd'], cfg['ad']
+    if cfg['summarizer'] in ('summary_start', 'summary_waypts'):
+        per_traj = 2 * 4 * 10 * (sd + ad)                       # read + write
+    elif cfg['summarizer'] in ('summary_corr', 'summary_corrdiff'):
+        w = min(5 if sd > 50 else 10, cfg['t'])
+        per_traj = 4 * (w * (sd + ad) + out.shape[1])
+    else:
+        per_traj = 4 * (cfg['t'] * (1 + sd + ad) + out.shape[1])
+    nbytes = float(per_traj) * n
+    ach = nbytes / (us * 1e-6) / 1e9
+    return {'bound': 'hbm', 'kernel': cfg['summarizer'], 'achieved': ach, 'peak': PEAK_HBM_GBS,
+            'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None, 'avg_us': us,
+            'algorithmic': '%.3e bytes per launch (1000 trajectories)' % nbytes}
+
+
+T0 = time.perf_counter()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='cfg5', choices=sorted(CONFIGS))
+    ap.add_argument('--pairs', type=int, default=0, help='pairs per GPU (default: config)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--watchdog', type=int, default=int(os.environ.get('BENCH_WATCHDOG', 1700)),
+                    help='dump tracebacks and exit after this many seconds')
+    ap.add_argument('--verbose', action='store_true')
+    args = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(args.watchdog, exit=True)
+
+    def note(msg):
+        if args.verbose:
+            print('[bench %.1fs] %s' % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+        args.gpus = world
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import bayes_sim_ig_amd as pkg
+    pkg._lib.require_gpu()
+    pkg.MDNN.VERBOSE = False
+    pkg.MDNN.USE_GRAPH = not args.no_graph
+    torch.cuda.set_device(local_rank)
+    device = 'cuda:%d' % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device(device))
+
+    cfg = dict(CONFIGS[args.config])
+    n = args.pairs or cfg['pairs']
+    note('generating pairs')
+    theta, states, actions = synth_pairs(cfg, n, 1234 + rank, device)
+    note('building model')
+    bsim = build_gpu_model(pkg, cfg, device, 1234)
+    if world > 1:
+        bsim.model.enable_data_parallel()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    np.random.seed(1234 + rank)
+    note('warmup')
+    for _ in range(args.warmup):
+        bsim.fit(theta, states, actions)
+        note('warmup fit done')
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logs = bsim.fit(theta, states, actions)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_pairs = n * world * args.steps
+    value = total_pairs / dt
+    final_test = float(np.mean([lg['test_loss'][-1] for lg in logs]))
+
+    out = None
+    if rank == 0:
+        out = {
+            'metric': 'summary_vectors_per_sec_in_fit', 'value': value, 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': '%s: %s %s%s K=%d D=%d, %s (I=%d), %d pairs/GPU, reference chunk '
+                            'protocol: <=1000-pair chunks, summarizer + 100 Adam updates x '
+                            'minibatch %d%s + 6 held-out evals per chunk'
+                            % (args.config, cfg['task'], cfg['model'],
+                               '-%d' % cfg['n_feat'] if cfg['n_feat'] else str(cfg['hidden']),
+                               cfg['k'], cfg['d'], cfg['summarizer'], bsim.model.input_dim, n,
+                               100, ' per rank (global %d, grad all-reduce)' % (100 * world)
+                               if world > 1 else ''),
+                'pairs_per_gpu': n, 'parallelism': 'dp%d' % world,
+                'hip_graph': not args.no_graph},
+            'sgd_visits_per_sec': value * 10.0,
+            'heldout_nll_last_step_mean': final_test,
+        }
+        note('timed region done: %.3f s' % dt)
+        out['roofline'] = time_dominant_kernel(pkg, cfg, bsim, device)
+        note('roofline done')
+        if world == 1:
+            out['nll_match'] = nll_check(pkg, cfg, theta, states, actions, device)
+            note('nll check done')
+            if not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline(cfg, theta[:12000], states[:12000],
+                                                   actions[:12000])
+                out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
