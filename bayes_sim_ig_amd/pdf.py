@@ -14,6 +14,8 @@ Deviations from the reference, on purpose:
     ``__div__``, pdf.py:363,525, so ``mog / proposal`` raises on py3);
   * ``MoG.calc_mean_and_cov`` returns the moment-matched mean/covariance
     (the reference reads a non-existent ``x.sigma``, pdf.py:549-554);
+  * ``MoG.__mul__`` / ``__truediv__`` use the correct product/quotient
+    normaliser (the reference's transcription flips one sign, pdf.py:511,533);
   * Halton sampling uses the plain Halton sequence of rff.halton_points
     (``ghalton`` is not available).
 """
@@ -236,13 +238,19 @@ class MoG:
 
     def _reweighted(self, ys, other, sign):
         """Mixing coefficients after multiplying (sign=+1) or dividing
-        (sign=-1) every component by ``other`` (pdf.py:501-531)."""
+        (sign=-1) every component x by ``other`` (y = x*other or x/other):
+        log c = 1/2 [logdetP_x + s logdetP_o - logdetP_y
+                     - x.m' P_x x.m - s o.m' P_o o.m + y.m' P_y y.m].
+        This is the normaliser of the Gaussian product/quotient (as in the
+        epsilon_free_inference original); the reference's transcription
+        (pdf.py:506-511, 528-533) has the sign of the y term flipped, on a
+        path its callers never reach (proposal=None, bayes_sim_main.py:154)."""
         logc = np.empty_like(self.a, dtype=float)
         for i, (x, y) in enumerate(zip(self.xs, ys)):
             v = x.logdetP + sign * other.logdetP - y.logdetP
             v -= x.m @ x.P @ x.m
-            v += sign * (other.m @ other.P @ other.m)
-            v -= y.m @ y.P @ y.m
+            v -= sign * (other.m @ other.P @ other.m)
+            v += y.m @ y.P @ y.m
             logc[i] = 0.5 * v
         la = np.log(self.a) + logc
         return np.exp(la - logsumexp(la))

@@ -1,0 +1,161 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol
+include/bsig.h declares, the Python mirror keeps the reference's interface
+(state_dict keys, torch-RNG init order, numpy-RNG frequency draw, error
+behaviour) and the product path refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+
+import bayes_sim_ig_amd as B
+from bayes_sim_ig_amd import _lib, pdf
+from oracle import estimators as oest
+
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'bsig.h')).read()
+    declared = set(re.findall(r'\b(bsig_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.exported_symbols())
+    assert _lib.load().bsig_version() >= 100
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, 'bayes_sim_ig_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert 'oracle' not in src.replace('Oracle of record', ''), fn
+
+
+def test_summary_dim_matches_reference_shapes():
+    g = golden('summaries.npz')
+    for case in ('cartpole', 'ant', 'short', 'pendulum'):
+        s, a = g[case + '.states'], g[case + '.actions']
+        for fn in ('summary_start', 'summary_corr', 'summary_corrdiff'):
+            if case + '.' + fn in g:
+                assert B.summarizers.summary_dim(fn, s.shape[1], s.shape[2], a.shape[2]) \
+                    == g[case + '.' + fn].shape[1]
+    for d, depth in zip(g['signature_depth.d'], g['signature_depth.depth']):
+        assert B.signature_depth(int(d)) == int(depth)
+    assert B.summarizers.summary_dim('summary_signatory', 11, 211, 20) == 232
+    assert B.summarizers.summary_dim('summary_signatory', 11, 17, 4) == 22 + 22 ** 2 + 22 ** 3
+
+
+@pytest.mark.parametrize('full', [False, True])
+def test_mdnn_matches_reference_interface(full):
+    kw = dict(input_dim=40, output_dim=3, output_lows=np.zeros(3), output_highs=np.ones(3),
+              n_gaussians=10, full_covariance=full, hidden_layers=(24, 24),
+              activation=torch.nn.Tanh, lr=5e-4)
+    torch.manual_seed(3)
+    m = B.MDNN(device='cpu', **kw)
+    torch.manual_seed(3)
+    o = oest.OracleMDNN(**kw)
+    assert list(m.state_dict()) == list(o.state_dict())
+    for a, b in zip(m.state_dict().values(), o.state_dict().values()):
+        assert torch.equal(a, b)                   # same torch-RNG init order
+    assert m.L_size == 3 and m.n_gaussians == 10 and m.lr == 5e-4
+    assert isinstance(m, torch.nn.Module) and m.activation is torch.nn.Tanh
+    # parameters are views of one flat buffer; load_state_dict writes through
+    sd = {k: torch.full_like(v, 0.25) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    used = sum(p.numel() for p in m.parameters())
+    assert float(m._flat.sum()) == pytest.approx(0.25 * used)
+    assert m._flat.numel() % 4 == 0
+    assert all(p.grad is not None and p.grad.data_ptr() >= m._flat_grad.data_ptr()
+               for p in m.parameters())
+
+
+def test_mdrff_frequency_draw_consumes_numpy_rng_like_reference():
+    np.random.seed(11)
+    m = B.MDRFF(input_dim=302, output_dim=13, output_lows=np.zeros(13),
+                output_highs=np.ones(13), n_gaussians=4, lr=1e-3, activation=torch.nn.Tanh,
+                full_covariance=False, n_feat=64, sigma=4.0)
+    np.random.seed(11)
+    ref = np.random.normal(0.0, 1.0, (32, 302))
+    np.testing.assert_array_equal(m.rff.freqs.numpy(), ref.astype(np.float32))
+    assert m.rff.a == pytest.approx(np.sqrt(2.0 / 64))
+    assert list(m.state_dict()) == ['pi.weight', 'pi.bias', 'mu.weight', 'mu.bias',
+                                    'Diag.0.weight', 'Diag.0.bias']
+    assert m.pi.weight.shape == (4, 64)
+    with pytest.raises(ValueError):
+        B.RFF(64, 302, 4.0, kernel='Bogus', quasi_random=False)
+
+
+@pytest.mark.skipif(not NO_GPU, reason='checks the no-GPU failure mode')
+def test_product_path_fails_loudly_without_gpu():
+    m = B.MDNN(input_dim=4, output_dim=2, output_lows=np.zeros(2), output_highs=np.ones(2),
+               n_gaussians=2, full_covariance=False, hidden_layers=(8,),
+               activation=torch.nn.Tanh, lr=1e-3)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.forward(torch.zeros(3, 4))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.run_training(torch.zeros(10, 4), torch.zeros(10, 2), 2, 2)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        B.summary_start(torch.zeros(1, 12, 3), torch.zeros(1, 12, 1))
+
+
+def test_bayessim_constructs_by_name_like_reference():
+    cfg = {'modelClass': 'MDRFF_Matern52_2.5', 'summarizerFxn': 'summary_corrdiff',
+           'trainTrajLen': 21, 'components': 4, 'hiddenLayers': (128, 128), 'lr': 1e-3}
+    B.MDNN.VERBOSE = False
+    np.random.seed(0)
+    bs = B.BayesSim(model_cfg=cfg, obs_dim=4, act_dim=1, params_dim=13,
+                    params_lows=np.zeros(13), params_highs=np.ones(13), prior=None)
+    assert isinstance(bs.model, B.MDRFF) and bs.model.rff.n_feat == 200
+    assert bs.model.input_dim == 302 and float(bs.model.rff.sigma[0, 0]) == 2.5
+    assert B.BayesSim.NUM_GRAD_UPDATES == 100 and B.BayesSim.MINIBATCH_SIZE == 100
+    assert B.BayesSim.get_n_trajs_per_batch(2500, 2000) == 500
+    with pytest.raises(NameError):
+        B.BayesSim(model_cfg=dict(cfg, summarizerFxn='nope'), obs_dim=4, act_dim=1,
+                   params_dim=13, params_lows=np.zeros(13), params_highs=np.ones(13),
+                   prior=None)
+
+
+def test_compat_aliases():
+    from bayes_sim_ig_amd import compat
+    compat.install()
+    from bayes_sim_ig.bayes_sim import BayesSim
+    from bayes_sim_ig.models.mdnn import MDNN
+    from bayes_sim_ig.models.mdrff import MDRFF
+    from bayes_sim_ig.utils.summarizers import summary_corrdiff
+    from bayes_sim_ig.utils import pdf as p2
+    assert BayesSim is B.BayesSim and MDNN is B.MDNN and MDRFF is B.MDRFF
+    assert summary_corrdiff is B.summary_corrdiff and p2 is pdf
+
+
+def test_pdf_matches_reference():
+    g = golden('pdf_cases.npz')
+    for tag in ('full', 'diag'):
+        mog = pdf.MoG(a=g['a'], ms=list(g['ms']), Ls=list(g['Ls_' + tag]))
+        np.testing.assert_allclose(mog.eval(g['x'], log=True), g['logpdf_' + tag], rtol=1e-12)
+        np.testing.assert_allclose(mog.eval(g['x'], log=False), g['pdf_' + tag], rtol=1e-12)
+        np.testing.assert_allclose(np.stack([c.S for c in mog.xs]), g['S_' + tag], rtol=1e-12)
+        np.testing.assert_allclose(np.stack([c.P for c in mog.xs]), g['P_' + tag], rtol=1e-9)
+        np.testing.assert_allclose([c.logdetP for c in mog.xs], g['logdetP_' + tag], rtol=1e-12)
+        np.random.seed(77)
+        np.testing.assert_allclose(mog.gen(n_samples=50), g['gen_' + tag], rtol=1e-12)
+    mog = pdf.MoG(a=np.array([0.6, 0.001, 0.397, 0.002]), ms=list(g['ms']),
+                  Ls=list(g['Ls_full']))
+    mog.prune_negligible_components(threshold=0.005)
+    np.testing.assert_allclose(mog.a, g['pruned_a'], rtol=1e-14)
+    np.testing.assert_allclose(np.stack([c.m for c in mog.xs]), g['pruned_ms'])
+    uni = pdf.Uniform(np.zeros(3), np.ones(3) * 2.0)
+    np.testing.assert_allclose(uni.eval(g['uniform_x']), g['uniform_logpdf'])
+    np.random.seed(78)
+    np.testing.assert_allclose(uni.gen(n_samples=5), g['uniform_gen'])
+    # product / quotient round trip (py3 __truediv__)
+    prior = pdf.Gaussian(m=np.zeros(3), S=4.0 * np.eye(3))
+    back = (mog * prior) / prior
+    np.testing.assert_allclose(back.a, mog.a, rtol=1e-9)
+    np.testing.assert_allclose(back.xs[0].m, mog.xs[0].m, rtol=1e-8, atol=1e-10)
