@@ -16,6 +16,7 @@ BSIG_OK, BSIG_EINVAL, BSIG_ELAUNCH, BSIG_EUNSUPPORTED, BSIG_ENONFINITE = 0, -1, 
 EPI_NONE, EPI_BIAS, EPI_BIAS_ACT, EPI_COS_SIN, EPI_COS_OFF, EPI_MUL_DACT = range(6)
 ACT_TANH, ACT_RELU, ACT_LEAKY_RELU, ACT_SIGMOID, ACT_IDENTITY = range(5)
 MAX_HIDDEN = 8
+FIT_GRAPH, FIT_SPLIT_ADAM = 1, 2
 
 i64, i32, u64, f32, vp, sz = (C.c_int64, C.c_int32, C.c_uint64, C.c_float,
                               C.c_void_p, C.c_size_t)
@@ -82,7 +83,7 @@ _PROTOS = {
     'bsig_mdn_loss_grad': (C.c_int, [C.POINTER(MdnCfg), vp, vp, i64, vp, vp, i64,
                                      vp, i64, vp, i64, i64, vp, u64, u64, vp, vp,
                                      vp, vp, sz, vp]),
-    'bsig_fit_create': (C.c_int, [C.POINTER(MdnCfg), i64, i64, C.POINTER(vp)]),
+    'bsig_fit_create': (C.c_int, [C.POINTER(MdnCfg), i64, i64, i64, C.POINTER(vp)]),
     'bsig_fit_destroy': (None, [vp]),
     'bsig_fit_workspace_bytes': (sz, [vp]),
     'bsig_fit_bind': (C.c_int, [vp, C.POINTER(FitBuffers), C.c_int]),

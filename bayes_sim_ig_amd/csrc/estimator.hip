@@ -1,36 +1,42 @@
 // MDNN / MDRFF estimator passes and the fit engine.
 //   head forward   : mdnn.py:108-119 (trunk + heads) / mdrff.py:28-30 (RFF first)
 //   loss + grad    : mdnn.py:229-233 (forward, mdn_loss_fn, backward)
-//   fit engine     : mdnn.py:228-242 — the whole update (minibatch gather,
-//                    forward, NLL, backward, Adam) is captured once in a HIP
-//                    graph and replayed per step with no host synchronisation;
-//                    per-step values (minibatch ids, Adam bias corrections,
-//                    loss slot, RNG stream) live in a small device state block
-//                    advanced by the graph's first kernel.
-#include "common.h"
+//   fit engine     : mdnn.py:228-242 — one update (minibatch gather, forward,
+//                    NLL, backward, Adam) is captured once in a HIP graph and
+//                    replayed per step with no host synchronisation.
+//
+// Replay without per-step host work: everything that changes between updates
+// is resolved on the device from a 16-word state block.  The step counter is
+// advanced by the single-writer hook of the head's finishing kernel, which sits
+// between the forward and the backward half of the update: forward kernels read
+// `step`, backward kernels read `step - 1`.  Minibatch rows are looked up in the
+// [n_updates, B] id table (drawn on the host in the reference's numpy-RNG
+// order, mdnn.py:219-222) at row offset step * B by the GEMM loaders and the
+// head kernel themselves — no gather kernel, no copies.
+//
+// MDRFF: the RFF features of a minibatch row depend only on the row, not on
+// the weights, so the projections of ALL minibatches of a run_training call
+// (n_updates * B gathered rows, plus the held-out rows once per evaluation)
+// are computed up front by ONE large fp32-MFMA GEMM — the same rows, the same
+// arithmetic and the same number of row visits as the reference's per-step
+// `rff.to_features(x_batch)` (mdrff.py:29), at large-GEMM efficiency instead of
+// 100 latency-bound M=100 launches.  The per-step graph then starts at the heads.
+//
+// Single rank: Adam is fused into the epilogue of each dW GEMM (weights and,
+// via the column-0 threads, the layer's bias), so an update has no optimizer
+// kernel.  Data parallel: gradients go to the flat buffer, the caller
+// all-reduces it, then one flat Adam kernel runs (bsig_fit_grad / _apply).
+#include "gemm.h"
+#include "head.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
 namespace bsig {
 
-// implemented in the other translation units
-int gemm_f32(const float* a, int64_t lda, int a_kmajor, const int32_t* a_rows,
-             const float* b, int64_t ldb, int b_kmajor, const int32_t* b_rows, float* c,
-             int64_t ldc, int64_t m, int64_t n, int64_t k, int epilogue, int act,
-             const float* bias, const float* aux, int64_t ldaux, float alpha,
-             void* workspace, size_t workspace_bytes, hipStream_t st);
-int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t ld_w,
-                        const float* seg_mu, int64_t ld_mu, const float* seg_sg,
-                        int64_t ld_sg, const float* seg_lo, int64_t ld_lo, int from_tuple,
-                        const float* y, int64_t ldy, const int32_t* y_rows, int64_t batch,
-                        int64_t norm_batch, const float* noise, uint64_t seed,
-                        uint64_t stream_id, const uint64_t* dyn_rng, float* loss,
-                        const int32_t* loss_slot, float* d_out, int64_t ld_dout,
-                        int32_t* nonfinite, void* workspace, size_t workspace_bytes,
-                        hipStream_t st);
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                 float beta1, float beta2, float eps, int64_t t, const float* dyn,
                 hipStream_t st);
@@ -77,7 +83,7 @@ static int make_layout(const bsig_mdn_cfg* c, Layout* L) {
 
 // ---- workspace carve ------------------------------------------------------
 struct Scratch {
-  float* feat;                      // [B, F] RFF features (MDRFF)
+  float* feat;                      // [B, F] RFF features (MDRFF, not hoisted)
   float* h[BSIG_MAX_HIDDEN];        // trunk activations [B, hidden_l]
   float* dz[2];                     // ping-pong [B, max hidden]
   float* o;                         // [B, Nh] raw head outputs
@@ -126,82 +132,152 @@ static void carve(const bsig_mdn_cfg* c, const Layout& L, int64_t B, void* base,
   s->head_ws = take(s->head_ws_bytes / sizeof(float) + 1);
   s->gemm_ws_bytes = gemm_ws_need(c, L, B);
   s->gemm_ws = take(s->gemm_ws_bytes / sizeof(float) + 1);
-  s->colsum_ws_bytes = (size_t)64 * std::max<int64_t>(L.nh, hmax) * sizeof(float);
+  s->colsum_ws_bytes = (size_t)64 * std::max<int64_t>(L.nh, std::max<int64_t>(hmax, 1)) * sizeof(float);
   s->colsum_ws = take(s->colsum_ws_bytes / sizeof(float));
   s->total_bytes = off;
 }
 
 // ---- passes ---------------------------------------------------------------
+// Where the estimator's input rows come from.  Logical minibatch row i reads
+// source index i + (dyn[0] + delta) * dyn_stride + dyn_base, looked up in
+// `rows` when that is given.  With `is_feat` the source already holds RFF
+// features (hoisted projection) and `rows` must be null.
 struct Inputs {
-  const float* x; int64_t ldx; const int32_t* rows;
-  const float* rff_coeff; int64_t ld_coeff; const float* rff_offset;
+  const float* x = nullptr; int64_t ldx = 0;
+  const int32_t* rows = nullptr;
+  const int32_t* dyn = nullptr; int64_t dyn_stride = 0, dyn_base = 0;
+  bool is_feat = false;
+  const float* rff_coeff = nullptr; int64_t ld_coeff = 0; const float* rff_offset = nullptr;
 };
 
-// trunk (or RFF) + heads -> s.o ; leaves activations in s.h / s.feat
+// Adam fused into the dW GEMMs (single rank)
+struct AdamFuse {
+  float* m; float* v; const float* dyn; float beta1, beta2, eps;
+};
+
+static void set_src_a(GemmParams& g, const float* x, int64_t ld, const Inputs* in, int delta) {
+  g.a = x; g.lda = ld; g.a_kmajor = 0;
+  if (in) {
+    g.a_rows = in->rows; g.dyn = in->dyn; g.dyn_delta = delta;
+    g.a_dyn_stride = in->dyn_stride; g.a_dyn_base = in->dyn_base;
+  }
+}
+static void set_src_b_kmajor(GemmParams& g, const float* x, int64_t ld, const Inputs* in,
+                             int delta) {
+  g.b = x; g.ldb = ld; g.b_kmajor = 1;
+  if (in) {
+    g.b_rows = in->rows; g.dyn = in->dyn; g.dyn_delta = delta;
+    g.b_dyn_stride = in->dyn_stride; g.b_dyn_base = in->dyn_base;
+  }
+}
+
+static int rff_project(const bsig_mdn_cfg* c, const Inputs& in, int64_t rows, float* feats,
+                       void* ws, size_t ws_bytes, hipStream_t st) {
+  BSIG_REQUIRE(in.rff_coeff, "MDRFF needs rff_coeff");
+  BSIG_REQUIRE(!(c->rff_cos_only && !in.rff_offset), "cos-only RFF needs an offset");
+  GemmParams g;
+  set_src_a(g, in.x, in.ldx, &in, 0);
+  g.b = in.rff_coeff; g.ldb = in.ld_coeff;
+  g.c = feats; g.ldc = c->rff_feats;
+  g.m = (int)rows; g.n = c->rff_cos_only ? c->rff_feats : c->rff_feats / 2; g.k = c->input_dim;
+  g.epilogue = c->rff_cos_only ? BSIG_EPI_COS_OFF : BSIG_EPI_COS_SIN;
+  g.bias = in.rff_offset; g.alpha = c->rff_scale;
+  return gemm_run(g, ws, ws_bytes, st);
+}
+
+// trunk (or RFF) + heads -> o ; leaves activations in s.h / s.feat
 static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* params,
                         const Inputs& in, int64_t B, const Scratch& s, float* o, int64_t ldo,
                         hipStream_t st) {
-  const float* feat = in.x; int64_t ldf = in.ldx; const int32_t* frows = in.rows;
-  if (c->rff_feats > 0) {
-    BSIG_REQUIRE(in.rff_coeff, "MDRFF needs rff_coeff");
-    const int64_t mf = c->rff_cos_only ? c->rff_feats : c->rff_feats / 2;
-    BSIG_REQUIRE(!(c->rff_cos_only && !in.rff_offset), "cos-only RFF needs an offset");
-    BSIG_TRY(gemm_f32(in.x, in.ldx, 0, in.rows, in.rff_coeff, in.ld_coeff, 0, nullptr, s.feat,
-                      c->rff_feats, B, mf, c->input_dim,
-                      c->rff_cos_only ? BSIG_EPI_COS_OFF : BSIG_EPI_COS_SIN, 0, in.rff_offset,
-                      nullptr, 0, c->rff_scale, s.gemm_ws, s.gemm_ws_bytes, st));
-    feat = s.feat; ldf = c->rff_feats; frows = nullptr;
+  const float* feat = in.x; int64_t ldf = in.ldx; const Inputs* src = &in;
+  if (c->rff_feats > 0 && !in.is_feat) {
+    BSIG_TRY(rff_project(c, in, B, s.feat, s.gemm_ws, s.gemm_ws_bytes, st));
+    feat = s.feat; ldf = c->rff_feats; src = nullptr;
   }
   for (int l = 0; l < L.n_layers; ++l) {
-    BSIG_TRY(gemm_f32(feat, ldf, 0, frows, params + L.w_off[l], L.in_dim[l], 0, nullptr, s.h[l],
-                      c->hidden[l], B, c->hidden[l], L.in_dim[l], BSIG_EPI_BIAS_ACT,
-                      c->activation, params + L.b_off[l], nullptr, 0, 1.f, s.gemm_ws,
-                      s.gemm_ws_bytes, st));
-    feat = s.h[l]; ldf = c->hidden[l]; frows = nullptr;
+    GemmParams g;
+    set_src_a(g, feat, ldf, src, 0);
+    g.b = params + L.w_off[l]; g.ldb = L.in_dim[l];
+    g.c = s.h[l]; g.ldc = c->hidden[l];
+    g.m = (int)B; g.n = c->hidden[l]; g.k = (int)L.in_dim[l];
+    g.epilogue = BSIG_EPI_BIAS_ACT; g.act = c->activation; g.bias = params + L.b_off[l];
+    BSIG_TRY(gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st));
+    feat = s.h[l]; ldf = c->hidden[l]; src = nullptr;
   }
-  BSIG_TRY(gemm_f32(feat, ldf, 0, frows, params + L.head_w_off, L.feat_dim, 0, nullptr, o, ldo,
-                    B, L.nh, L.feat_dim, BSIG_EPI_BIAS, 0, params + L.head_b_off, nullptr, 0,
-                    1.f, s.gemm_ws, s.gemm_ws_bytes, st));
-  return BSIG_OK;
+  GemmParams g;
+  set_src_a(g, feat, ldf, src, 0);
+  g.b = params + L.head_w_off; g.ldb = L.feat_dim;
+  g.c = o; g.ldc = ldo;
+  g.m = (int)B; g.n = (int)L.nh; g.k = (int)L.feat_dim;
+  g.epilogue = BSIG_EPI_BIAS; g.bias = params + L.head_b_off;
+  return gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st);
 }
 
-// backward from s.d_o into the flat gradient buffer
-static int backward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* params,
-                         const Inputs& in, int64_t B, const Scratch& s, float* grads,
-                         hipStream_t st) {
+// dW[nout, nin] = dY^T X (+ fused Adam) for one layer
+static int weight_grad(const float* dy, int64_t nout, const float* xin, int64_t ldin,
+                       const Inputs* src, int delta, int64_t nin, int64_t B, float* params,
+                       float* grads, int64_t w_off, int64_t b_off, const AdamFuse* fuse,
+                       const Scratch& s, hipStream_t st) {
+  GemmParams g;
+  g.a = dy; g.lda = nout; g.a_kmajor = 1;
+  set_src_b_kmajor(g, xin, ldin, src, delta);
+  g.m = (int)nout; g.n = (int)nin; g.k = (int)B; g.ldc = nin;
+  if (fuse) {
+    g.epilogue = EPI_ADAM;
+    g.c = params + w_off; g.adam_m = fuse->m + w_off; g.adam_v = fuse->v + w_off;
+    g.adam_dyn = fuse->dyn; g.beta1 = fuse->beta1; g.beta2 = fuse->beta2; g.adam_eps = fuse->eps;
+    g.bias_p = params + b_off; g.bias_m = fuse->m + b_off; g.bias_v = fuse->v + b_off;
+    g.bias_g = grads + b_off;
+  } else {
+    g.epilogue = BSIG_EPI_NONE;
+    g.c = grads + w_off;
+  }
+  return gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st);
+}
+
+// backward from s.d_o.  Every product that READS a weight matrix is issued
+// before the GEMM that updates it (fused Adam).  `delta` = offset of the step
+// counter seen by these kernels relative to the forward half.
+static int backward_pass(const bsig_mdn_cfg* c, const Layout& L, float* params,
+                         const Inputs& in, int delta, int64_t B, const Scratch& s, float* grads,
+                         const AdamFuse* fuse, hipStream_t st) {
   // input of the heads
-  const float* feat; int64_t ldf; const int32_t* frows = nullptr;
+  const float* feat; int64_t ldf; const Inputs* fsrc = nullptr;
   if (L.n_layers > 0) { feat = s.h[L.n_layers - 1]; ldf = c->hidden[L.n_layers - 1]; }
-  else if (c->rff_feats > 0) { feat = s.feat; ldf = c->rff_feats; }
-  else { feat = in.x; ldf = in.ldx; frows = in.rows; }
-  // dW_heads[Nh, F] = dO^T feat ; db = colsum(dO)
-  BSIG_TRY(gemm_f32(s.d_o, L.nh, 1, nullptr, feat, ldf, 1, frows, grads + L.head_w_off,
-                    L.feat_dim, L.nh, L.feat_dim, B, BSIG_EPI_NONE, 0, nullptr, nullptr, 0, 1.f,
-                    s.gemm_ws, s.gemm_ws_bytes, st));
-  BSIG_TRY(colsum_launch(s.d_o, L.nh, B, L.nh, grads + L.head_b_off, s.colsum_ws,
-                         s.colsum_ws_bytes, st));
-  if (L.n_layers == 0) return BSIG_OK;
-  // dz_L = (dO W_heads) * act'(h_L)
+  else if (c->rff_feats > 0 && !in.is_feat) { feat = s.feat; ldf = c->rff_feats; }
+  else { feat = in.x; ldf = in.ldx; fsrc = &in; }
   int cur = 0;
-  BSIG_TRY(gemm_f32(s.d_o, L.nh, 0, nullptr, params + L.head_w_off, L.feat_dim, 1, nullptr,
-                    s.dz[cur], L.feat_dim, B, L.feat_dim, L.nh, BSIG_EPI_MUL_DACT,
-                    c->activation, nullptr, feat, ldf, 1.f, s.gemm_ws, s.gemm_ws_bytes, st));
+  if (L.n_layers > 0) {   // dz_L = (dO W_heads) * act'(h_L)   [reads W_heads]
+    GemmParams g;
+    g.a = s.d_o; g.lda = L.nh;
+    g.b = params + L.head_w_off; g.ldb = L.feat_dim; g.b_kmajor = 1;
+    g.c = s.dz[cur]; g.ldc = L.feat_dim;
+    g.m = (int)B; g.n = (int)L.feat_dim; g.k = (int)L.nh;
+    g.epilogue = BSIG_EPI_MUL_DACT; g.act = c->activation; g.aux = feat; g.ldaux = ldf;
+    BSIG_TRY(gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st));
+  }
+  // heads: dW = dO^T feat (bias gradient = column sums of dO, from the finish kernel)
+  BSIG_TRY(weight_grad(s.d_o, L.nh, feat, ldf, fsrc, delta, L.feat_dim, B, params, grads,
+                       L.head_w_off, L.head_b_off, fuse, s, st));
   for (int l = L.n_layers - 1; l >= 0; --l) {
     const int64_t hw = c->hidden[l];
-    const float* xin; int64_t ldin; const int32_t* rin = nullptr;
+    const float* xin; int64_t ldin; const Inputs* xsrc = nullptr;
     if (l > 0) { xin = s.h[l - 1]; ldin = c->hidden[l - 1]; }
-    else { xin = in.x; ldin = in.ldx; rin = in.rows; }
-    BSIG_TRY(gemm_f32(s.dz[cur], hw, 1, nullptr, xin, ldin, 1, rin, grads + L.w_off[l],
-                      L.in_dim[l], hw, L.in_dim[l], B, BSIG_EPI_NONE, 0, nullptr, nullptr, 0,
-                      1.f, s.gemm_ws, s.gemm_ws_bytes, st));
+    else { xin = in.x; ldin = in.ldx; xsrc = &in; }
     BSIG_TRY(colsum_launch(s.dz[cur], hw, B, hw, grads + L.b_off[l], s.colsum_ws,
                            s.colsum_ws_bytes, st));
-    if (l > 0) {
-      BSIG_TRY(gemm_f32(s.dz[cur], hw, 0, nullptr, params + L.w_off[l], L.in_dim[l], 1, nullptr,
-                        s.dz[cur ^ 1], L.in_dim[l], B, L.in_dim[l], hw, BSIG_EPI_MUL_DACT,
-                        c->activation, nullptr, xin, ldin, 1.f, s.gemm_ws, s.gemm_ws_bytes, st));
-      cur ^= 1;
+    if (l > 0) {           // dz_{l-1} = (dz_l W_l) * act'(h_{l-1})   [reads W_l]
+      GemmParams g;
+      g.a = s.dz[cur]; g.lda = hw;
+      g.b = params + L.w_off[l]; g.ldb = L.in_dim[l]; g.b_kmajor = 1;
+      g.c = s.dz[cur ^ 1]; g.ldc = L.in_dim[l];
+      g.m = (int)B; g.n = (int)L.in_dim[l]; g.k = (int)hw;
+      g.epilogue = BSIG_EPI_MUL_DACT; g.act = c->activation; g.aux = xin; g.ldaux = ldin;
+      BSIG_TRY(gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st));
     }
+    BSIG_TRY(weight_grad(s.dz[cur], hw, xin, ldin, xsrc, delta, L.in_dim[l], B, params, grads,
+                         L.w_off[l], L.b_off[l], fuse, s, st));
+    cur ^= 1;
   }
   return BSIG_OK;
 }
@@ -210,56 +286,42 @@ static int head_nll(const bsig_mdn_cfg* c, const Layout& L, const Scratch& s, co
                     int64_t ldy, const int32_t* y_rows, int64_t B, int64_t norm_batch,
                     const float* noise, uint64_t seed, uint64_t stream_id,
                     const uint64_t* dyn_rng, float* loss, const int32_t* loss_slot, bool bwd,
-                    int32_t* nonfinite, hipStream_t st) {
+                    float* head_bias_grad, int32_t* nonfinite, const HeadDyn* dyn,
+                    hipStream_t st) {
   const int64_t D = c->head.out_dim, K = c->head.n_comp;
   return mdn_head_nll_launch(&c->head, s.o, L.nh, s.o + K, L.nh, s.o + K + D * K, L.nh,
                              c->head.full_cov ? s.o + K + 2 * D * K : nullptr, L.nh, 0, y, ldy,
                              y_rows, B, norm_batch, noise, seed, stream_id, dyn_rng, loss,
-                             loss_slot, bwd ? s.d_o : nullptr, L.nh, nonfinite, s.head_ws,
-                             s.head_ws_bytes, st);
+                             loss_slot, bwd ? s.d_o : nullptr, L.nh,
+                             bwd ? head_bias_grad : nullptr, nonfinite, s.head_ws,
+                             s.head_ws_bytes, st, dyn);
 }
 
 // ---- fit engine -----------------------------------------------------------
 // device state block (int32 words)
-enum { ST_STEP = 0, ST_EVAL = 1, ST_NONFINITE = 2, ST_CUR_STEP = 3, ST_ADAM0 = 4, ST_ADAM1 = 5,
-       ST_CUR_EVAL = 6, ST_RNG = 8 /* 4 words: seed, counter (uint64 x2) */, ST_WORDS = 16 };
+enum { ST_STEP = 0, ST_EVAL = 1, ST_NONFINITE = 2, ST_ADAM0 = 4, ST_ADAM1 = 5,
+       ST_RNG = 8 /* 4 words: seed, counter (uint64 x2) */, ST_WORDS = 16 };
 
 __global__ void fit_begin_kernel(int32_t* state, uint64_t seed) {
   if (threadIdx.x < ST_WORDS) state[threadIdx.x] = 0;
   __syncthreads();
-  if (threadIdx.x == 0) reinterpret_cast<uint64_t*>(state + ST_RNG)[0] = seed;
-}
-
-// First kernel of every update: publish this step's values, advance counters,
-// copy the minibatch ids (mdnn.py:219-222: ids drawn on the host in the
-// reference's numpy-RNG order, uploaded once per chunk as a table).
-__global__ __launch_bounds__(256) void step_begin_kernel(int32_t* __restrict__ state,
-                                                         const int32_t* __restrict__ ids_table,
-                                                         int32_t* __restrict__ cur_ids,
-                                                         int batch, double beta1, double beta2,
-                                                         double lr) {
-  const int step = state[ST_STEP];
-  for (int i = threadIdx.x; i < batch; i += blockDim.x)
-    cur_ids[i] = ids_table[(int64_t)step * batch + i];
-  __syncthreads();
   if (threadIdx.x == 0) {
-    const double t = (double)(step + 1);
-    const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
-    reinterpret_cast<float*>(state)[ST_ADAM0] = (float)(lr / bc1);
-    reinterpret_cast<float*>(state)[ST_ADAM1] = (float)(1.0 / sqrt(bc2));
-    state[ST_CUR_STEP] = step;
-    state[ST_STEP] = step + 1;
-    reinterpret_cast<uint64_t*>(state + ST_RNG)[1] += 1;
+    reinterpret_cast<uint64_t*>(state + ST_RNG)[0] = seed;
+    reinterpret_cast<uint64_t*>(state + ST_RNG)[1] = 1;
   }
 }
 
-__global__ void eval_begin_kernel(int32_t* state) {
-  if (threadIdx.x == 0) {
-    const int e = state[ST_EVAL];
-    state[ST_CUR_EVAL] = e;
-    state[ST_EVAL] = e + 1;
-    reinterpret_cast<uint64_t*>(state + ST_RNG)[1] += 1;
-  }
+__global__ void iota_mod_kernel(int32_t* out, int n, int mod) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[i] = i % mod;
+}
+
+static int64_t count_evals(int64_t n_updates) {   // mdnn.py:235
+  const int64_t every = std::max<int64_t>(n_updates / 5, 1);
+  int64_t n = 0;
+  for (int64_t it = 0; it < n_updates; ++it)
+    if (it % every == 0 || it + 1 == n_updates) ++n;
+  return n;
 }
 
 }  // namespace bsig
@@ -269,12 +331,14 @@ using namespace bsig;
 struct bsig_fit_plan {
   bsig_mdn_cfg cfg;
   Layout L;
-  int64_t batch, max_test;
+  int64_t batch, max_test, n_updates, n_evals;
+  bool hoist;                  // RFF projection of every minibatch up front
+  int64_t feat_rows;           // n_updates*batch + n_evals*max_test
   bsig_fit_buffers buf;
   bool bound;
   int64_t norm_batch;
-  size_t train_ws_bytes, test_ws_bytes;
-  bool use_graph;
+  size_t train_ws_bytes, test_ws_bytes, feats_bytes, big_gemm_ws_bytes, iota_bytes;
+  bool use_graph, split_adam;
   hipStream_t cap_stream;
   hipGraphExec_t g_step, g_grad, g_apply, g_eval;
 };
@@ -282,36 +346,65 @@ struct bsig_fit_plan {
 namespace bsig {
 
 static size_t plan_ws_bytes(const bsig_fit_plan* p) {
-  // [cur_ids batch][train scratch][eval scratch]
-  return round_up<size_t>((size_t)p->batch * sizeof(int32_t), 256) + p->train_ws_bytes +
-         p->test_ws_bytes;
+  return p->train_ws_bytes + p->test_ws_bytes + p->feats_bytes + p->big_gemm_ws_bytes +
+         p->iota_bytes;
 }
 
-static void plan_scratch(const bsig_fit_plan* p, int32_t** cur_ids, Scratch* tr, Scratch* te) {
+struct PlanMem { Scratch tr, te; float* feats; float* big_ws; int32_t* iota; };
+
+static void plan_mem(const bsig_fit_plan* p, PlanMem* m) {
   char* base = reinterpret_cast<char*>(p->buf.workspace);
-  *cur_ids = reinterpret_cast<int32_t*>(base);
-  base += round_up<size_t>((size_t)p->batch * sizeof(int32_t), 256);
-  carve(&p->cfg, p->L, p->batch, base, tr);
+  carve(&p->cfg, p->L, p->batch, base, &m->tr);
   base += p->train_ws_bytes;
-  carve(&p->cfg, p->L, std::max<int64_t>(p->max_test, 1), base, te);
+  carve(&p->cfg, p->L, std::max<int64_t>(p->max_test, 1), base, &m->te);
+  base += p->test_ws_bytes;
+  m->feats = reinterpret_cast<float*>(base); base += p->feats_bytes;
+  m->big_ws = reinterpret_cast<float*>(base); base += p->big_gemm_ws_bytes;
+  m->iota = reinterpret_cast<int32_t*>(base);
 }
 
-static int enqueue_grad(bsig_fit_plan* p, hipStream_t st) {
-  int32_t* cur_ids; Scratch tr, te;
-  plan_scratch(p, &cur_ids, &tr, &te);
+static Inputs train_inputs(const bsig_fit_plan* p, const PlanMem& m) {
   const bsig_fit_buffers& b = p->buf;
-  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, st, b.state, b.ids_table,
-                     cur_ids, (int)p->batch, (double)p->cfg.beta1, (double)p->cfg.beta2,
-                     (double)p->cfg.lr);
-  BSIG_CHECK_LAUNCH("step_begin");
-  Inputs in{b.x_train, b.ldx_train, cur_ids, b.rff_coeff, b.ld_coeff, b.rff_offset};
-  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, p->batch, tr, tr.o, p->L.nh, st));
-  BSIG_TRY(head_nll(&p->cfg, p->L, tr, b.y_train, b.ldy_train, cur_ids, p->batch,
+  Inputs in;
+  in.dyn = b.state + ST_STEP; in.dyn_stride = p->batch;
+  in.rff_coeff = b.rff_coeff; in.ld_coeff = b.ld_coeff; in.rff_offset = b.rff_offset;
+  if (p->hoist) { in.x = m.feats; in.ldx = p->cfg.rff_feats; in.is_feat = true; }
+  else { in.x = b.x_train; in.ldx = b.ldx_train; in.rows = b.ids_table; }
+  return in;
+}
+
+static Inputs eval_inputs(const bsig_fit_plan* p, const PlanMem& m) {
+  const bsig_fit_buffers& b = p->buf;
+  Inputs in;
+  in.rff_coeff = b.rff_coeff; in.ld_coeff = b.ld_coeff; in.rff_offset = b.rff_offset;
+  if (p->hoist) {
+    in.x = m.feats; in.ldx = p->cfg.rff_feats; in.is_feat = true;
+    in.dyn = b.state + ST_EVAL; in.dyn_stride = b.n_test; in.dyn_base = p->n_updates * p->batch;
+  } else {
+    in.x = b.x_test; in.ldx = b.ldx_test;
+  }
+  return in;
+}
+
+// forward + NLL + finish (advances the step) [+ backward]
+static int enqueue_grad(bsig_fit_plan* p, hipStream_t st, bool fuse_adam) {
+  PlanMem m; plan_mem(p, &m);
+  const bsig_fit_buffers& b = p->buf;
+  const Inputs in = train_inputs(p, m);
+  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, p->batch, m.tr, m.tr.o, p->L.nh, st));
+  HeadDyn hd;
+  hd.y_dyn = b.state + ST_STEP; hd.y_dyn_stride = p->batch;
+  hd.hook.state = b.state; hd.hook.kind = 1;
+  hd.hook.lr = p->cfg.lr; hd.hook.beta1 = p->cfg.beta1; hd.hook.beta2 = p->cfg.beta2;
+  BSIG_TRY(head_nll(&p->cfg, p->L, m.tr, b.y_train, b.ldy_train, b.ids_table, p->batch,
                     p->norm_batch, nullptr, 0, 0,
                     reinterpret_cast<const uint64_t*>(b.state + ST_RNG), b.train_loss,
-                    b.state + ST_CUR_STEP, true, b.state + ST_NONFINITE, st));
-  BSIG_TRY(backward_pass(&p->cfg, p->L, b.params, in, p->batch, tr, b.grads, st));
-  return BSIG_OK;
+                    b.state + ST_STEP, true, b.grads + p->L.head_b_off, b.state + ST_NONFINITE,
+                    &hd, st));
+  AdamFuse fuse{b.exp_avg, b.exp_avg_sq, reinterpret_cast<const float*>(b.state) + ST_ADAM0,
+                p->cfg.beta1, p->cfg.beta2, p->cfg.adam_eps};
+  return backward_pass(&p->cfg, p->L, b.params, in, -1, p->batch, m.tr, b.grads,
+                       fuse_adam ? &fuse : nullptr, st);
 }
 
 static int enqueue_apply(bsig_fit_plan* p, hipStream_t st) {
@@ -322,17 +415,43 @@ static int enqueue_apply(bsig_fit_plan* p, hipStream_t st) {
 }
 
 static int enqueue_eval(bsig_fit_plan* p, hipStream_t st) {
-  int32_t* cur_ids; Scratch tr, te;
-  plan_scratch(p, &cur_ids, &tr, &te);
+  PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
-  hipLaunchKernelGGL(eval_begin_kernel, dim3(1), dim3(64), 0, st, b.state);
-  BSIG_CHECK_LAUNCH("eval_begin");
-  if (b.n_test <= 0) return BSIG_OK;
-  Inputs in{b.x_test, b.ldx_test, nullptr, b.rff_coeff, b.ld_coeff, b.rff_offset};
-  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, b.n_test, te, te.o, p->L.nh, st));
-  BSIG_TRY(head_nll(&p->cfg, p->L, te, b.y_test, b.ldy_test, nullptr, b.n_test, b.n_test,
-                    nullptr, 0, 0, reinterpret_cast<const uint64_t*>(b.state + ST_RNG),
-                    b.test_loss, b.state + ST_CUR_EVAL, false, b.state + ST_NONFINITE, st));
+  HeadDyn hd;
+  hd.hook.state = b.state; hd.hook.kind = 2;
+  if (b.n_test <= 0) {   // nothing held out: still consume an evaluation slot
+    hipLaunchKernelGGL(iota_mod_kernel, dim3(1), dim3(64), 0, st, b.state + ST_EVAL + 0, 0, 1);
+    BSIG_CHECK_LAUNCH("eval_noop");
+    return BSIG_OK;
+  }
+  const Inputs in = eval_inputs(p, m);
+  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, b.n_test, m.te, m.te.o, p->L.nh, st));
+  return head_nll(&p->cfg, p->L, m.te, b.y_test, b.ldy_test, nullptr, b.n_test, b.n_test,
+                  nullptr, 0, 0, reinterpret_cast<const uint64_t*>(b.state + ST_RNG),
+                  b.test_loss, b.state + ST_EVAL, false, nullptr, b.state + ST_NONFINITE, &hd,
+                  st);
+}
+
+// RFF projection of every minibatch row of this call (and of the held-out rows,
+// once per evaluation) in two large GEMMs.
+static int enqueue_hoisted_rff(bsig_fit_plan* p, hipStream_t st) {
+  PlanMem m; plan_mem(p, &m);
+  const bsig_fit_buffers& b = p->buf;
+  Inputs in;
+  in.x = b.x_train; in.ldx = b.ldx_train; in.rows = b.ids_table;
+  in.rff_coeff = b.rff_coeff; in.ld_coeff = b.ld_coeff; in.rff_offset = b.rff_offset;
+  BSIG_TRY(rff_project(&p->cfg, in, p->n_updates * p->batch, m.feats, m.big_ws,
+                       p->big_gemm_ws_bytes, st));
+  if (b.n_test > 0) {
+    const int n = (int)(p->n_evals * b.n_test);
+    hipLaunchKernelGGL(iota_mod_kernel, dim3(std::min(ceil_div(n, 256), 256)), dim3(256), 0, st,
+                       m.iota, n, (int)b.n_test);
+    BSIG_CHECK_LAUNCH("iota_mod");
+    in.x = b.x_test; in.ldx = b.ldx_test; in.rows = m.iota;
+    BSIG_TRY(rff_project(&p->cfg, in, n,
+                         m.feats + (size_t)p->n_updates * p->batch * p->cfg.rff_feats, m.big_ws,
+                         p->big_gemm_ws_bytes, st));
+  }
   return BSIG_OK;
 }
 
@@ -357,14 +476,14 @@ static int capture(bsig_fit_plan* p, hipGraphExec_t* out, F&& body) {
 }
 
 static int ensure_graphs(bsig_fit_plan* p) {
-  if (!p->use_graph || p->g_step) return BSIG_OK;
-  BSIG_TRY(capture(p, &p->g_grad, [&](hipStream_t s) { return enqueue_grad(p, s); }));
-  BSIG_TRY(capture(p, &p->g_apply, [&](hipStream_t s) { return enqueue_apply(p, s); }));
+  if (!p->use_graph || p->g_eval) return BSIG_OK;
+  if (p->split_adam) {
+    BSIG_TRY(capture(p, &p->g_grad, [&](hipStream_t s) { return enqueue_grad(p, s, false); }));
+    BSIG_TRY(capture(p, &p->g_apply, [&](hipStream_t s) { return enqueue_apply(p, s); }));
+  } else {
+    BSIG_TRY(capture(p, &p->g_step, [&](hipStream_t s) { return enqueue_grad(p, s, true); }));
+  }
   BSIG_TRY(capture(p, &p->g_eval, [&](hipStream_t s) { return enqueue_eval(p, s); }));
-  BSIG_TRY(capture(p, &p->g_step, [&](hipStream_t s) {
-    BSIG_TRY(enqueue_grad(p, s));
-    return enqueue_apply(p, s);
-  }));
   return BSIG_OK;
 }
 
@@ -415,7 +534,9 @@ extern "C" int bsig_mdn_head_forward(const bsig_mdn_cfg* cfg, const float* param
   BSIG_REQUIRE(workspace && workspace_bytes >= s.total_bytes,
                "head_forward: workspace %zu < %zu", workspace_bytes, s.total_bytes);
   carve(cfg, L, batch, workspace, &s);
-  Inputs in{x, ldx, x_rows, rff_coeff, ld_coeff, rff_offset};
+  Inputs in;
+  in.x = x; in.ldx = ldx; in.rows = x_rows;
+  in.rff_coeff = rff_coeff; in.ld_coeff = ld_coeff; in.rff_offset = rff_offset;
   return forward_pass(cfg, L, params, in, batch, s, head_out, ld_head, as_stream(stream));
 }
 
@@ -438,16 +559,19 @@ extern "C" int bsig_mdn_loss_grad(const bsig_mdn_cfg* cfg, const float* params,
                workspace_bytes, s.total_bytes);
   carve(cfg, L, batch, workspace, &s);
   hipStream_t st = as_stream(stream);
-  Inputs in{x, ldx, rows, rff_coeff, ld_coeff, rff_offset};
+  Inputs in;
+  in.x = x; in.ldx = ldx; in.rows = rows;
+  in.rff_coeff = rff_coeff; in.ld_coeff = ld_coeff; in.rff_offset = rff_offset;
   BSIG_TRY(forward_pass(cfg, L, params, in, batch, s, s.o, L.nh, st));
   BSIG_TRY(head_nll(cfg, L, s, y, ldy, rows, batch, norm_batch, noise, seed, stream_id, nullptr,
-                    loss, nullptr, true, nonfinite, st));
-  return backward_pass(cfg, L, params, in, batch, s, grads, st);
+                    loss, nullptr, true, grads + L.head_b_off, nonfinite, nullptr, st));
+  return backward_pass(cfg, L, const_cast<float*>(params), in, 0, batch, s, grads, nullptr, st);
 }
 
 extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t max_test_rows,
-                               bsig_fit_plan** plan) {
-  BSIG_REQUIRE(cfg && plan && batch >= 1 && max_test_rows >= 0, "fit_create: bad args");
+                               int64_t n_updates, bsig_fit_plan** plan) {
+  BSIG_REQUIRE(cfg && plan && batch >= 1 && max_test_rows >= 0 && n_updates >= 0,
+               "fit_create: bad args");
   bsig_fit_plan* p = new (std::nothrow) bsig_fit_plan();
   BSIG_REQUIRE(p, "fit_create: out of memory");
   std::memset(p, 0, sizeof(*p));
@@ -455,10 +579,25 @@ extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t m
   const int rc = make_layout(cfg, &p->L);
   if (rc != BSIG_OK) { delete p; return rc; }
   p->batch = batch; p->max_test = max_test_rows; p->norm_batch = batch;
+  p->n_updates = n_updates; p->n_evals = count_evals(n_updates);
   Scratch s;
   carve(cfg, p->L, batch, nullptr, &s); p->train_ws_bytes = s.total_bytes;
   carve(cfg, p->L, std::max<int64_t>(max_test_rows, 1), nullptr, &s);
   p->test_ws_bytes = s.total_bytes;
+  p->feat_rows = n_updates * batch + p->n_evals * max_test_rows;
+  const size_t feats = (size_t)p->feat_rows * (size_t)std::max(cfg->rff_feats, 0) * sizeof(float);
+  const char* no_hoist = getenv("BSIG_NO_RFF_HOIST");
+  p->hoist = cfg->rff_feats > 0 && n_updates > 0 && feats <= ((size_t)4 << 30) &&
+             !(no_hoist && no_hoist[0] == '1');
+  if (p->hoist) {
+    p->feats_bytes = round_up<size_t>(feats, 256);
+    const int64_t mf = cfg->rff_cos_only ? cfg->rff_feats : cfg->rff_feats / 2;
+    p->big_gemm_ws_bytes = round_up<size_t>(
+        std::max(bsig_gemm_workspace_bytes(n_updates * batch, mf, cfg->input_dim),
+                 bsig_gemm_workspace_bytes(std::max<int64_t>(p->n_evals * max_test_rows, 1), mf,
+                                           cfg->input_dim)) + 256, 256);
+    p->iota_bytes = round_up<size_t>((size_t)(p->n_evals * max_test_rows + 1) * sizeof(int32_t), 256);
+  }
   *plan = p;
   return BSIG_OK;
 }
@@ -474,7 +613,7 @@ extern "C" size_t bsig_fit_workspace_bytes(const bsig_fit_plan* p) {
   return p ? plan_ws_bytes(p) : 0;
 }
 
-extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int use_graph) {
+extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int flags) {
   BSIG_REQUIRE(p && b, "fit_bind: null");
   BSIG_REQUIRE(b->params && b->grads && b->exp_avg && b->exp_avg_sq && b->state &&
                b->workspace && b->x_train && b->y_train && b->ids_table && b->train_loss &&
@@ -486,13 +625,16 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int us
                (long long)b->n_test, (long long)p->max_test);
   BSIG_REQUIRE(b->ldx_train >= p->cfg.input_dim && b->ldy_train >= p->cfg.head.out_dim,
                "fit_bind: leading dims too small");
+  BSIG_REQUIRE(!(b->n_test > 0 && !(b->x_test && b->y_test)), "fit_bind: null test buffers");
+  const bool graph = (flags & BSIG_FIT_GRAPH) != 0, split = (flags & BSIG_FIT_SPLIT_ADAM) != 0;
   const bool same = p->bound && std::memcmp(&p->buf, b, sizeof(*b)) == 0 &&
-                    p->use_graph == (use_graph != 0);
+                    p->use_graph == graph && p->split_adam == split;
   if (!same) {
     drop_graphs(p);
     p->buf = *b;
     p->bound = true;
-    p->use_graph = use_graph != 0;
+    p->use_graph = graph;
+    p->split_adam = split;
   }
   if (p->use_graph && !p->cap_stream)
     BSIG_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
@@ -510,17 +652,18 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
   // fresh optimizer state for every run_training call (mdnn.py:203)
   BSIG_HIP(hipMemsetAsync(p->buf.exp_avg, 0, (size_t)p->L.total * sizeof(float), st));
   BSIG_HIP(hipMemsetAsync(p->buf.exp_avg_sq, 0, (size_t)p->L.total * sizeof(float), st));
+  if (p->hoist) BSIG_TRY(enqueue_hoisted_rff(p, st));
   return ensure_graphs(p);
 }
 
 extern "C" int bsig_fit_grad(bsig_fit_plan* p, bsig_stream_t stream) {
-  BSIG_REQUIRE(p && p->bound, "fit_grad: plan not bound");
+  BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_grad: plan not bound with SPLIT_ADAM");
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_grad, as_stream(stream))); return BSIG_OK; }
-  return enqueue_grad(p, as_stream(stream));
+  return enqueue_grad(p, as_stream(stream), false);
 }
 
 extern "C" int bsig_fit_apply(bsig_fit_plan* p, bsig_stream_t stream) {
-  BSIG_REQUIRE(p && p->bound, "fit_apply: plan not bound");
+  BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_apply: plan not bound with SPLIT_ADAM");
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_apply, as_stream(stream))); return BSIG_OK; }
   return enqueue_apply(p, as_stream(stream));
 }
@@ -533,16 +676,23 @@ extern "C" int bsig_fit_eval(bsig_fit_plan* p, bsig_stream_t stream) {
 
 extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound, "fit_run: plan not bound");
-  BSIG_REQUIRE(n_updates >= 0, "fit_run: n_updates < 0");
+  BSIG_REQUIRE(n_updates >= 0 && n_updates <= p->n_updates,
+               "fit_run: n_updates %lld exceeds the plan's %lld", (long long)n_updates,
+               (long long)p->n_updates);
   hipStream_t st = as_stream(stream);
   if (p->use_graph) BSIG_TRY(ensure_graphs(p));
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
   for (int64_t it = 0; it < n_updates; ++it) {
     if (p->use_graph) {
-      BSIG_HIP(hipGraphLaunch(p->g_step, st));
+      if (p->split_adam) {
+        BSIG_HIP(hipGraphLaunch(p->g_grad, st));
+        BSIG_HIP(hipGraphLaunch(p->g_apply, st));
+      } else {
+        BSIG_HIP(hipGraphLaunch(p->g_step, st));
+      }
     } else {
-      BSIG_TRY(enqueue_grad(p, st));
-      BSIG_TRY(enqueue_apply(p, st));
+      BSIG_TRY(enqueue_grad(p, st, !p->split_adam));
+      if (p->split_adam) BSIG_TRY(enqueue_apply(p, st));
     }
     if (it % every == 0 || it + 1 == n_updates) {
       if (p->use_graph) BSIG_HIP(hipGraphLaunch(p->g_eval, st));

@@ -76,34 +76,40 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float l
   return BSIG_OK;
 }
 
-// out[j] = sum_i x[i*ld + j]; two deterministic stages for tall inputs.
+// out[j] = sum_i x[i*ld + j]; block = 64 columns x 4 row lanes, grid.y = row
+// slabs; two deterministic stages for tall inputs.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld,
                                                      int64_t rows, int64_t cols,
                                                      int64_t rows_per_slab,
                                                      float* __restrict__ out) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= cols) return;
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + cl;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
   const int64_t r1 = (r0 + rows_per_slab < rows) ? r0 + rows_per_slab : rows;
   float acc = 0.f;
-  for (int64_t i = r0; i < r1; ++i) acc += x[i * ld + j];
-  out[(int64_t)blockIdx.y * cols + j] = acc;
+  if (j < cols)
+    for (int64_t i = r0 + rl; i < r1; i += 4) acc += x[i * ld + j];
+  part[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && j < cols)
+    out[(int64_t)blockIdx.y * cols + j] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 int colsum_launch(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
                   void* workspace, size_t workspace_bytes, hipStream_t st) {
   BSIG_REQUIRE(x && out && rows >= 0 && cols >= 1 && ld >= cols, "colsum: bad args");
   int64_t slabs = 1;
-  if (rows > 512) slabs = std::min<int64_t>(ceil_div<int64_t>(rows, 256), 64);
+  if (rows > 1024) slabs = std::min<int64_t>(ceil_div<int64_t>(rows, 512), 64);
   if (slabs > 1 && (!workspace || workspace_bytes < (size_t)slabs * cols * sizeof(float)))
     slabs = 1;
   const int64_t per = ceil_div<int64_t>(std::max<int64_t>(rows, 1), slabs);
   float* stage = slabs > 1 ? reinterpret_cast<float*>(workspace) : out;
-  hipLaunchKernelGGL(colsum_kernel, dim3((int)ceil_div<int64_t>(cols, 256), (int)slabs),
+  hipLaunchKernelGGL(colsum_kernel, dim3((int)ceil_div<int64_t>(cols, 64), (int)slabs),
                      dim3(256), 0, st, x, ld, rows, cols, per, stage);
   BSIG_CHECK_LAUNCH("colsum");
   if (slabs > 1) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((int)ceil_div<int64_t>(cols, 256), 1), dim3(256), 0,
+    hipLaunchKernelGGL(colsum_kernel, dim3((int)ceil_div<int64_t>(cols, 64), 1), dim3(256), 0,
                        st, stage, cols, slabs, cols, slabs, out);
     BSIG_CHECK_LAUNCH("colsum2");
   }

@@ -1,0 +1,37 @@
+// Internal description of one GEMM launch (see gemm_f32.hip).
+#pragma once
+#include "common.h"
+
+namespace bsig {
+
+// extra epilogue, internal to the fit engine: the accumulator is the gradient
+// of c; c / adam_m / adam_v are updated in place with one Adam step
+// (torch.optim.Adam defaults, mdnn.py:203,234) — dW GEMM and optimizer fused.
+constexpr int EPI_ADAM = 100;
+
+struct GemmParams {
+  const float* a = nullptr; int64_t lda = 0; const int32_t* a_rows = nullptr; int a_kmajor = 0;
+  const float* b = nullptr; int64_t ldb = 0; const int32_t* b_rows = nullptr; int b_kmajor = 0;
+  float* c = nullptr; int64_t ldc = 0;
+  int m = 0, n = 0, k = 0, k_chunk = 0, splits = 1;
+  int epilogue = BSIG_EPI_NONE, act = 0;
+  const float* bias = nullptr; const float* aux = nullptr; int64_t ldaux = 0; float alpha = 1.f;
+  float* partial = nullptr;
+  // Row offsets resolved on the device (graph replay): logical row i of the
+  // gathered / offset operand reads source index i + (dyn[0]+dyn_delta)*stride + base
+  // (A: its M rows, or its contraction rows when k-major; same for B).
+  const int32_t* dyn = nullptr; int dyn_delta = 0;
+  int64_t a_dyn_stride = 0, a_dyn_base = 0, b_dyn_stride = 0, b_dyn_base = 0;
+  // EPI_ADAM
+  float* adam_m = nullptr; float* adam_v = nullptr; const float* adam_dyn = nullptr;
+  float beta1 = 0.9f, beta2 = 0.999f, adam_eps = 1e-8f;
+  float* grad_out = nullptr;   // optional: also store the raw gradient
+  // bias of the same layer, updated by the threads that own column 0:
+  // bias_p[row] with gradient bias_g[row] (column sums computed earlier)
+  float* bias_p = nullptr; float* bias_m = nullptr; float* bias_v = nullptr;
+  const float* bias_g = nullptr;
+};
+
+int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st);
+
+}  // namespace bsig

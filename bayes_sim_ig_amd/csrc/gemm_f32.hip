@@ -18,9 +18,10 @@
 // permutation of 0..7, identical for A and B.
 // Split-K (gridDim.z) writes fp32 partial slabs and a second kernel reduces
 // them in a fixed order and applies the epilogue: bitwise reproducible.
-#include "common.h"
+#include "gemm.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace bsig {
 
@@ -28,16 +29,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
 constexpr int BKP = BK + 4;
-
-struct GemmParams {
-  const float* a; int64_t lda; const int32_t* a_rows;
-  const float* b; int64_t ldb; const int32_t* b_rows;
-  float* c; int64_t ldc;
-  int m, n, k, k_chunk, splits;
-  int epilogue, act;
-  const float* bias; const float* aux; int64_t ldaux; float alpha;
-  float* partial;
-};
 
 __device__ inline float act_fwd(float v, int act) {
   switch (act) {
@@ -87,63 +78,106 @@ __device__ inline void epilogue_store(const GemmParams& p, int row, int col, flo
     case BSIG_EPI_BIAS_ACT: epilogue_one<BSIG_EPI_BIAS_ACT>(p, row, col, v); break;
     case BSIG_EPI_COS_SIN: epilogue_one<BSIG_EPI_COS_SIN>(p, row, col, v); break;
     case BSIG_EPI_COS_OFF: epilogue_one<BSIG_EPI_COS_OFF>(p, row, col, v); break;
-    default: epilogue_one<BSIG_EPI_MUL_DACT>(p, row, col, v); break;
+    case BSIG_EPI_MUL_DACT: epilogue_one<BSIG_EPI_MUL_DACT>(p, row, col, v); break;
+    default: {  // EPI_ADAM: v is the gradient of c[row, col]
+      const int64_t e = (int64_t)row * p.ldc + col;
+      if (p.grad_out) p.grad_out[e] = v;
+      const float m1 = p.adam_m[e] + (v - p.adam_m[e]) * (1.0f - p.beta1);
+      const float v1 = p.adam_v[e] * p.beta2 + (1.0f - p.beta2) * v * v;
+      p.adam_m[e] = m1;
+      p.adam_v[e] = v1;
+      p.c[e] = p.c[e] - p.adam_dyn[0] * (m1 / (sqrtf(v1) * p.adam_dyn[1] + p.adam_eps));
+      if (col == 0 && p.bias_p) {
+        const float g = p.bias_g[row];
+        const float bm = p.bias_m[row] + (g - p.bias_m[row]) * (1.0f - p.beta1);
+        const float bv = p.bias_v[row] * p.beta2 + (1.0f - p.beta2) * g * g;
+        p.bias_m[row] = bm;
+        p.bias_v[row] = bv;
+        p.bias_p[row] = p.bias_p[row] - p.adam_dyn[0] * (bm / (sqrtf(bv) * p.adam_dyn[1] + p.adam_eps));
+      }
+      break;
+    }
   }
 }
 
 // ---- global -> register fetch and register -> LDS commit of one operand tile
+// All loads of a tile are unconditional (addresses clamped into the operand,
+// out-of-range elements zeroed afterwards) so they issue back to back and are
+// waited for once, at the commit.  Only the contraction tail must be zeroed:
+// rows beyond M / N only feed output rows / columns that are never stored.
 template <int ROWS, bool KMAJOR, int VEC, int NT>
 struct TileLoader {
   static constexpr int kItems = ROWS * BK / (NT * VEC);
   static_assert(ROWS * BK % (NT * VEC) == 0, "tile not divisible");
   float r[kItems][VEC];
+  int srow[kItems];   // k-contiguous operand: gathered source row of each item
+
+  int64_t off;        // device-resolved row offset of the gathered dimension
+
+  __device__ inline void init(const int32_t* __restrict__ idx, int row0, int nrows, int tid,
+                              int64_t row_off) {
+    off = row_off;
+    if constexpr (!KMAJOR) {
+      constexpr int per_row = BK / VEC;
+#pragma unroll
+      for (int it = 0; it < kItems; ++it) {
+        const int64_t gr = min(row0 + (tid + it * NT) / per_row, nrows - 1) + row_off;
+        srow[it] = idx ? idx[gr] : (int)gr;
+      }
+    }
+  }
 
   __device__ inline void fetch(const float* __restrict__ g, int64_t ld,
                                const int32_t* __restrict__ idx, int row0, int nrows,
-                               int k0, int kend, int tid) {
+                               int k0, int kend, int ktot, int tid) {
+    if constexpr (!KMAJOR) {
+      constexpr int per_row = BK / VEC;
+      const int cc = (tid % per_row) * VEC;   // NT % per_row == 0: same for every item
+      const int gk = k0 + cc;
+      // stay inside the row pitch (ld % 4 == 0 when VEC == 4)
+      const int gkc = (VEC == 4) ? min(gk, (int)ld - 4) : min(gk, ktot - 1);
 #pragma unroll
-    for (int it = 0; it < kItems; ++it) {
-      const int item = tid + it * NT;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) r[it][v] = 0.f;
-      if constexpr (!KMAJOR) {
-        constexpr int per_row = BK / VEC;
-        const int rr = item / per_row, cc = (item % per_row) * VEC;
-        const int gr = row0 + rr, gk = k0 + cc;
-        if (gr < nrows && gk < kend) {
-          const int64_t src_row = idx ? (int64_t)idx[gr] : (int64_t)gr;
-          const float* src = g + src_row * ld + gk;
-          if constexpr (VEC == 4) {
-            if (gk + 3 < kend) {
-              const float4 q = *reinterpret_cast<const float4*>(src);
-              r[it][0] = q.x; r[it][1] = q.y; r[it][2] = q.z; r[it][3] = q.w;
-            } else {
-#pragma unroll
-              for (int v = 0; v < 4; ++v) if (gk + v < kend) r[it][v] = src[v];
-            }
-          } else {
-            r[it][0] = src[0];
-          }
+      for (int it = 0; it < kItems; ++it) {
+        const float* src = g + (int64_t)srow[it] * ld + gkc;
+        if constexpr (VEC == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          r[it][0] = q.x; r[it][1] = q.y; r[it][2] = q.z; r[it][3] = q.w;
+        } else {
+          r[it][0] = src[0];
         }
-      } else {
-        constexpr int per_k = ROWS / VEC;
-        const int kk = item / per_k, cc = (item % per_k) * VEC;
-        const int gk = k0 + kk, gr = row0 + cc;
-        if (gk < kend && gr < nrows) {
-          const int64_t src_row = idx ? (int64_t)idx[gk] : (int64_t)gk;
-          const float* src = g + src_row * ld + gr;
-          if constexpr (VEC == 4) {
-            if (gr + 3 < nrows) {
-              const float4 q = *reinterpret_cast<const float4*>(src);
-              r[it][0] = q.x; r[it][1] = q.y; r[it][2] = q.z; r[it][3] = q.w;
-            } else {
+      }
 #pragma unroll
-              for (int v = 0; v < 4; ++v) if (gr + v < nrows) r[it][v] = src[v];
-            }
-          } else {
-            r[it][0] = src[0];
-          }
+      for (int it = 0; it < kItems; ++it)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          if (gk + v >= kend) r[it][v] = 0.f;
+    } else {
+      constexpr int per_k = ROWS / VEC;
+      const int cc = (tid % per_k) * VEC;
+      const int gr = row0 + cc;
+      const int grc = (VEC == 4) ? min(gr, (int)ld - 4) : min(gr, nrows - 1);
+      int krow[kItems];
+#pragma unroll
+      for (int it = 0; it < kItems; ++it) {
+        const int64_t gkc = min(k0 + (tid + it * NT) / per_k, ktot - 1) + off;
+        krow[it] = idx ? idx[gkc] : (int)gkc;
+      }
+#pragma unroll
+      for (int it = 0; it < kItems; ++it) {
+        const float* src = g + (int64_t)krow[it] * ld + grc;
+        if constexpr (VEC == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          r[it][0] = q.x; r[it][1] = q.y; r[it][2] = q.z; r[it][3] = q.w;
+        } else {
+          r[it][0] = src[0];
         }
+      }
+#pragma unroll
+      for (int it = 0; it < kItems; ++it) {
+        const bool dead = k0 + (tid + it * NT) / per_k >= kend;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          if (dead) r[it][v] = 0.f;
       }
     }
   }
@@ -201,9 +235,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   TileLoader<BM, AKM, AVEC, NT> la;
   TileLoader<BN, BKM, BVEC, NT> lb;
   const int nkt = (kend - kbeg + BK - 1) / BK;
+  const int64_t dstep = p.dyn ? (int64_t)(p.dyn[0] + p.dyn_delta) : 0;
+  la.init(p.a_rows, m0, p.m, tid, dstep * p.a_dyn_stride + p.a_dyn_base);
+  lb.init(p.b_rows, n0, p.n, tid, dstep * p.b_dyn_stride + p.b_dyn_base);
   if (nkt > 0) {
-    la.fetch(p.a, p.lda, p.a_rows, m0, p.m, kbeg, kend, tid);
-    lb.fetch(p.b, p.ldb, p.b_rows, n0, p.n, kbeg, kend, tid);
+    la.fetch(p.a, p.lda, p.a_rows, m0, p.m, kbeg, kend, p.k, tid);
+    lb.fetch(p.b, p.ldb, p.b_rows, n0, p.n, kbeg, kend, p.k, tid);
   }
   for (int kt = 0; kt < nkt; ++kt) {
     la.commit(As, tid);
@@ -211,8 +248,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
     __syncthreads();
     if (kt + 1 < nkt) {  // prefetch the next tile into registers
       const int k0 = kbeg + (kt + 1) * BK;
-      la.fetch(p.a, p.lda, p.a_rows, m0, p.m, k0, kend, tid);
-      lb.fetch(p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, tid);
+      la.fetch(p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid);
+      lb.fetch(p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid);
     }
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
@@ -316,23 +353,47 @@ static int launch_tile(const GemmParams& p, bool akm, bool bkm, int avec, int bv
   return BSIG_EUNSUPPORTED;
 }
 
-struct GemmPlan { bool big; int splits; int k_chunk; };
+enum { TILE_64 = 0, TILE_128 = 1, TILE_128x32 = 2 };
+struct GemmPlan { int tile; int splits; int k_chunk; };
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// Tile / split-K choice.  Large problems: 128x128 tiles, no split.  Minibatch
+// sized M (<= 128 rows): 128x32 tiles so the big operand (weights / RFF
+// coefficients) is streamed exactly once, split-K until ~4 workgroups per CU.
 static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
   GemmPlan pl;
   const int64_t t128 = ceil_div<int64_t>(m, 128) * ceil_div<int64_t>(n, 128);
-  pl.big = (m >= 256 && n >= 128 && t128 >= 192);
-  const int64_t tiles = pl.big ? t128 : ceil_div<int64_t>(m, 64) * ceil_div<int64_t>(n, 64);
+  int64_t tiles, target;
+  if (m >= 256 && n >= 128 && t128 >= 192) {
+    pl.tile = TILE_128; tiles = t128; target = 256;
+  } else if (m <= 128 && n >= 64) {
+    pl.tile = TILE_128x32; tiles = ceil_div<int64_t>(n, 32); target = 1024;
+  } else {
+    pl.tile = TILE_64; tiles = ceil_div<int64_t>(m, 64) * ceil_div<int64_t>(n, 64); target = 768;
+  }
+  const int forced_tile = env_int("BSIG_GEMM_TILE", -1);
+  if (forced_tile >= 0) {
+    pl.tile = forced_tile;
+    const int bm = forced_tile == TILE_64 ? 64 : 128;
+    const int bn = forced_tile == TILE_64 ? 64 : (forced_tile == TILE_128 ? 128 : 32);
+    tiles = ceil_div<int64_t>(m, bm) * ceil_div<int64_t>(n, bn);
+  }
   int64_t splits = 1;
-  if (tiles < 256) {
-    splits = ceil_div<int64_t>(512, tiles);
+  if (tiles < target) {
+    splits = ceil_div<int64_t>(target, tiles);
     const int64_t max_by_k = k / (2 * BK) > 0 ? k / (2 * BK) : 1;
     if (splits > max_by_k) splits = max_by_k;
     if (splits > 64) splits = 64;
-    const int64_t max_by_ws = (int64_t)(ws_bytes / (sizeof(float) * (size_t)(m * n)));
-    if (splits > max_by_ws) splits = max_by_ws;
-    if (splits < 1) splits = 1;
   }
+  const int forced = env_int("BSIG_GEMM_SPLITS", 0);
+  if (forced > 0) splits = forced;
+  const int64_t max_by_ws = (int64_t)(ws_bytes / (sizeof(float) * (size_t)(m * n)));
+  if (splits > max_by_ws) splits = max_by_ws;
+  if (splits < 1) splits = 1;
   int64_t chunk = round_up<int64_t>(ceil_div<int64_t>(k, splits), BK);
   splits = ceil_div<int64_t>(k, chunk);
   pl.splits = (int)splits;
@@ -344,45 +405,59 @@ static int pick_vec(const float* ptr, int64_t ld) {
   return (ld % 4 == 0 && aligned(ptr, 16)) ? 4 : 1;
 }
 
-int gemm_f32(const float* a, int64_t lda, int a_kmajor, const int32_t* a_rows,
-             const float* b, int64_t ldb, int b_kmajor, const int32_t* b_rows, float* c,
-             int64_t ldc, int64_t m, int64_t n, int64_t k, int epilogue, int act,
-             const float* bias, const float* aux, int64_t ldaux, float alpha,
-             void* workspace, size_t workspace_bytes, hipStream_t st) {
-  BSIG_REQUIRE(a && b && c, "gemm: null pointer");
-  BSIG_REQUIRE(m >= 0 && n >= 0 && k >= 0 && m < (1 << 30) && n < (1 << 30) && k < (1 << 30),
-               "gemm: bad dims");
-  BSIG_REQUIRE(epilogue >= BSIG_EPI_NONE && epilogue <= BSIG_EPI_MUL_DACT, "gemm: bad epilogue");
-  BSIG_REQUIRE(!((epilogue == BSIG_EPI_BIAS || epilogue == BSIG_EPI_BIAS_ACT ||
-                  epilogue == BSIG_EPI_COS_OFF) && !bias), "gemm: epilogue needs bias");
-  BSIG_REQUIRE(!(epilogue == BSIG_EPI_MUL_DACT && !aux), "gemm: epilogue needs aux");
-  BSIG_REQUIRE(ldc >= (epilogue == BSIG_EPI_COS_SIN ? 2 * n : n), "gemm: ldc too small");
-  if (m == 0 || n == 0) return BSIG_OK;
-  GemmParams p;
-  p.a = a; p.lda = lda; p.a_rows = a_rows;
-  p.b = b; p.ldb = ldb; p.b_rows = b_rows;
-  p.c = c; p.ldc = ldc;
-  p.m = (int)m; p.n = (int)n; p.k = (int)k;
-  p.epilogue = epilogue; p.act = act; p.bias = bias; p.aux = aux; p.ldaux = ldaux;
-  p.alpha = alpha;
-  const GemmPlan pl = plan_gemm(m, n, k, workspace ? workspace_bytes : 0);
+int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  BSIG_REQUIRE(p.a && p.b && p.c, "gemm: null pointer");
+  BSIG_REQUIRE(p.m >= 0 && p.n >= 0 && p.k >= 0, "gemm: bad dims");
+  const int e = p.epilogue;
+  BSIG_REQUIRE((e >= BSIG_EPI_NONE && e <= BSIG_EPI_MUL_DACT) || e == EPI_ADAM,
+               "gemm: bad epilogue");
+  BSIG_REQUIRE(!((e == BSIG_EPI_BIAS || e == BSIG_EPI_BIAS_ACT || e == BSIG_EPI_COS_OFF) &&
+                 !p.bias), "gemm: epilogue needs bias");
+  BSIG_REQUIRE(!(e == BSIG_EPI_MUL_DACT && !p.aux), "gemm: epilogue needs aux");
+  BSIG_REQUIRE(!(e == EPI_ADAM && !(p.adam_m && p.adam_v && p.adam_dyn)),
+               "gemm: Adam epilogue needs its state");
+  BSIG_REQUIRE(p.ldc >= (e == BSIG_EPI_COS_SIN ? 2 * (int64_t)p.n : (int64_t)p.n),
+               "gemm: ldc too small");
+  if (p.m == 0 || p.n == 0) return BSIG_OK;
+  const GemmPlan pl = plan_gemm(p.m, p.n, p.k, workspace ? workspace_bytes : 0);
   p.splits = pl.splits; p.k_chunk = pl.k_chunk;
   p.partial = reinterpret_cast<float*>(workspace);
-  const int avec = pick_vec(a, lda), bvec = pick_vec(b, ldb);
+  // a device-resolved row offset changes the alignment of nothing: offsets are whole rows
+  const int avec = pick_vec(p.a, p.lda), bvec = pick_vec(p.b, p.ldb);
   int rc;
-  if (pl.big)
-    rc = launch_tile<2, 2, 2, 2>(p, a_kmajor != 0, b_kmajor != 0, avec, bvec, st);
+  if (pl.tile == TILE_128)
+    rc = launch_tile<2, 2, 2, 2>(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
+  else if (pl.tile == TILE_128x32)
+    rc = launch_tile<4, 1, 1, 1>(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else
-    rc = launch_tile<2, 2, 1, 1>(p, a_kmajor != 0, b_kmajor != 0, avec, bvec, st);
+    rc = launch_tile<2, 2, 1, 1>(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   if (rc != BSIG_OK) return rc;
   BSIG_CHECK_LAUNCH("gemm_mfma");
   if (p.splits > 1) {
-    const int64_t total = m * n;
+    const int64_t total = (int64_t)p.m * p.n;
     const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total, 256), 2048);
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
     BSIG_CHECK_LAUNCH("gemm_reduce");
   }
   return BSIG_OK;
+}
+
+int gemm_f32(const float* a, int64_t lda, int a_kmajor, const int32_t* a_rows,
+             const float* b, int64_t ldb, int b_kmajor, const int32_t* b_rows, float* c,
+             int64_t ldc, int64_t m, int64_t n, int64_t k, int epilogue, int act,
+             const float* bias, const float* aux, int64_t ldaux, float alpha,
+             void* workspace, size_t workspace_bytes, hipStream_t st) {
+  BSIG_REQUIRE(m >= 0 && n >= 0 && k >= 0 && m < (1 << 30) && n < (1 << 30) && k < (1 << 30),
+               "gemm: bad dims");
+  BSIG_REQUIRE(epilogue >= BSIG_EPI_NONE && epilogue <= BSIG_EPI_MUL_DACT, "gemm: bad epilogue");
+  GemmParams p;
+  p.a = a; p.lda = lda; p.a_rows = a_rows; p.a_kmajor = a_kmajor;
+  p.b = b; p.ldb = ldb; p.b_rows = b_rows; p.b_kmajor = b_kmajor;
+  p.c = c; p.ldc = ldc;
+  p.m = (int)m; p.n = (int)n; p.k = (int)k;
+  p.epilogue = epilogue; p.act = act; p.bias = bias; p.aux = aux; p.ldaux = ldaux;
+  p.alpha = alpha;
+  return gemm_run(p, workspace, workspace_bytes, st);
 }
 
 __global__ __launch_bounds__(256) void rff_coeff_kernel(const float* __restrict__ freqs,
@@ -403,8 +478,10 @@ __global__ __launch_bounds__(256) void rff_coeff_kernel(const float* __restrict_
 using namespace bsig;
 
 extern "C" size_t bsig_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
-  const GemmPlan pl = plan_gemm(m, n, k, (size_t)1 << 40);
-  return pl.splits > 1 ? (size_t)pl.splits * (size_t)m * (size_t)n * sizeof(float) : 0;
+  (void)k;
+  return (size_t)64 * (size_t)m * (size_t)n * sizeof(float) <= ((size_t)256 << 20)
+             ? (size_t)64 * (size_t)m * (size_t)n * sizeof(float)
+             : plan_gemm(m, n, k, (size_t)1 << 40).splits * (size_t)m * (size_t)n * sizeof(float);
 }
 
 extern "C" int bsig_gemm_f32(const float* a, int64_t lda, int a_kmajor,

@@ -12,7 +12,7 @@
 // leave with lane-contiguous stores.  Row sums (loss, jitter terms) are
 // reduced with wavefront shuffles, one partial per workgroup, summed in a
 // fixed order by the finishing kernel (bitwise reproducible, no atomics).
-#include "common.h"
+#include "head.h"
 
 #include <algorithm>
 
@@ -27,6 +27,7 @@ struct HeadArgs {
   const float* seg_sg; int64_t ld_sg;  // pre-activation (fused) or L_d (tuple)
   const float* seg_lo; int64_t ld_lo;  // Ls*K / row or nullptr
   const float* y; int64_t ldy; const int32_t* y_rows;
+  const int32_t* y_dyn; int64_t y_dyn_stride;  // y_rows index offset = y_dyn[0]*stride (replay)
   int batch; float inv_norm;
   int D, K, Ls, Nh, R;
   int from_tuple;
@@ -34,6 +35,7 @@ struct HeadArgs {
   const uint64_t* dyn_rng;              // device {seed, stream}: overrides (graph replay)
   float eps_noise, min_w, ll_limit;
   const float* sig_partials;           // [kSigBlocks] partial sums of exp(pre)
+  int sig_inline;                      // 1: every workgroup sums exp(pre) itself (small B)
   float* d_out; int64_t ld_dout;       // nullptr: forward only
   float* block_lse;                    // [gridDim.x]
   float* block_uds;                    // [gridDim.x]  sum u * dL/dsigma
@@ -84,7 +86,8 @@ __global__ void mdn_nll_kernel(HeadArgs a) {
     for (int j = tid; j < DK; j += nt) t[K + DK + j] = a.seg_sg[row * a.ld_sg + j];
     if (FULL)
       for (int j = tid; j < Ls * K; j += nt) t[K + 2 * DK + j] = a.seg_lo[row * a.ld_lo + j];
-    const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row] : row;
+    const int64_t yoff = a.y_dyn ? (int64_t)a.y_dyn[0] * a.y_dyn_stride : 0;
+    const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
     for (int j = tid; j < D; j += nt) ybuf[r * D + j] = a.y[yrow * a.ldy + j];
   }
   // jitter scale eps = EPS_NOISE * mean(exp(pre))  (batch-global)
@@ -256,16 +259,186 @@ __global__ void mdn_nll_kernel(HeadArgs a) {
   if (bad && a.nonfinite) atomicOr(a.nonfinite, 1);
 }
 
+// Diagonal covariance, one WAVEFRONT per minibatch row (the B=100 schedule of
+// bayes_sim.py:20-23 would leave a thread-per-(row,k) mapping with 4 busy lanes):
+// lane l < TPR = (64/K)*K owns component k = l % K and the dimensions
+// d = l/K, l/K + TPR/K, ...; per-k sums meet in LDS; gradients overwrite the
+// staged row in place and leave lane-contiguous.
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D = a.D, K = a.K, Nh = a.Nh;
+  const int DK = D * K;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int per_wave = Nh + D + 2 * 64 + K;
+  float* red = smem;                       // [16]
+  float* tile = smem + 16 + wid * per_wave;  // [Nh]
+  float* yv = tile + Nh;                   // [D]
+  float* pq = yv + D;                      // [64] partial quad
+  float* pl = pq + 64;                     // [64] partial logdet
+  float* rk = pl + 64;                     // [K]
+  const int row = blockIdx.x * WPB + wid;
+  const bool active = row < a.batch;
+
+  // jitter scale eps = EPS_NOISE * mean(exp(pre)) over the whole minibatch
+  float eps = 0.f;
+  if (!a.from_tuple && a.eps_noise != 0.f) {
+    float s = 0.f;
+    if (a.sig_inline) {
+      const int total = a.batch * DK;
+      for (int e = tid; e < total; e += WPB * 64) {
+        const int rr = e / DK;
+        s += expf(a.seg_sg[(int64_t)rr * a.ld_sg + (e - rr * DK)]);
+      }
+    } else if (tid < kSigBlocks) {
+      s = a.sig_partials[tid];
+    }
+    s = block_sum(s, red);
+    eps = a.eps_noise * (s / ((float)a.batch * (float)DK));
+  }
+  if (active) {
+    for (int j = lane; j < K; j += 64) tile[j] = a.seg_w[(int64_t)row * a.ld_w + j];
+    for (int j = lane; j < DK; j += 64) tile[K + j] = a.seg_mu[(int64_t)row * a.ld_mu + j];
+    for (int j = lane; j < DK; j += 64) tile[K + DK + j] = a.seg_sg[(int64_t)row * a.ld_sg + j];
+    const int64_t yoff = a.y_dyn ? (int64_t)a.y_dyn[0] * a.y_dyn_stride : 0;
+    const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
+    for (int j = lane; j < D; j += 64) yv[j] = a.y[yrow * a.ldy + j];
+  }
+  __syncthreads();
+
+  const int groups = 64 / K;               // d-slots per sweep
+  const int TPR = groups * K;
+  const int k = lane % K, d0 = lane / K;
+  const bool elem = active && lane < TPR;
+  bool bad = false;
+  float quad = 0.f, logdet = 0.f;
+  if (elem) {
+    for (int d = d0; d < D; d += groups) {
+      const float mu = tile[K + d * K + k];
+      const float sraw = tile[K + DK + d * K + k];
+      float sg = a.from_tuple ? sraw : expf(sraw);
+      if (eps != 0.f) sg += jitter_u(a, row, d, k) * eps;
+      bad |= !(isfinite(mu) && isfinite(sg));
+      const float z = (yv[d] - mu) / sg;
+      quad += z * z;
+      logdet += logf(sg);
+    }
+  }
+  pq[lane] = quad;
+  pl[lane] = logdet;
+  // mixture weights (every lane, redundantly: K is small)
+  float mx = 0.f, den = 1.f, csum = 1.f;
+  if (active && !a.from_tuple) {
+    mx = tile[0];
+    for (int j = 1; j < K; ++j) mx = fmaxf(mx, tile[j]);
+    den = 0.f;
+    for (int j = 0; j < K; ++j) den += expf(tile[j] - mx);
+    csum = 0.f;
+    for (int j = 0; j < K; ++j) csum += fminf(fmaxf(expf(tile[j] - mx) / den, a.min_w), 1.0f);
+  }
+  __syncthreads();
+  float logp = 0.f;
+  if (active && lane < K) {
+    float q = 0.f, ld = 0.f;
+    for (int j = lane; j < TPR; j += K) { q += pq[j]; ld += pl[j]; }
+    logp = -0.5f * q - ld - (float)D * kHalfLog2Pi;
+    const float w = a.from_tuple ? tile[lane]
+                                 : fminf(fmaxf(expf(tile[lane] - mx) / den, a.min_w), 1.0f) / csum;
+    const float lp = fminf(fmaxf(logp, -a.ll_limit), a.ll_limit);
+    const float rv = lp + logf(fminf(fmaxf(w, a.min_w), 1.0f));
+    bad |= !(isfinite(w) && isfinite(logp) && isfinite(rv));
+    rk[lane] = rv;
+    pq[lane] = logp;                         // keep logp_k for the clamp indicator
+  }
+  __syncthreads();
+  float lse = 0.f;
+  if (active) {
+    float m2 = rk[0];
+    for (int j = 1; j < K; ++j) m2 = fmaxf(m2, rk[j]);
+    float se = 0.f;
+    for (int j = 0; j < K; ++j) se += expf(rk[j] - m2);
+    lse = m2 + logf(se);
+  }
+  const float lse_sum = block_sum((active && lane == 0) ? lse : 0.f, red);
+  if (tid == 0) a.block_lse[blockIdx.x] = lse_sum;
+
+  const bool bwd = a.d_out != nullptr;
+  float uds = 0.f, dlogit = 0.f;
+  if (bwd && elem) {
+    const float sc = -expf(rk[k] - lse) * a.inv_norm;
+    const float lpk = pq[k];
+    const float g_lp = (lpk >= -a.ll_limit && lpk <= a.ll_limit) ? sc : 0.f;
+    for (int d = d0; d < D; d += groups) {
+      const float mu = tile[K + d * K + k];
+      const float sraw = tile[K + DK + d * K + k];
+      float sg0 = 1.f, sg, u = 0.f;
+      if (a.from_tuple) sg = sraw;
+      else {
+        sg0 = expf(sraw);
+        sg = sg0;
+        if (eps != 0.f) { u = jitter_u(a, row, d, k); sg += u * eps; }
+      }
+      const float z = (yv[d] - mu) / sg;
+      const float dsg = g_lp * (z * z - 1.0f) / sg;
+      uds += u * dsg;
+      tile[K + d * K + k] = g_lp * z / sg;
+      tile[K + DK + d * K + k] = dsg * sg0;
+    }
+  }
+  if (bwd && active && lane < K) {          // mixture-weight path, lane = component
+    if (a.from_tuple) {
+      const float w = tile[lane];
+      const float sc = -expf(rk[lane] - lse) * a.inv_norm;
+      dlogit = (w >= a.min_w && w <= 1.0f) ? sc / fminf(fmaxf(w, a.min_w), 1.0f) : 0.f;
+    } else {
+      float s1 = 0.f;
+      for (int j = 0; j < K; ++j) {
+        const float sj = expf(tile[j] - mx) / den;
+        const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
+        const float scj = -expf(rk[j] - lse) * a.inv_norm;
+        const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / fminf(fmaxf(wj, a.min_w), 1.0f) : 0.f;
+        s1 += gwj * wj;
+      }
+      float s2 = 0.f, gs_k = 0.f, s_k = 0.f;
+      for (int j = 0; j < K; ++j) {
+        const float sj = expf(tile[j] - mx) / den;
+        const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
+        const float scj = -expf(rk[j] - lse) * a.inv_norm;
+        const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / fminf(fmaxf(wj, a.min_w), 1.0f) : 0.f;
+        const float gsj = (sj >= a.min_w && sj <= 1.0f) ? (gwj - s1) / csum : 0.f;
+        s2 += gsj * sj;
+        if (j == lane) { gs_k = gsj; s_k = sj; }
+      }
+      dlogit = s_k * (gs_k - s2);
+    }
+  }
+  const float uds_sum = block_sum(uds, red);   // barrier: logits are read before they change
+  if (tid == 0 && a.block_uds) a.block_uds[blockIdx.x] = uds_sum;
+  if (bwd) {
+    if (active && lane < K) tile[lane] = dlogit;
+    __syncthreads();
+    if (active) {
+      float* o = a.d_out + (int64_t)row * a.ld_dout;
+      for (int j = lane; j < Nh; j += 64) o[j] = tile[j];
+    }
+  }
+  if (bad && a.nonfinite) atomicOr(a.nonfinite, 1);
+}
+
 // Finishing kernel: loss = -(sum of block partials) / batch; jitter-scale
-// gradient term d pre += (EPS/(B*D*K)) * sum(u * dL/dsigma) * exp(pre)
-// (the non-detached mean of mdnn.py:115).
+// gradient term d pre += (EPS/(B*D*K)) * sum(u * dL/dsigma) * exp(pre) (the
+// non-detached mean of mdnn.py:115); column sums of the corrected d_out (the
+// head bias gradients).  Grid: x = 64-column groups of d_out, y = row slabs;
+// block = 64 columns x 4 row lanes.
 __global__ __launch_bounds__(256) void mdn_finish_kernel(
     const float* __restrict__ block_lse, const float* __restrict__ block_uds, int nblocks,
-    int batch, int dk, float eps_noise, const float* __restrict__ pre, int64_t ld_pre,
-    float* __restrict__ d_pre, int64_t ld_dpre, float* __restrict__ loss,
-    const int32_t* __restrict__ loss_slot, int32_t* __restrict__ nonfinite) {
+    int batch, int pre_begin, int dk, int nh, float eps_noise, const float* __restrict__ pre,
+    int64_t ld_pre, float* __restrict__ d_out, int64_t ld_dout, float* __restrict__ colsum,
+    int rows_per_slab, float* __restrict__ loss, const int32_t* __restrict__ loss_slot,
+    int32_t* __restrict__ nonfinite, FinishHook hook) {
   __shared__ float red[8];
-  if (blockIdx.x == 0 && loss) {
+  __shared__ float part[4][64];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && loss) {
     float s = 0.f;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += block_lse[i];
     s = block_sum(s, red);
@@ -275,15 +448,50 @@ __global__ __launch_bounds__(256) void mdn_finish_kernel(
       if (!isfinite(l) && nonfinite) atomicOr(nonfinite, 1);
     }
   }
-  if (d_pre && eps_noise != 0.f) {
+  // Fit-engine state advance (single writer: block (0,0), thread 0; every
+  // reader of these words runs in an earlier or a later kernel).
+  if (hook.state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    int32_t* st = hook.state;
+    if (hook.kind == 1) {           // end of the forward half of update `step`
+      const int step = st[0];
+      const double t = (double)(step + 1);
+      reinterpret_cast<float*>(st)[4] = (float)(hook.lr / (1.0 - pow(hook.beta1, t)));
+      reinterpret_cast<float*>(st)[5] = (float)(1.0 / sqrt(1.0 - pow(hook.beta2, t)));
+      st[0] = step + 1;
+    } else {                        // end of a held-out evaluation
+      st[1] = st[1] + 1;
+    }
+    reinterpret_cast<uint64_t*>(st + 8)[1] += 1;   // jitter RNG stream
+  }
+  if (!d_out) return;
+  float c = 0.f;
+  if (eps_noise != 0.f) {
     float s = 0.f;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += block_uds[i];
     s = block_sum(s, red);
-    const float c = eps_noise / ((float)batch * (float)dk) * s;
-    for (int row = blockIdx.x; row < batch; row += gridDim.x)
-      for (int j = threadIdx.x; j < dk; j += blockDim.x)
-        d_pre[(int64_t)row * ld_dpre + j] += c * expf(pre[(int64_t)row * ld_pre + j]);
+    c = eps_noise / ((float)batch * (float)dk) * s;
   }
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * rows_per_slab;
+  const int r1 = min(batch, r0 + rows_per_slab);
+  const bool fix = c != 0.f && col >= pre_begin && col < pre_begin + dk;
+  float acc = 0.f;
+  if (col < nh) {
+    for (int row = r0 + rl; row < r1; row += 4) {
+      float v = d_out[(int64_t)row * ld_dout + col];
+      if (fix) {
+        v += c * expf(pre[(int64_t)row * ld_pre + (col - pre_begin)]);
+        d_out[(int64_t)row * ld_dout + col] = v;
+      }
+      acc += v;
+    }
+  }
+  if (!colsum) return;
+  part[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && col < nh)
+    colsum[(int64_t)blockIdx.y * nh + col] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 // forward() tuple, mdnn.py:109-119
@@ -338,7 +546,16 @@ __global__ __launch_bounds__(256) void mdn_outputs_kernel(
 }
 
 // ---------------------------------------------------------------- host side
-struct HeadGeom { int D, K, Ls, Nh, R, threads; size_t lds; int blocks; };
+int colsum_launch(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
+                  void* workspace, size_t workspace_bytes, hipStream_t st);
+
+constexpr int kWavesPerBlock = 4;     // diag kernel: rows per workgroup
+constexpr int kMaxSlabs = 64;         // finish kernel: row slabs for tall batches
+
+struct HeadGeom {
+  int D, K, Ls, Nh, R, threads; size_t lds; int blocks;
+  bool wave_per_row; int slabs, rows_per_slab;
+};
 
 static int head_geom(const bsig_head_dims* d, int64_t batch, HeadGeom* g) {
   BSIG_REQUIRE(d && d->out_dim >= 1 && d->n_comp >= 1, "mdn head: bad dims");
@@ -346,27 +563,37 @@ static int head_geom(const bsig_head_dims* d, int64_t batch, HeadGeom* g) {
   g->D = d->out_dim; g->K = d->n_comp;
   g->Ls = d->full_cov ? d->out_dim * (d->out_dim - 1) / 2 : 0;
   g->Nh = g->K + 2 * g->D * g->K + g->Ls * g->K;
-  const int rmax = 256 / g->K;
-  int R = (int)std::min<int64_t>(rmax, std::max<int64_t>(1, ceil_div<int64_t>(batch, 128)));
-  for (;; --R) {
-    const int threads = (int)round_up(R * g->K, 64);
-    const size_t lds = ((size_t)R * (g->Nh + g->D + g->K) + 16 +
-                        (g->Ls ? (size_t)2 * g->D * threads : 0)) * sizeof(float);
-    if (lds <= 96 * 1024 || R == 1) {
-      g->R = R; g->threads = threads; g->lds = lds;
-      break;
+  g->wave_per_row = g->Ls == 0;
+  if (g->wave_per_row) {
+    g->R = kWavesPerBlock; g->threads = kWavesPerBlock * 64;
+    g->lds = (16 + (size_t)kWavesPerBlock * (g->Nh + g->D + 128 + g->K)) * sizeof(float);
+  } else {
+    const int rmax = 256 / g->K;
+    int R = (int)std::min<int64_t>(rmax, std::max<int64_t>(1, ceil_div<int64_t>(batch, 128)));
+    for (;; --R) {
+      const int threads = (int)round_up(R * g->K, 64);
+      const size_t lds = ((size_t)R * (g->Nh + g->D + g->K) + 16 +
+                          (size_t)2 * g->D * threads) * sizeof(float);
+      if (lds <= 60 * 1024 || R == 1) {
+        g->R = R; g->threads = threads; g->lds = lds;
+        break;
+      }
     }
   }
-  if (g->lds > 150 * 1024) {
-    set_error("mdn head: a single row needs %zu B of LDS", g->lds);
+  if (g->lds > 64 * 1024) {
+    set_error("mdn head: %zu B of LDS needed for one workgroup", g->lds);
     return BSIG_EUNSUPPORTED;
   }
   g->blocks = (int)ceil_div<int64_t>(batch, g->R);
+  g->slabs = batch > 1024 ? (int)std::min<int64_t>(ceil_div<int64_t>(batch, 512), kMaxSlabs) : 1;
+  g->rows_per_slab = (int)ceil_div<int64_t>(batch, g->slabs);
   return BSIG_OK;
 }
 
-// workspace floats: [sig partials kSigBlocks][block_lse nblk][block_uds nblk]
-static size_t head_ws_floats(const HeadGeom& g) { return kSigBlocks + 2 * (size_t)g.blocks; }
+// workspace floats: [sig partials][block_lse nblk][block_uds nblk][colsum slabs x Nh]
+static size_t head_ws_floats(const HeadGeom& g) {
+  return kSigBlocks + 2 * (size_t)g.blocks + (size_t)kMaxSlabs * g.Nh;
+}
 
 int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t ld_w,
                         const float* seg_mu, int64_t ld_mu, const float* seg_sg,
@@ -374,9 +601,9 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
                         const float* y, int64_t ldy, const int32_t* y_rows, int64_t batch,
                         int64_t norm_batch, const float* noise, uint64_t seed,
                         uint64_t stream_id, const uint64_t* dyn_rng, float* loss,
-                        const int32_t* loss_slot,
-                        float* d_out, int64_t ld_dout, int32_t* nonfinite, void* workspace,
-                        size_t workspace_bytes, hipStream_t st) {
+                        const int32_t* loss_slot, float* d_out, int64_t ld_dout,
+                        float* colsum_out, int32_t* nonfinite, void* workspace,
+                        size_t workspace_bytes, hipStream_t st, const HeadDyn* dyn) {
   HeadGeom g;
   BSIG_TRY(head_geom(dims, batch, &g));
   BSIG_REQUIRE(batch >= 1 && batch < (1 << 30), "mdn head: bad batch");
@@ -384,13 +611,16 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
                "mdn head: workspace too small (%zu < %zu)", workspace_bytes,
                head_ws_floats(g) * sizeof(float));
   BSIG_REQUIRE(!(g.Ls > 0 && !seg_lo), "mdn head: full covariance needs lower entries");
+  BSIG_REQUIRE(!(colsum_out && !d_out), "mdn head: bias gradients need d_head_out");
   float* ws = reinterpret_cast<float*>(workspace);
   float* sig_partials = ws;
   float* block_lse = ws + kSigBlocks;
   float* block_uds = block_lse + g.blocks;
+  float* slab_sums = block_uds + g.blocks;
   const int DK = g.D * g.K;
   const bool jitter = !from_tuple && dims->eps_noise != 0.f;
-  if (jitter) {
+  const bool sig_inline = g.wave_per_row && batch * DK <= 32768;
+  if (jitter && !sig_inline) {
     hipLaunchKernelGGL(sigma0_sum_kernel, dim3(kSigBlocks), dim3(256), 0, st, seg_sg, ld_sg,
                        (int)batch, DK, sig_partials);
     BSIG_CHECK_LAUNCH("sigma0_sum");
@@ -399,27 +629,35 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
   a.seg_w = seg_w; a.ld_w = ld_w; a.seg_mu = seg_mu; a.ld_mu = ld_mu;
   a.seg_sg = seg_sg; a.ld_sg = ld_sg; a.seg_lo = seg_lo; a.ld_lo = ld_lo;
   a.y = y; a.ldy = ldy; a.y_rows = y_rows;
+  a.y_dyn = dyn ? dyn->y_dyn : nullptr; a.y_dyn_stride = dyn ? dyn->y_dyn_stride : 0;
   a.batch = (int)batch; a.inv_norm = 1.0f / (float)norm_batch;
   a.D = g.D; a.K = g.K; a.Ls = g.Ls; a.Nh = g.Nh; a.R = g.R;
   a.from_tuple = from_tuple;
   a.noise = noise; a.seed = seed; a.stream_id = stream_id; a.dyn_rng = dyn_rng;
   a.eps_noise = from_tuple ? 0.f : dims->eps_noise;
   a.min_w = dims->min_weight; a.ll_limit = dims->ll_limit;
-  a.sig_partials = sig_partials;
+  a.sig_partials = sig_partials; a.sig_inline = sig_inline ? 1 : 0;
   a.d_out = d_out; a.ld_dout = ld_dout;
   a.block_lse = block_lse; a.block_uds = block_uds; a.nonfinite = nonfinite;
-  if (g.Ls > 0)
-    hipLaunchKernelGGL(mdn_nll_kernel<true>, dim3(g.blocks), dim3(g.threads), g.lds, st, a);
+  if (g.wave_per_row)
+    hipLaunchKernelGGL(mdn_nll_diag_wave_kernel<kWavesPerBlock>, dim3(g.blocks),
+                       dim3(g.threads), g.lds, st, a);
   else
-    hipLaunchKernelGGL(mdn_nll_kernel<false>, dim3(g.blocks), dim3(g.threads), g.lds, st, a);
+    hipLaunchKernelGGL(mdn_nll_kernel<true>, dim3(g.blocks), dim3(g.threads), g.lds, st, a);
   BSIG_CHECK_LAUNCH("mdn_nll");
+  // finish: loss, jitter-scale gradient correction, head bias gradients
   const bool correct = jitter && d_out != nullptr;
-  const int fblocks = correct ? (int)std::min<int64_t>(batch, 512) : 1;
-  hipLaunchKernelGGL(mdn_finish_kernel, dim3(fblocks), dim3(256), 0, st, block_lse, block_uds,
-                     g.blocks, (int)batch, DK, correct ? dims->eps_noise : 0.f, seg_sg, ld_sg,
-                     correct ? d_out + g.K + DK : nullptr, ld_dout, loss, loss_slot,
-                     nonfinite);
+  const bool sweep = correct || colsum_out != nullptr;
+  const dim3 fgrid(sweep ? (unsigned)ceil_div(g.Nh, 64) : 1u, sweep ? (unsigned)g.slabs : 1u);
+  float* cs = colsum_out ? (g.slabs > 1 ? slab_sums : colsum_out) : nullptr;
+  hipLaunchKernelGGL(mdn_finish_kernel, fgrid, dim3(256), 0, st, block_lse, block_uds,
+                     g.blocks, (int)batch, g.K + DK, DK, g.Nh,
+                     correct ? dims->eps_noise : 0.f, seg_sg, ld_sg, sweep ? d_out : nullptr,
+                     ld_dout, cs, g.rows_per_slab, loss, loss_slot, nonfinite,
+                     dyn ? dyn->hook : FinishHook());
   BSIG_CHECK_LAUNCH("mdn_finish");
+  if (colsum_out && g.slabs > 1)
+    BSIG_TRY(colsum_launch(slab_sums, g.Nh, g.slabs, g.Nh, colsum_out, nullptr, 0, st));
   return BSIG_OK;
 }
 
@@ -479,8 +717,8 @@ extern "C" int bsig_mdn_nll_from_tuple(const bsig_head_dims* dims, const float* 
   const int64_t Ls = dims->full_cov ? D * (D - 1) / 2 : 0;
   return mdn_head_nll_launch(dims, weights, K, mu, D * K, l_d, D * K, lower, Ls * K, 1, y,
                              ldy, nullptr, batch, batch, nullptr, 0, 0, nullptr, loss, nullptr,
-                             nullptr, 0, nonfinite, workspace, workspace_bytes,
-                             as_stream(stream));
+                             nullptr, 0, nullptr, nonfinite, workspace, workspace_bytes,
+                             as_stream(stream), nullptr);
 }
 
 extern "C" int bsig_mdn_head_nll(const bsig_head_dims* dims, const float* head_out,
@@ -497,6 +735,6 @@ extern "C" int bsig_mdn_head_nll(const bsig_head_dims* dims, const float* head_o
   return mdn_head_nll_launch(dims, head_out, ld, head_out + K, ld, head_out + K + D * K, ld,
                              dims->full_cov ? head_out + K + 2 * D * K : nullptr, ld, 0, y,
                              ldy, y_rows, batch, norm_batch, noise, seed, stream_id, nullptr,
-                             loss, nullptr, d_head_out, ld, nonfinite, workspace, workspace_bytes,
-                             as_stream(stream));
+                             loss, nullptr, d_head_out, ld, nullptr, nonfinite, workspace, workspace_bytes,
+                             as_stream(stream), nullptr);
 }

@@ -342,13 +342,14 @@ class MDNN(nn.Module):
         test_loss = self._buf('test_loss', len(eval_its))
         state = self._buf('state', 16, torch.int32)
         # plan (graphs) keyed by everything baked into the captured kernels
-        key = (batch_size, max(n_test, self._bufs.get('cap_test', 0)), cfg.head.eps_noise,
-               cfg.lr, cfg.head.min_weight, cfg.head.ll_limit)
+        key = (batch_size, max(n_test, self._bufs.get('cap_test', 0)), n_updates,
+               cfg.head.eps_noise, cfg.lr, cfg.head.min_weight, cfg.head.ll_limit)
         if self._plan is None or self._plan_key != key:
             if self._plan:
                 lib.bsig_fit_destroy(self._plan)
             handle = C.c_void_p()
-            _lib.check(lib.bsig_fit_create(C.byref(cfg), batch_size, key[1], C.byref(handle)))
+            _lib.check(lib.bsig_fit_create(C.byref(cfg), batch_size, key[1], n_updates,
+                                           C.byref(handle)))
             self._plan, self._plan_key = handle, key
             self._bufs['cap_test'] = key[1]
         ws = self._buf('fit_ws', int(lib.bsig_fit_workspace_bytes(self._plan)) // 4 + 1)
@@ -367,7 +368,9 @@ class MDNN(nn.Module):
         fb.train_loss, fb.test_loss = train_loss.data_ptr(), test_loss.data_ptr()
         fb.state = state.data_ptr()
         fb.workspace, fb.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-        _lib.check(lib.bsig_fit_bind(self._plan, C.byref(fb), 1 if type(self).USE_GRAPH else 0))
+        flags = (_lib.FIT_GRAPH if type(self).USE_GRAPH else 0) | \
+            (_lib.FIT_SPLIT_ADAM if self._dp is not None else 0)
+        _lib.check(lib.bsig_fit_bind(self._plan, C.byref(fb), flags))
         world = 1 if self._dp is None else self._dp.world
         _lib.check(lib.bsig_fit_begin(self._plan, self._seed(), batch_size * world, st))
         if self._dp is None:

@@ -234,26 +234,35 @@ typedef struct bsig_fit_buffers {
   const int32_t* ids_table;      /* [n_updates, batch] minibatch row ids   */
   float* train_loss;             /* [n_updates]  loss of every update      */
   float* test_loss;              /* [n_evals]                              */
-  int32_t* state;                /* [16] int32 engine state (zeroed by begin) */
+  int32_t* state;                /* [16] int32 engine state (reset by begin); word 2 = non-finite flag */
   void* workspace; size_t workspace_bytes;
 } bsig_fit_buffers;
 
 typedef struct bsig_fit_plan bsig_fit_plan;
 
+/* n_updates: updates per run (sizes the hoisted-RFF feature block of MDRFF:
+ * the projections of all n_updates*batch minibatch rows and of the held-out
+ * rows of every evaluation are computed by bsig_fit_begin in one large GEMM). */
 int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t max_test_rows,
-                    bsig_fit_plan** plan);
+                    int64_t n_updates, bsig_fit_plan** plan);
 void bsig_fit_destroy(bsig_fit_plan* plan);
 size_t bsig_fit_workspace_bytes(const bsig_fit_plan* plan);
-/* Bind buffers (re-captures graphs only if something changed). */
-int bsig_fit_bind(bsig_fit_plan* plan, const bsig_fit_buffers* buffers, int use_graph);
+/* Bind buffers (re-captures graphs only if something changed).  flags:
+ * BSIG_FIT_GRAPH replays the update from HIP graphs; BSIG_FIT_SPLIT_ADAM keeps
+ * gradient and optimizer as separate phases (bsig_fit_grad / bsig_fit_apply,
+ * needed for the data-parallel gradient exchange) instead of fusing Adam into
+ * the weight-gradient GEMM epilogues. */
+#define BSIG_FIT_GRAPH 1
+#define BSIG_FIT_SPLIT_ADAM 2
+int bsig_fit_bind(bsig_fit_plan* plan, const bsig_fit_buffers* buffers, int flags);
 /* Reset step counter / Adam state (fresh optimizer per call, mdnn.py:203). */
 int bsig_fit_begin(bsig_fit_plan* plan, uint64_t seed, int64_t norm_batch,
                    bsig_stream_t stream);
 /* n_updates SGD updates with a held-out evaluation every max(n_updates/5,1)
- * updates and after the last (mdnn.py:235-242).  Single-rank: gradient and
- * Adam fused in one graph. */
+ * updates and after the last (mdnn.py:235-242). */
 int bsig_fit_run(bsig_fit_plan* plan, int64_t n_updates, bsig_stream_t stream);
-/* Data-parallel pieces: gradient only (all-reduce `grads` outside), then Adam. */
+/* Data-parallel pieces (BSIG_FIT_SPLIT_ADAM): gradient only (all-reduce
+ * `grads` outside), then the flat Adam step. */
 int bsig_fit_grad(bsig_fit_plan* plan, bsig_stream_t stream);
 int bsig_fit_apply(bsig_fit_plan* plan, bsig_stream_t stream);
 int bsig_fit_eval(bsig_fit_plan* plan, bsig_stream_t stream);
