@@ -188,7 +188,7 @@ static int rff_project(const bsig_mdn_cfg* c, const Inputs& in, int64_t rows, fl
 // trunk (or RFF) + heads -> o ; leaves activations in s.h / s.feat
 static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* params,
                         const Inputs& in, int64_t B, const Scratch& s, float* o, int64_t ldo,
-                        hipStream_t st) {
+                        hipStream_t st, int* n_sig = nullptr) {
   const float* feat = in.x; int64_t ldf = in.ldx; const Inputs* src = &in;
   if (c->rff_feats > 0 && !in.is_feat) {
     BSIG_TRY(rff_project(c, in, B, s.feat, s.gemm_ws, s.gemm_ws_bytes, st));
@@ -210,7 +210,16 @@ static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* par
   g.c = o; g.ldc = ldo;
   g.m = (int)B; g.n = (int)L.nh; g.k = (int)L.feat_dim;
   g.epilogue = BSIG_EPI_BIAS; g.bias = params + L.head_b_off;
-  return gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st);
+  if (n_sig && c->head.eps_noise != 0.f) {   // sum(exp(pre_diag)) partials for the jitter scale
+    g.expsum = s.head_ws;
+    g.expsum_col0 = c->head.n_comp + c->head.out_dim * c->head.n_comp;
+    g.expsum_ncols = c->head.out_dim * c->head.n_comp;
+  }
+  int n = 0;
+  BSIG_TRY(gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st, &n));
+  if (n_sig) *n_sig = n <= head_sig_capacity() ? n : 0;
+  if (n > head_sig_capacity()) { set_error("head GEMM produced %d exp partials", n); return BSIG_EUNSUPPORTED; }
+  return BSIG_OK;
 }
 
 // dW[nout, nin] = dY^T X (+ fused Adam) for one layer
@@ -300,7 +309,8 @@ static int head_nll(const bsig_mdn_cfg* c, const Layout& L, const Scratch& s, co
 // ---- fit engine -----------------------------------------------------------
 // device state block (int32 words)
 enum { ST_STEP = 0, ST_EVAL = 1, ST_NONFINITE = 2, ST_ADAM0 = 4, ST_ADAM1 = 5,
-       ST_RNG = 8 /* 4 words: seed, counter (uint64 x2) */, ST_WORDS = 16 };
+       ST_RNG = 8 /* 4 words: seed, counter (uint64 x2) */,
+       ST_BETA_POW = 12 /* 4 words: beta1^t, beta2^t (double x2) */, ST_WORDS = 16 };
 
 __global__ void fit_begin_kernel(int32_t* state, uint64_t seed) {
   if (threadIdx.x < ST_WORDS) state[threadIdx.x] = 0;
@@ -308,6 +318,8 @@ __global__ void fit_begin_kernel(int32_t* state, uint64_t seed) {
   if (threadIdx.x == 0) {
     reinterpret_cast<uint64_t*>(state + ST_RNG)[0] = seed;
     reinterpret_cast<uint64_t*>(state + ST_RNG)[1] = 1;
+    reinterpret_cast<double*>(state + ST_BETA_POW)[0] = 1.0;   // beta1^0, beta2^0
+    reinterpret_cast<double*>(state + ST_BETA_POW)[1] = 1.0;
   }
 }
 
@@ -391,8 +403,11 @@ static int enqueue_grad(bsig_fit_plan* p, hipStream_t st, bool fuse_adam) {
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
   const Inputs in = train_inputs(p, m);
-  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, p->batch, m.tr, m.tr.o, p->L.nh, st));
+  int n_sig = 0;
+  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, p->batch, m.tr, m.tr.o, p->L.nh, st,
+                        &n_sig));
   HeadDyn hd;
+  hd.n_sig_ready = n_sig;
   hd.y_dyn = b.state + ST_STEP; hd.y_dyn_stride = p->batch;
   hd.hook.state = b.state; hd.hook.kind = 1;
   hd.hook.lr = p->cfg.lr; hd.hook.beta1 = p->cfg.beta1; hd.hook.beta2 = p->cfg.beta2;
@@ -425,7 +440,10 @@ static int enqueue_eval(bsig_fit_plan* p, hipStream_t st) {
     return BSIG_OK;
   }
   const Inputs in = eval_inputs(p, m);
-  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, b.n_test, m.te, m.te.o, p->L.nh, st));
+  int n_sig = 0;
+  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, b.n_test, m.te, m.te.o, p->L.nh, st,
+                        &n_sig));
+  hd.n_sig_ready = n_sig;
   return head_nll(&p->cfg, p->L, m.te, b.y_test, b.ldy_test, nullptr, b.n_test, b.n_test,
                   nullptr, 0, 0, reinterpret_cast<const uint64_t*>(b.state + ST_RNG),
                   b.test_loss, b.state + ST_EVAL, false, nullptr, b.state + ST_NONFINITE, &hd,
@@ -562,9 +580,12 @@ extern "C" int bsig_mdn_loss_grad(const bsig_mdn_cfg* cfg, const float* params,
   Inputs in;
   in.x = x; in.ldx = ldx; in.rows = rows;
   in.rff_coeff = rff_coeff; in.ld_coeff = ld_coeff; in.rff_offset = rff_offset;
-  BSIG_TRY(forward_pass(cfg, L, params, in, batch, s, s.o, L.nh, st));
+  int n_sig = 0;
+  BSIG_TRY(forward_pass(cfg, L, params, in, batch, s, s.o, L.nh, st, &n_sig));
+  HeadDyn hd;
+  hd.n_sig_ready = n_sig;
   BSIG_TRY(head_nll(cfg, L, s, y, ldy, rows, batch, norm_batch, noise, seed, stream_id, nullptr,
-                    loss, nullptr, true, grads + L.head_b_off, nonfinite, nullptr, st));
+                    loss, nullptr, true, grads + L.head_b_off, nonfinite, &hd, st));
   return backward_pass(cfg, L, const_cast<float*>(params), in, 0, batch, s, grads, nullptr, st);
 }
 

@@ -89,7 +89,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const int64_t r1 = (r0 + rows_per_slab < rows) ? r0 + rows_per_slab : rows;
   float acc = 0.f;
   if (j < cols)
-    for (int64_t i = r0 + rl; i < r1; i += 4) acc += x[i * ld + j];
+    for (int64_t i0 = r0 + rl; i0 < r1; i0 += 32) {   // 8 rows in flight per thread
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = (i0 + 4 * u < r1) ? i0 + 4 * u : r1 - 1;
+        q[u] = x[i * ld + j];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 4 * u < r1) acc += q[u];
+    }
   part[rl][cl] = acc;
   __syncthreads();
   if (rl == 0 && j < cols)

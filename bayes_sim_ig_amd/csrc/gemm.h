@@ -25,6 +25,10 @@ struct GemmParams {
   // EPI_ADAM
   float* adam_m = nullptr; float* adam_v = nullptr; const float* adam_dyn = nullptr;
   float beta1 = 0.9f, beta2 = 0.999f, adam_eps = 1e-8f;
+  // Side output of BSIG_EPI_BIAS: per-workgroup partial sums of exp(c[m, n]) over
+  // the columns [expsum_col0, expsum_col0 + expsum_ncols) — the head GEMM hands
+  // sum(exp(pre_diag)) (jitter scale, mdnn.py:115) to the NLL kernel for free.
+  float* expsum = nullptr; int expsum_col0 = 0, expsum_ncols = 0;
   float* grad_out = nullptr;   // optional: also store the raw gradient
   // bias of the same layer, updated by the threads that own column 0:
   // bias_p[row] with gradient bias_g[row] (column sums computed earlier)
@@ -32,6 +36,8 @@ struct GemmParams {
   const float* bias_g = nullptr;
 };
 
-int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st);
+// n_expsum (optional) receives the number of expsum partials written.
+int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st,
+             int* n_expsum = nullptr);
 
 }  // namespace bsig

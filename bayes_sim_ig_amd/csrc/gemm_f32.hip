@@ -100,6 +100,118 @@ __device__ inline void epilogue_store(const GemmParams& p, int row, int col, flo
   }
 }
 
+// Epilogue of one 32x32 accumulator tile read back from the wave's LDS patch:
+// lane (h, l31) owns column `col` of rows rbase + 2*it, it = 0..15.  All
+// operand loads of the 16 rows are issued before the first store so that they
+// overlap (the pointers may alias as far as the compiler knows).
+template <int EPI>
+__device__ inline void tile_epilogue(const GemmParams& p, const float* __restrict__ patch,
+                                     int rbase, int col, int h, int l31, float& exp_acc) {
+  float v[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) v[it] = patch[(2 * it + h) * 32 + l31];
+  const bool colok = col < p.n;
+  if constexpr (EPI == EPI_ADAM) {
+    float pm[16], pv[16], pp[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = rbase + 2 * it;
+      const int64_t e = (colok && row < p.m) ? (int64_t)row * p.ldc + col : 0;
+      pm[it] = p.adam_m[e]; pv[it] = p.adam_v[e]; pp[it] = p.c[e];
+    }
+    const float ss = p.adam_dyn[0], ib = p.adam_dyn[1];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = rbase + 2 * it;
+      if (colok && row < p.m) {
+        const int64_t e = (int64_t)row * p.ldc + col;
+        const float g = v[it];
+        if (p.grad_out) p.grad_out[e] = g;
+        const float m1 = pm[it] + (g - pm[it]) * (1.0f - p.beta1);
+        const float v1 = pv[it] * p.beta2 + (1.0f - p.beta2) * g * g;
+        p.adam_m[e] = m1;
+        p.adam_v[e] = v1;
+        p.c[e] = pp[it] - ss * (m1 / (sqrtf(v1) * ib + p.adam_eps));
+      }
+    }
+    if (col == 0 && p.bias_p) {
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int row = rbase + 2 * it;
+        if (row < p.m) {
+          const float g = p.bias_g[row];
+          const float bm = p.bias_m[row] + (g - p.bias_m[row]) * (1.0f - p.beta1);
+          const float bv = p.bias_v[row] * p.beta2 + (1.0f - p.beta2) * g * g;
+          p.bias_m[row] = bm;
+          p.bias_v[row] = bv;
+          p.bias_p[row] = p.bias_p[row] - ss * (bm / (sqrtf(bv) * ib + p.adam_eps));
+        }
+      }
+    }
+  } else if constexpr (EPI == BSIG_EPI_MUL_DACT) {
+    float hv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = rbase + 2 * it;
+      hv[it] = (colok && row < p.m) ? p.aux[(int64_t)row * p.ldaux + col] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = rbase + 2 * it;
+      if (colok && row < p.m)
+        p.c[(int64_t)row * p.ldc + col] = v[it] * act_bwd_from_out(hv[it], p.act);
+    }
+  } else if constexpr (EPI < 0) {   // raw split-K partial slab
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = rbase + 2 * it;
+      if (colok && row < p.m)
+        p.partial[((int64_t)blockIdx.z * p.m + row) * p.n + col] = v[it];
+    }
+  } else {
+    float bias = 0.f;
+    if constexpr (EPI == BSIG_EPI_BIAS || EPI == BSIG_EPI_BIAS_ACT || EPI == BSIG_EPI_COS_OFF)
+      bias = colok ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = rbase + 2 * it;
+      if (colok && row < p.m) {
+        float* dst = p.c + (int64_t)row * p.ldc + col;
+        if constexpr (EPI == BSIG_EPI_NONE) *dst = v[it];
+        else if constexpr (EPI == BSIG_EPI_BIAS) {
+          const float o = v[it] + bias;
+          *dst = o;
+          if (p.expsum && col >= p.expsum_col0 && col < p.expsum_col0 + p.expsum_ncols)
+            exp_acc += expf(o);
+        }
+        else if constexpr (EPI == BSIG_EPI_BIAS_ACT) *dst = act_fwd(v[it] + bias, p.act);
+        else if constexpr (EPI == BSIG_EPI_COS_OFF) *dst = p.alpha * cosf(v[it] + bias);
+        else {
+          float sn, cs;
+          sincosf(v[it], &sn, &cs);
+          dst[0] = p.alpha * cs;
+          dst[p.n] = p.alpha * sn;
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void run_tile_epilogue(const GemmParams& p, const float* patch,
+                                                  int rbase, int col, int h, int l31,
+                                                  float& exp_acc) {
+  switch (p.splits > 1 ? -1 : p.epilogue) {
+    case -1: tile_epilogue<-1>(p, patch, rbase, col, h, l31, exp_acc); break;
+    case BSIG_EPI_NONE: tile_epilogue<BSIG_EPI_NONE>(p, patch, rbase, col, h, l31, exp_acc); break;
+    case BSIG_EPI_BIAS: tile_epilogue<BSIG_EPI_BIAS>(p, patch, rbase, col, h, l31, exp_acc); break;
+    case BSIG_EPI_BIAS_ACT: tile_epilogue<BSIG_EPI_BIAS_ACT>(p, patch, rbase, col, h, l31, exp_acc); break;
+    case BSIG_EPI_COS_SIN: tile_epilogue<BSIG_EPI_COS_SIN>(p, patch, rbase, col, h, l31, exp_acc); break;
+    case BSIG_EPI_COS_OFF: tile_epilogue<BSIG_EPI_COS_OFF>(p, patch, rbase, col, h, l31, exp_acc); break;
+    case BSIG_EPI_MUL_DACT: tile_epilogue<BSIG_EPI_MUL_DACT>(p, patch, rbase, col, h, l31, exp_acc); break;
+    default: tile_epilogue<EPI_ADAM>(p, patch, rbase, col, h, l31, exp_acc); break;
+  }
+}
+
 // ---- global -> register fetch and register -> LDS commit of one operand tile
 // All loads of a tile are unconditional (addresses clamped into the operand,
 // out-of-range elements zeroed afterwards) so they issue back to back and are
@@ -109,7 +221,7 @@ template <int ROWS, bool KMAJOR, int VEC, int NT>
 struct TileLoader {
   static constexpr int kItems = ROWS * BK / (NT * VEC);
   static_assert(ROWS * BK % (NT * VEC) == 0, "tile not divisible");
-  float r[kItems][VEC];
+  struct Regs { float r[kItems][VEC]; };   // one tile in flight
   int srow[kItems];   // k-contiguous operand: gathered source row of each item
 
   int64_t off;        // device-resolved row offset of the gathered dimension
@@ -127,9 +239,10 @@ struct TileLoader {
     }
   }
 
-  __device__ inline void fetch(const float* __restrict__ g, int64_t ld,
+  __device__ inline void fetch(Regs& t, const float* __restrict__ g, int64_t ld,
                                const int32_t* __restrict__ idx, int row0, int nrows,
-                               int k0, int kend, int ktot, int tid) {
+                               int k0, int kend, int ktot, int tid) const {
+    auto& r = t.r;
     if constexpr (!KMAJOR) {
       constexpr int per_row = BK / VEC;
       const int cc = (tid % per_row) * VEC;   // NT % per_row == 0: same for every item
@@ -182,7 +295,8 @@ struct TileLoader {
     }
   }
 
-  __device__ inline void commit(float* __restrict__ lds, int tid) const {
+  __device__ inline void commit(const Regs& t, float* __restrict__ lds, int tid) const {
+    const auto& r = t.r;
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
       const int item = tid + it * NT;
@@ -232,60 +346,75 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+  // Software pipeline: PD operand tiles in flight in registers.  The
+  // minibatch-sized problems (M or K ~ 100) are latency bound — a dependent
+  // global round trip costs more than a whole K step of MFMAs — so the loads of
+  // PD K steps are issued back to back and consumed in order.
+  constexpr int PD = (TM * TN == 1) ? 4 : 2;
   TileLoader<BM, AKM, AVEC, NT> la;
   TileLoader<BN, BKM, BVEC, NT> lb;
+  typename TileLoader<BM, AKM, AVEC, NT>::Regs ra[PD];
+  typename TileLoader<BN, BKM, BVEC, NT>::Regs rb[PD];
   const int nkt = (kend - kbeg + BK - 1) / BK;
   const int64_t dstep = p.dyn ? (int64_t)(p.dyn[0] + p.dyn_delta) : 0;
   la.init(p.a_rows, m0, p.m, tid, dstep * p.a_dyn_stride + p.a_dyn_base);
   lb.init(p.b_rows, n0, p.n, tid, dstep * p.b_dyn_stride + p.b_dyn_base);
-  if (nkt > 0) {
-    la.fetch(p.a, p.lda, p.a_rows, m0, p.m, kbeg, kend, p.k, tid);
-    lb.fetch(p.b, p.ldb, p.b_rows, n0, p.n, kbeg, kend, p.k, tid);
-  }
-  for (int kt = 0; kt < nkt; ++kt) {
-    la.commit(As, tid);
-    lb.commit(Bs, tid);
-    __syncthreads();
-    if (kt + 1 < nkt) {  // prefetch the next tile into registers
-      const int k0 = kbeg + (kt + 1) * BK;
-      la.fetch(p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid);
-      lb.fetch(p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid);
+#pragma unroll
+  for (int s = 0; s < PD; ++s)
+    if (s < nkt) {
+      la.fetch(ra[s], p.a, p.lda, p.a_rows, m0, p.m, kbeg + s * BK, kend, p.k, tid);
+      lb.fetch(rb[s], p.b, p.ldb, p.b_rows, n0, p.n, kbeg + s * BK, kend, p.k, tid);
     }
+  for (int kt0 = 0; kt0 < nkt; kt0 += PD) {
 #pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
-      float af[TM][4], bf[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 32 + l31;
-        if constexpr (!AKM) {
-          const float4 q = *reinterpret_cast<const float4*>(&As[row * BKP + kg * 8 + h * 4]);
-          af[i][0] = q.x; af[i][1] = q.y; af[i][2] = q.z; af[i][3] = q.w;
-        } else {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) af[i][s] = As[(kg * 8 + h * 4 + s) * BM + row];
+    for (int s = 0; s < PD; ++s) {
+      const int kt = kt0 + s;
+      if (kt < nkt) {          // block-uniform
+        la.commit(ra[s], As, tid);
+        lb.commit(rb[s], Bs, tid);
+        __syncthreads();
+        if (kt + PD < nkt) {   // refill this register slot
+          const int k0 = kbeg + (kt + PD) * BK;
+          la.fetch(ra[s], p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid);
+          lb.fetch(rb[s], p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid);
         }
-      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = (wn * TN + j) * 32 + l31;
-        if constexpr (!BKM) {
-          const float4 q = *reinterpret_cast<const float4*>(&Bs[col * BKP + kg * 8 + h * 4]);
-          bf[j][0] = q.x; bf[j][1] = q.y; bf[j][2] = q.z; bf[j][3] = q.w;
-        } else {
+        for (int kg = 0; kg < BK / 8; ++kg) {
+          float af[TM][4], bf[TN][4];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) bf[j][s] = Bs[(kg * 8 + h * 4 + s) * BN + col];
+          for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 32 + l31;
+            if constexpr (!AKM) {
+              const float4 q = *reinterpret_cast<const float4*>(&As[row * BKP + kg * 8 + h * 4]);
+              af[i][0] = q.x; af[i][1] = q.y; af[i][2] = q.z; af[i][3] = q.w;
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) af[i][u] = As[(kg * 8 + h * 4 + u) * BM + row];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = (wn * TN + j) * 32 + l31;
+            if constexpr (!BKM) {
+              const float4 q = *reinterpret_cast<const float4*>(&Bs[col * BKP + kg * 8 + h * 4]);
+              bf[j][0] = q.x; bf[j][1] = q.y; bf[j][2] = q.z; bf[j][3] = q.w;
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) bf[j][u] = Bs[(kg * 8 + h * 4 + u) * BN + col];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], bf[j][u], acc[i][j],
+                                                                 0, 0, 0);
         }
+        __syncthreads();
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j],
-                                                             0, 0, 0);
     }
-    __syncthreads();
   }
 
   // Epilogue.  C/D fragment of a 32x32 tile: col = lane & 31,
@@ -294,37 +423,62 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   // barrier) so that the accumulator indices stay compile-time constants while
   // the epilogue itself is a runtime switch.
   float* patch = smem + wid * (32 * 32);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q)
-        patch[((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + l31] = acc[i][j][q];
-      __builtin_amdgcn_wave_barrier();
-      const int col = n0 + (wn * TN + j) * 32 + l31;
-      const int rbase = m0 + (wm * TM + i) * 32 + h;
-#pragma unroll 1
-      for (int it = 0; it < 16; ++it) {
-        const int row = rbase + 2 * it;
-        const float v = patch[(2 * it + h) * 32 + l31];
-        if (col < p.n && row < p.m) {
-          if (p.splits > 1) p.partial[((int64_t)blockIdx.z * p.m + row) * p.n + col] = v;
-          else epilogue_store(p, row, col, v);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
+  float exp_acc = 0.f;
+  // (i, j) enumerated explicitly: the accumulator indices must be constants
+#define BSIG_TILE_EPILOGUE(I, J)                                                          \
+  if constexpr ((I) < TM && (J) < TN) {                                                   \
+    _Pragma("unroll") for (int q = 0; q < 16; ++q)                                        \
+        patch[((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + l31] = acc[I][J][q];                \
+    __builtin_amdgcn_wave_barrier();                                                      \
+    run_tile_epilogue(p, patch, m0 + (wm * TM + (I)) * 32 + h,                            \
+                      n0 + (wn * TN + (J)) * 32 + l31, h, l31, exp_acc);                  \
+    __builtin_amdgcn_wave_barrier();                                                      \
+  }
+  BSIG_TILE_EPILOGUE(0, 0)
+  BSIG_TILE_EPILOGUE(0, 1)
+  BSIG_TILE_EPILOGUE(1, 0)
+  BSIG_TILE_EPILOGUE(1, 1)
+#undef BSIG_TILE_EPILOGUE
+  static_assert(TM <= 2 && TN <= 2, "extend the tile enumeration");
+  if (p.expsum && p.splits == 1) {   // one partial per workgroup, fixed order
+    const float s = block_sum(exp_acc, smem);
+    if (tid == 0) p.expsum[blockIdx.y * gridDim.x + blockIdx.x] = s;
   }
 }
 
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
   const int64_t total = (int64_t)p.m * p.n;
+  float exp_acc = 0.f;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
-    for (int z = 0; z < p.splits; ++z) v += p.partial[(int64_t)z * total + e];
-    epilogue_store(p, (int)(e / p.n), (int)(e % p.n), v);
+    int z = 0;
+    for (; z + 16 <= p.splits; z += 16) {   // 16 slab loads in flight, summed in slab order
+      float q[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) q[u] = p.partial[(int64_t)(z + u) * total + e];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v += q[u];
+    }
+    if (z + 8 <= p.splits) {
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = p.partial[(int64_t)(z + u) * total + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += q[u];
+      z += 8;
+    }
+    for (; z < p.splits; ++z) v += p.partial[(int64_t)z * total + e];
+    const int row = (int)(e / p.n), col = (int)(e % p.n);
+    epilogue_store(p, row, col, v);
+    if (p.expsum && p.epilogue == BSIG_EPI_BIAS && col >= p.expsum_col0 &&
+        col < p.expsum_col0 + p.expsum_ncols)
+      exp_acc += expf(v + p.bias[col]);
+  }
+  if (p.expsum) {
+    __shared__ float red[8];
+    const float s = block_sum(exp_acc, red);
+    if (threadIdx.x == 0) p.expsum[blockIdx.x] = s;
   }
 }
 
@@ -371,9 +525,9 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
   if (m >= 256 && n >= 128 && t128 >= 192) {
     pl.tile = TILE_128; tiles = t128; target = 256;
   } else if (m <= 128 && n >= 64) {
-    pl.tile = TILE_128x32; tiles = ceil_div<int64_t>(n, 32); target = 1024;
+    pl.tile = TILE_128x32; tiles = ceil_div<int64_t>(n, 32); target = 512;
   } else {
-    pl.tile = TILE_64; tiles = ceil_div<int64_t>(m, 64) * ceil_div<int64_t>(n, 64); target = 768;
+    pl.tile = TILE_64; tiles = ceil_div<int64_t>(m, 64) * ceil_div<int64_t>(n, 64); target = 512;
   }
   const int forced_tile = env_int("BSIG_GEMM_TILE", -1);
   if (forced_tile >= 0) {
@@ -385,7 +539,7 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
   int64_t splits = 1;
   if (tiles < target) {
     splits = ceil_div<int64_t>(target, tiles);
-    const int64_t max_by_k = k / (2 * BK) > 0 ? k / (2 * BK) : 1;
+    const int64_t max_by_k = k / (4 * BK) > 0 ? k / (4 * BK) : 1;   // >= PD K steps per block
     if (splits > max_by_k) splits = max_by_k;
     if (splits > 64) splits = 64;
   }
@@ -405,7 +559,8 @@ static int pick_vec(const float* ptr, int64_t ld) {
   return (ld % 4 == 0 && aligned(ptr, 16)) ? 4 : 1;
 }
 
-int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st) {
+int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st,
+             int* n_expsum) {
   BSIG_REQUIRE(p.a && p.b && p.c, "gemm: null pointer");
   BSIG_REQUIRE(p.m >= 0 && p.n >= 0 && p.k >= 0, "gemm: bad dims");
   const int e = p.epilogue;
@@ -418,6 +573,8 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
                "gemm: Adam epilogue needs its state");
   BSIG_REQUIRE(p.ldc >= (e == BSIG_EPI_COS_SIN ? 2 * (int64_t)p.n : (int64_t)p.n),
                "gemm: ldc too small");
+  if (n_expsum) *n_expsum = 0;
+  BSIG_REQUIRE(!(p.expsum && e != BSIG_EPI_BIAS), "gemm: expsum needs the bias epilogue");
   if (p.m == 0 || p.n == 0) return BSIG_OK;
   const GemmPlan pl = plan_gemm(p.m, p.n, p.k, workspace ? workspace_bytes : 0);
   p.splits = pl.splits; p.k_chunk = pl.k_chunk;
@@ -438,6 +595,11 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total, 256), 2048);
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
     BSIG_CHECK_LAUNCH("gemm_reduce");
+    if (n_expsum && p.expsum) *n_expsum = blocks;
+  } else if (n_expsum && p.expsum) {
+    const int bm = pl.tile == TILE_64 ? 64 : 128;
+    const int bn = pl.tile == TILE_64 ? 64 : (pl.tile == TILE_128 ? 128 : 32);
+    *n_expsum = ceil_div(p.m, bm) * ceil_div(p.n, bn);
   }
   return BSIG_OK;
 }

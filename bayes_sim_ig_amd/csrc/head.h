@@ -13,6 +13,7 @@ struct FinishHook {
 };
 struct HeadDyn {
   const int32_t* y_dyn = nullptr; int64_t y_dyn_stride = 0;  // y_rows offset = y_dyn[0]*stride
+  int n_sig_ready = 0;   // exp(pre) partial sums already sit at workspace[0..n) (GEMM side output)
   FinishHook hook;
 };
 
@@ -25,5 +26,7 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
                         const int32_t* loss_slot, float* d_out, int64_t ld_dout,
                         float* colsum_out, int32_t* nonfinite, void* workspace,
                         size_t workspace_bytes, hipStream_t st, const HeadDyn* dyn);
+
+int head_sig_capacity();   // max partial sums the head workspace can take
 
 }  // namespace bsig

@@ -5,13 +5,17 @@
 // graph (closed forms: SURVEY.md Appendix A.3, checked against the reference's
 // autograd in tests/test_oracle_mdn.py).
 //
-// Layout: a workgroup owns R consecutive minibatch rows; their raw head
-// outputs [R, Nh] are staged in LDS with lane-contiguous loads, thread (r, k)
-// evaluates component k of row r from LDS, the K per-component terms meet in
-// LDS for the logsumexp, gradients overwrite the staged tile in place and
-// leave with lane-contiguous stores.  Row sums (loss, jitter terms) are
-// reduced with wavefront shuffles, one partial per workgroup, summed in a
-// fixed order by the finishing kernel (bitwise reproducible, no atomics).
+// Diagonal covariance (every BASELINE config): one WAVEFRONT per minibatch
+// row.  The row's raw head outputs are staged in LDS with lane-contiguous
+// loads; lane l < (64/K)*K owns component k = l % K and the dimensions
+// d = l/K + q*(64/K); its per-element values stay in registers between the
+// forward and the backward half; the per-component sums meet in LDS for the
+// logsumexp; gradients overwrite the staged row in place and leave with
+// lane-contiguous stores.  Full covariance: a workgroup owns R rows, thread
+// (r, k) runs the forward / back substitution of component k from LDS.
+// Row sums (loss, jitter terms) are reduced with wavefront shuffles, one
+// partial per workgroup, summed in a fixed order by the finishing kernel
+// (bitwise reproducible, no atomics).
 #include "head.h"
 
 #include <algorithm>
@@ -19,7 +23,9 @@
 namespace bsig {
 
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
-constexpr int kSigBlocks = 64;
+constexpr int kSigMax = 4096;       // capacity of the exp(pre) partial-sum array
+constexpr int kSigBlocks = 512;     // blocks of the stand-alone sigma0_sum kernel
+constexpr int kElemsPerLane = 8;    // wave kernel: register-cached elements per lane
 
 struct HeadArgs {
   const float* seg_w; int64_t ld_w;    // logits (fused) or weights (tuple), K / row
@@ -32,10 +38,9 @@ struct HeadArgs {
   int D, K, Ls, Nh, R;
   int from_tuple;
   const float* noise; uint64_t seed, stream_id;
-  const uint64_t* dyn_rng;              // device {seed, stream}: overrides (graph replay)
+  const uint64_t* dyn_rng;             // device {seed, stream}: overrides (graph replay)
   float eps_noise, min_w, ll_limit;
-  const float* sig_partials;           // [kSigBlocks] partial sums of exp(pre)
-  int sig_inline;                      // 1: every workgroup sums exp(pre) itself (small B)
+  const float* sig_partials; int n_sig;  // partial sums of exp(pre) over the minibatch
   float* d_out; int64_t ld_dout;       // nullptr: forward only
   float* block_lse;                    // [gridDim.x]
   float* block_uds;                    // [gridDim.x]  sum u * dL/dsigma
@@ -50,19 +55,49 @@ __device__ inline float jitter_u(const HeadArgs& a, int row, int d, int k) {
   return u01(philox4x32_10(seed, sid, (uint64_t)e).v[0]);
 }
 
+// eps = EPS_NOISE * mean(exp(pre)) from the partial sums (every workgroup
+// adds the same values in the same order)
+__device__ inline float jitter_eps(const HeadArgs& a, float* red) {
+  float s = 0.f;
+  for (int i0 = threadIdx.x; i0 < a.n_sig; i0 += 4 * blockDim.x) {
+    float q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      q[u] = i < a.n_sig ? a.sig_partials[i] : 0.f;
+    }
+    s += (q[0] + q[1]) + (q[2] + q[3]);
+  }
+  s = block_sum(s, red);
+  return a.eps_noise * (s / ((float)a.batch * (float)(a.D * a.K)));
+}
+
 // sum_{b,d,k} exp(pre[b, d*K+k]) in kSigBlocks partials (for eps = EPS*mean(L_d),
-// mdnn.py:115)
+// mdnn.py:115) when no producer kernel delivered them
 __global__ __launch_bounds__(256) void sigma0_sum_kernel(const float* __restrict__ pre,
                                                          int64_t ld, int batch, int dk,
                                                          float* __restrict__ partials) {
   __shared__ float red[8];
+  const int64_t total = (int64_t)batch * dk;
   float acc = 0.f;
-  for (int row = blockIdx.x; row < batch; row += gridDim.x)
-    for (int j = threadIdx.x; j < dk; j += blockDim.x) acc += expf(pre[(int64_t)row * ld + j]);
+  for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < total;
+       e0 += (int64_t)8 * gridDim.x * 256) {
+    float q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t e = std::min<int64_t>(e0 + (int64_t)u * gridDim.x * 256, total - 1);
+      const int64_t r = e / dk;
+      q[u] = pre[r * ld + (e - r * dk)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + (int64_t)u * gridDim.x * 256 < total) acc += expf(q[u]);
+  }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
+// ---- generic kernel: thread (r, k); full covariance and very wide diagonals ----
 template <bool FULL>
 __global__ void mdn_nll_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -78,6 +113,7 @@ __global__ void mdn_nll_kernel(HeadArgs a) {
   const int nrows = min(R, a.batch - row0);
 
   // ---- stage the R rows (four segments, each lane-contiguous) -------------
+  const int64_t yoff = a.y_dyn ? (int64_t)a.y_dyn[0] * a.y_dyn_stride : 0;
   for (int r = 0; r < nrows; ++r) {
     const int64_t row = row0 + r;
     float* t = tile + r * Nh;
@@ -86,17 +122,11 @@ __global__ void mdn_nll_kernel(HeadArgs a) {
     for (int j = tid; j < DK; j += nt) t[K + DK + j] = a.seg_sg[row * a.ld_sg + j];
     if (FULL)
       for (int j = tid; j < Ls * K; j += nt) t[K + 2 * DK + j] = a.seg_lo[row * a.ld_lo + j];
-    const int64_t yoff = a.y_dyn ? (int64_t)a.y_dyn[0] * a.y_dyn_stride : 0;
     const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
     for (int j = tid; j < D; j += nt) ybuf[r * D + j] = a.y[yrow * a.ldy + j];
   }
-  // jitter scale eps = EPS_NOISE * mean(exp(pre))  (batch-global)
   float eps = 0.f;
-  if (!a.from_tuple && a.eps_noise != 0.f) {
-    float s = (tid < kSigBlocks) ? a.sig_partials[tid] : 0.f;
-    s = block_sum(s, red);
-    eps = a.eps_noise * (s / ((float)a.batch * (float)DK));
-  }
+  if (!a.from_tuple && a.eps_noise != 0.f) eps = jitter_eps(a, red);
   __syncthreads();
 
   const int r = tid / K, k = tid - r * K;
@@ -259,51 +289,35 @@ __global__ void mdn_nll_kernel(HeadArgs a) {
   if (bad && a.nonfinite) atomicOr(a.nonfinite, 1);
 }
 
-// Diagonal covariance, one WAVEFRONT per minibatch row (the B=100 schedule of
-// bayes_sim.py:20-23 would leave a thread-per-(row,k) mapping with 4 busy lanes):
-// lane l < TPR = (64/K)*K owns component k = l % K and the dimensions
-// d = l/K, l/K + TPR/K, ...; per-k sums meet in LDS; gradients overwrite the
-// staged row in place and leave lane-contiguous.
+// ---- diagonal covariance, one wavefront per row ------------------------------
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int D = a.D, K = a.K, Nh = a.Nh;
   const int DK = D * K;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int per_wave = Nh + D + 2 * 64 + K;
+  const int per_wave = Nh + D + 2 * 64 + 2 * K;
   float* red = smem;                       // [16]
   float* tile = smem + 16 + wid * per_wave;  // [Nh]
   float* yv = tile + Nh;                   // [D]
   float* pq = yv + D;                      // [64] partial quad
   float* pl = pq + 64;                     // [64] partial logdet
-  float* rk = pl + 64;                     // [K]
+  float* rk = pl + 64;                     // [K] clamp(logp)+log clamp(w)
+  float* lpk = rk + K;                     // [K] raw logp (clamp indicator)
   const int row = blockIdx.x * WPB + wid;
   const bool active = row < a.batch;
 
-  // jitter scale eps = EPS_NOISE * mean(exp(pre)) over the whole minibatch
-  float eps = 0.f;
-  if (!a.from_tuple && a.eps_noise != 0.f) {
-    float s = 0.f;
-    if (a.sig_inline) {
-      const int total = a.batch * DK;
-      for (int e = tid; e < total; e += WPB * 64) {
-        const int rr = e / DK;
-        s += expf(a.seg_sg[(int64_t)rr * a.ld_sg + (e - rr * DK)]);
-      }
-    } else if (tid < kSigBlocks) {
-      s = a.sig_partials[tid];
-    }
-    s = block_sum(s, red);
-    eps = a.eps_noise * (s / ((float)a.batch * (float)DK));
-  }
+  // every independent global load is issued before anything waits
   if (active) {
+    const int64_t yoff = a.y_dyn ? (int64_t)a.y_dyn[0] * a.y_dyn_stride : 0;
+    const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
     for (int j = lane; j < K; j += 64) tile[j] = a.seg_w[(int64_t)row * a.ld_w + j];
     for (int j = lane; j < DK; j += 64) tile[K + j] = a.seg_mu[(int64_t)row * a.ld_mu + j];
     for (int j = lane; j < DK; j += 64) tile[K + DK + j] = a.seg_sg[(int64_t)row * a.ld_sg + j];
-    const int64_t yoff = a.y_dyn ? (int64_t)a.y_dyn[0] * a.y_dyn_stride : 0;
-    const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
     for (int j = lane; j < D; j += 64) yv[j] = a.y[yrow * a.ldy + j];
   }
+  float eps = 0.f;
+  if (!a.from_tuple && a.eps_noise != 0.f) eps = jitter_eps(a, red);
   __syncthreads();
 
   const int groups = 64 / K;               // d-slots per sweep
@@ -311,17 +325,28 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
   const int k = lane % K, d0 = lane / K;
   const bool elem = active && lane < TPR;
   bool bad = false;
+  // per-element values kept for the backward half
+  float ez[kElemsPerLane], esg[kElemsPerLane], esg0[kElemsPerLane], eu[kElemsPerLane];
   float quad = 0.f, logdet = 0.f;
-  if (elem) {
-    for (int d = d0; d < D; d += groups) {
+#pragma unroll
+  for (int q = 0; q < kElemsPerLane; ++q) {
+    const int d = d0 + q * groups;
+    ez[q] = 0.f; esg[q] = 1.f; esg0[q] = 1.f; eu[q] = 0.f;
+    if (elem && d < D) {
       const float mu = tile[K + d * K + k];
       const float sraw = tile[K + DK + d * K + k];
-      float sg = a.from_tuple ? sraw : expf(sraw);
-      if (eps != 0.f) sg += jitter_u(a, row, d, k) * eps;
+      float sg0 = 1.f, sg, u = 0.f;
+      if (a.from_tuple) sg = sraw;
+      else {
+        sg0 = expf(sraw);
+        sg = sg0;
+        if (eps != 0.f) { u = jitter_u(a, row, d, k); sg += u * eps; }
+      }
       bad |= !(isfinite(mu) && isfinite(sg));
       const float z = (yv[d] - mu) / sg;
       quad += z * z;
       logdet += logf(sg);
+      ez[q] = z; esg[q] = sg; esg0[q] = sg0; eu[q] = u;
     }
   }
   pq[lane] = quad;
@@ -337,18 +362,17 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
     for (int j = 0; j < K; ++j) csum += fminf(fmaxf(expf(tile[j] - mx) / den, a.min_w), 1.0f);
   }
   __syncthreads();
-  float logp = 0.f;
   if (active && lane < K) {
     float q = 0.f, ld = 0.f;
     for (int j = lane; j < TPR; j += K) { q += pq[j]; ld += pl[j]; }
-    logp = -0.5f * q - ld - (float)D * kHalfLog2Pi;
+    const float logp = -0.5f * q - ld - (float)D * kHalfLog2Pi;
     const float w = a.from_tuple ? tile[lane]
                                  : fminf(fmaxf(expf(tile[lane] - mx) / den, a.min_w), 1.0f) / csum;
     const float lp = fminf(fmaxf(logp, -a.ll_limit), a.ll_limit);
     const float rv = lp + logf(fminf(fmaxf(w, a.min_w), 1.0f));
     bad |= !(isfinite(w) && isfinite(logp) && isfinite(rv));
     rk[lane] = rv;
-    pq[lane] = logp;                         // keep logp_k for the clamp indicator
+    lpk[lane] = logp;
   }
   __syncthreads();
   float lse = 0.f;
@@ -366,23 +390,17 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
   float uds = 0.f, dlogit = 0.f;
   if (bwd && elem) {
     const float sc = -expf(rk[k] - lse) * a.inv_norm;
-    const float lpk = pq[k];
-    const float g_lp = (lpk >= -a.ll_limit && lpk <= a.ll_limit) ? sc : 0.f;
-    for (int d = d0; d < D; d += groups) {
-      const float mu = tile[K + d * K + k];
-      const float sraw = tile[K + DK + d * K + k];
-      float sg0 = 1.f, sg, u = 0.f;
-      if (a.from_tuple) sg = sraw;
-      else {
-        sg0 = expf(sraw);
-        sg = sg0;
-        if (eps != 0.f) { u = jitter_u(a, row, d, k); sg += u * eps; }
+    const float lp0 = lpk[k];
+    const float g_lp = (lp0 >= -a.ll_limit && lp0 <= a.ll_limit) ? sc : 0.f;
+#pragma unroll
+    for (int q = 0; q < kElemsPerLane; ++q) {
+      const int d = d0 + q * groups;
+      if (d < D) {
+        const float dsg = g_lp * (ez[q] * ez[q] - 1.0f) / esg[q];
+        uds += eu[q] * dsg;
+        tile[K + d * K + k] = g_lp * ez[q] / esg[q];
+        tile[K + DK + d * K + k] = dsg * esg0[q];
       }
-      const float z = (yv[d] - mu) / sg;
-      const float dsg = g_lp * (z * z - 1.0f) / sg;
-      uds += u * dsg;
-      tile[K + d * K + k] = g_lp * z / sg;
-      tile[K + DK + d * K + k] = dsg * sg0;
     }
   }
   if (bwd && active && lane < K) {          // mixture-weight path, lane = component
@@ -429,15 +447,16 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
 // gradient term d pre += (EPS/(B*D*K)) * sum(u * dL/dsigma) * exp(pre) (the
 // non-detached mean of mdnn.py:115); column sums of the corrected d_out (the
 // head bias gradients).  Grid: x = 64-column groups of d_out, y = row slabs;
-// block = 64 columns x 4 row lanes.
-__global__ __launch_bounds__(256) void mdn_finish_kernel(
+// block = 64 columns x 16 row lanes.
+constexpr int kFinishLanes = 16;
+__global__ __launch_bounds__(64 * kFinishLanes) void mdn_finish_kernel(
     const float* __restrict__ block_lse, const float* __restrict__ block_uds, int nblocks,
     int batch, int pre_begin, int dk, int nh, float eps_noise, const float* __restrict__ pre,
     int64_t ld_pre, float* __restrict__ d_out, int64_t ld_dout, float* __restrict__ colsum,
     int rows_per_slab, float* __restrict__ loss, const int32_t* __restrict__ loss_slot,
     int32_t* __restrict__ nonfinite, FinishHook hook) {
-  __shared__ float red[8];
-  __shared__ float part[4][64];
+  __shared__ float red[16];
+  __shared__ float part[kFinishLanes][64];
   if (blockIdx.x == 0 && blockIdx.y == 0 && loss) {
     float s = 0.f;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += block_lse[i];
@@ -453,11 +472,13 @@ __global__ __launch_bounds__(256) void mdn_finish_kernel(
   if (hook.state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     int32_t* st = hook.state;
     if (hook.kind == 1) {           // end of the forward half of update `step`
-      const int step = st[0];
-      const double t = (double)(step + 1);
-      reinterpret_cast<float*>(st)[4] = (float)(hook.lr / (1.0 - pow(hook.beta1, t)));
-      reinterpret_cast<float*>(st)[5] = (float)(1.0 / sqrt(1.0 - pow(hook.beta2, t)));
-      st[0] = step + 1;
+      // beta^t as running products (double): no pow() on the device
+      double* bp = reinterpret_cast<double*>(st + 12);
+      const double b1t = bp[0] * hook.beta1, b2t = bp[1] * hook.beta2;
+      bp[0] = b1t; bp[1] = b2t;
+      reinterpret_cast<float*>(st)[4] = (float)(hook.lr / (1.0 - b1t));
+      reinterpret_cast<float*>(st)[5] = (float)(1.0 / sqrt(1.0 - b2t));
+      st[0] = st[0] + 1;
     } else {                        // end of a held-out evaluation
       st[1] = st[1] + 1;
     }
@@ -478,34 +499,52 @@ __global__ __launch_bounds__(256) void mdn_finish_kernel(
   const bool fix = c != 0.f && col >= pre_begin && col < pre_begin + dk;
   float acc = 0.f;
   if (col < nh) {
-    for (int row = r0 + rl; row < r1; row += 4) {
-      float v = d_out[(int64_t)row * ld_dout + col];
-      if (fix) {
-        v += c * expf(pre[(int64_t)row * ld_pre + (col - pre_begin)]);
-        d_out[(int64_t)row * ld_dout + col] = v;
+    for (int row0 = r0 + rl; row0 < r1; row0 += 8 * kFinishLanes) {   // 8 rows in flight
+      float dv[8], pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = min(row0 + kFinishLanes * u, r1 - 1);
+        dv[u] = d_out[(int64_t)row * ld_dout + col];
+        pv[u] = fix ? pre[(int64_t)row * ld_pre + (col - pre_begin)] : 0.f;
       }
-      acc += v;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = row0 + kFinishLanes * u;
+        if (row < r1) {
+          float v = dv[u];
+          if (fix) {
+            v += c * expf(pv[u]);
+            d_out[(int64_t)row * ld_dout + col] = v;
+          }
+          acc += v;
+        }
+      }
     }
   }
   if (!colsum) return;
   part[rl][cl] = acc;
   __syncthreads();
-  if (rl == 0 && col < nh)
-    colsum[(int64_t)blockIdx.y * nh + col] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+  if (rl == 0 && col < nh) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < kFinishLanes; ++q) t += part[q][cl];
+    colsum[(int64_t)blockIdx.y * nh + col] = t;
+  }
 }
 
 // forward() tuple, mdnn.py:109-119
 __global__ __launch_bounds__(256) void mdn_outputs_kernel(
     const float* __restrict__ o, int64_t ld, int batch, int D, int K, int Ls,
     const float* __restrict__ noise, uint64_t seed, uint64_t stream_id, float eps_noise,
-    float min_w, const float* __restrict__ sig_partials, float* __restrict__ weights,
+    float min_w, const float* __restrict__ sig_partials, int n_sig, float* __restrict__ weights,
     float* __restrict__ mu, float* __restrict__ l_d, float* __restrict__ lower,
     int32_t* __restrict__ nonfinite) {
   __shared__ float red[8];
   const int DK = D * K, Nh = K + 2 * DK + Ls * K;
   float eps = 0.f;
   if (eps_noise != 0.f) {
-    float s = (threadIdx.x < kSigBlocks) ? sig_partials[threadIdx.x] : 0.f;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_sig; i += blockDim.x) s += sig_partials[i];
     s = block_sum(s, red);
     eps = eps_noise * (s / ((float)batch * (float)DK));
   }
@@ -549,7 +588,7 @@ __global__ __launch_bounds__(256) void mdn_outputs_kernel(
 int colsum_launch(const float* x, int64_t ld, int64_t rows, int64_t cols, float* out,
                   void* workspace, size_t workspace_bytes, hipStream_t st);
 
-constexpr int kWavesPerBlock = 4;     // diag kernel: rows per workgroup
+constexpr int kWavesPerBlock = 8;     // diag kernel: rows per workgroup
 constexpr int kMaxSlabs = 64;         // finish kernel: row slabs for tall batches
 
 struct HeadGeom {
@@ -563,17 +602,20 @@ static int head_geom(const bsig_head_dims* d, int64_t batch, HeadGeom* g) {
   g->D = d->out_dim; g->K = d->n_comp;
   g->Ls = d->full_cov ? d->out_dim * (d->out_dim - 1) / 2 : 0;
   g->Nh = g->K + 2 * g->D * g->K + g->Ls * g->K;
-  g->wave_per_row = g->Ls == 0;
+  const int groups = 64 / g->K;
+  g->wave_per_row = g->Ls == 0 && ceil_div(g->D, groups) <= kElemsPerLane;
+  const size_t wave_lds =
+      (16 + (size_t)kWavesPerBlock * (g->Nh + g->D + 128 + 2 * g->K)) * sizeof(float);
+  if (g->wave_per_row && wave_lds > 60 * 1024) g->wave_per_row = false;
   if (g->wave_per_row) {
-    g->R = kWavesPerBlock; g->threads = kWavesPerBlock * 64;
-    g->lds = (16 + (size_t)kWavesPerBlock * (g->Nh + g->D + 128 + g->K)) * sizeof(float);
+    g->R = kWavesPerBlock; g->threads = kWavesPerBlock * 64; g->lds = wave_lds;
   } else {
     const int rmax = 256 / g->K;
     int R = (int)std::min<int64_t>(rmax, std::max<int64_t>(1, ceil_div<int64_t>(batch, 128)));
     for (;; --R) {
       const int threads = (int)round_up(R * g->K, 64);
       const size_t lds = ((size_t)R * (g->Nh + g->D + g->K) + 16 +
-                          (size_t)2 * g->D * threads) * sizeof(float);
+                          (g->Ls ? (size_t)2 * g->D * threads : 0)) * sizeof(float);
       if (lds <= 60 * 1024 || R == 1) {
         g->R = R; g->threads = threads; g->lds = lds;
         break;
@@ -590,10 +632,12 @@ static int head_geom(const bsig_head_dims* d, int64_t batch, HeadGeom* g) {
   return BSIG_OK;
 }
 
-// workspace floats: [sig partials][block_lse nblk][block_uds nblk][colsum slabs x Nh]
+// workspace floats: [sig partials kSigMax][block_lse nblk][block_uds nblk][colsum slabs x Nh]
 static size_t head_ws_floats(const HeadGeom& g) {
-  return kSigBlocks + 2 * (size_t)g.blocks + (size_t)kMaxSlabs * g.Nh;
+  return kSigMax + 2 * (size_t)g.blocks + (size_t)kMaxSlabs * g.Nh;
 }
+
+int head_sig_capacity() { return kSigMax; }
 
 int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t ld_w,
                         const float* seg_mu, int64_t ld_mu, const float* seg_sg,
@@ -614,14 +658,16 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
   BSIG_REQUIRE(!(colsum_out && !d_out), "mdn head: bias gradients need d_head_out");
   float* ws = reinterpret_cast<float*>(workspace);
   float* sig_partials = ws;
-  float* block_lse = ws + kSigBlocks;
+  float* block_lse = ws + kSigMax;
   float* block_uds = block_lse + g.blocks;
   float* slab_sums = block_uds + g.blocks;
   const int DK = g.D * g.K;
   const bool jitter = !from_tuple && dims->eps_noise != 0.f;
-  const bool sig_inline = g.wave_per_row && batch * DK <= 32768;
-  if (jitter && !sig_inline) {
-    hipLaunchKernelGGL(sigma0_sum_kernel, dim3(kSigBlocks), dim3(256), 0, st, seg_sg, ld_sg,
+  int n_sig = dyn ? dyn->n_sig_ready : 0;   // partial sums delivered by the producer of head_out
+  BSIG_REQUIRE(n_sig >= 0 && n_sig <= kSigMax, "mdn head: bad n_sig_ready");
+  if (jitter && n_sig == 0) {
+    n_sig = (int)std::min<int64_t>(kSigBlocks, ceil_div<int64_t>(batch * DK, 2048));
+    hipLaunchKernelGGL(sigma0_sum_kernel, dim3(n_sig), dim3(256), 0, st, seg_sg, ld_sg,
                        (int)batch, DK, sig_partials);
     BSIG_CHECK_LAUNCH("sigma0_sum");
   }
@@ -636,22 +682,24 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
   a.noise = noise; a.seed = seed; a.stream_id = stream_id; a.dyn_rng = dyn_rng;
   a.eps_noise = from_tuple ? 0.f : dims->eps_noise;
   a.min_w = dims->min_weight; a.ll_limit = dims->ll_limit;
-  a.sig_partials = sig_partials; a.sig_inline = sig_inline ? 1 : 0;
+  a.sig_partials = sig_partials; a.n_sig = n_sig;
   a.d_out = d_out; a.ld_dout = ld_dout;
   a.block_lse = block_lse; a.block_uds = block_uds; a.nonfinite = nonfinite;
   if (g.wave_per_row)
     hipLaunchKernelGGL(mdn_nll_diag_wave_kernel<kWavesPerBlock>, dim3(g.blocks),
                        dim3(g.threads), g.lds, st, a);
-  else
+  else if (g.Ls > 0)
     hipLaunchKernelGGL(mdn_nll_kernel<true>, dim3(g.blocks), dim3(g.threads), g.lds, st, a);
+  else
+    hipLaunchKernelGGL(mdn_nll_kernel<false>, dim3(g.blocks), dim3(g.threads), g.lds, st, a);
   BSIG_CHECK_LAUNCH("mdn_nll");
   // finish: loss, jitter-scale gradient correction, head bias gradients
   const bool correct = jitter && d_out != nullptr;
   const bool sweep = correct || colsum_out != nullptr;
   const dim3 fgrid(sweep ? (unsigned)ceil_div(g.Nh, 64) : 1u, sweep ? (unsigned)g.slabs : 1u);
   float* cs = colsum_out ? (g.slabs > 1 ? slab_sums : colsum_out) : nullptr;
-  hipLaunchKernelGGL(mdn_finish_kernel, fgrid, dim3(256), 0, st, block_lse, block_uds,
-                     g.blocks, (int)batch, g.K + DK, DK, g.Nh,
+  hipLaunchKernelGGL(mdn_finish_kernel, fgrid, dim3(64 * kFinishLanes), 0, st, block_lse,
+                     block_uds, g.blocks, (int)batch, g.K + DK, DK, g.Nh,
                      correct ? dims->eps_noise : 0.f, seg_sg, ld_sg, sweep ? d_out : nullptr,
                      ld_dout, cs, g.rows_per_slab, loss, loss_slot, nonfinite,
                      dyn ? dyn->hook : FinishHook());
@@ -690,19 +738,21 @@ extern "C" int bsig_mdn_head_outputs(const bsig_head_dims* dims, const float* he
   const int Ls = dims->full_cov ? D * (D - 1) / 2 : 0;
   BSIG_REQUIRE(!(Ls > 0 && !lower), "head_outputs: full covariance needs `lower`");
   BSIG_REQUIRE(ld >= bsig_head_width(dims), "head_outputs: ld too small");
-  BSIG_REQUIRE(workspace && workspace_bytes >= kSigBlocks * sizeof(float),
+  BSIG_REQUIRE(workspace && workspace_bytes >= kSigMax * sizeof(float),
                "head_outputs: workspace too small");
   float* sig_partials = reinterpret_cast<float*>(workspace);
   hipStream_t st = as_stream(stream);
+  int n_sig = 0;
   if (dims->eps_noise != 0.f) {
-    hipLaunchKernelGGL(sigma0_sum_kernel, dim3(kSigBlocks), dim3(256), 0, st,
+    n_sig = (int)std::min<int64_t>(kSigBlocks, ceil_div<int64_t>(batch * D * K, 2048));
+    hipLaunchKernelGGL(sigma0_sum_kernel, dim3(n_sig), dim3(256), 0, st,
                        head_out + K + D * K, ld, (int)batch, D * K, sig_partials);
     BSIG_CHECK_LAUNCH("sigma0_sum");
   }
   hipLaunchKernelGGL(mdn_outputs_kernel, dim3((int)std::min<int64_t>(batch, 2048)), dim3(256),
                      0, st, head_out, ld, (int)batch, D, K, Ls, noise, seed, stream_id,
-                     dims->eps_noise, dims->min_weight, sig_partials, weights, mu, l_d, lower,
-                     nonfinite);
+                     dims->eps_noise, dims->min_weight, sig_partials, n_sig, weights, mu, l_d,
+                     lower, nonfinite);
   BSIG_CHECK_LAUNCH("mdn_outputs");
   return BSIG_OK;
 }
@@ -735,6 +785,6 @@ extern "C" int bsig_mdn_head_nll(const bsig_head_dims* dims, const float* head_o
   return mdn_head_nll_launch(dims, head_out, ld, head_out + K, ld, head_out + K + D * K, ld,
                              dims->full_cov ? head_out + K + 2 * D * K : nullptr, ld, 0, y,
                              ldy, y_rows, batch, norm_batch, noise, seed, stream_id, nullptr,
-                             loss, nullptr, d_head_out, ld, nullptr, nonfinite, workspace, workspace_bytes,
-                             as_stream(stream), nullptr);
+                             loss, nullptr, d_head_out, ld, nullptr, nonfinite, workspace,
+                             workspace_bytes, as_stream(stream), nullptr);
 }
