@@ -4,6 +4,8 @@
 // all global traffic is lane-contiguous.
 #include "common.h"
 
+#include <algorithm>
+
 namespace bsig {
 
 // ------------------------------------------------------------------ K1
@@ -131,6 +133,68 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
   }
 }
 
+// Small summaries (Cartpole: 302 floats): one wavefront per trajectory, four
+// per workgroup, so a launch still covers the chip with lane-contiguous stores.
+__global__ __launch_bounds__(256) void crosscorr_wave_kernel(
+    const float* __restrict__ states, const float* __restrict__ actions,
+    float* __restrict__ out, int64_t n, int ts, int ta, int sd, int ad, int w,
+    int use_diff, int64_t ld_out, int32_t* __restrict__ nonfinite) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int sfeat = sd - 1;
+  const int S = w * sfeat, A = w * ad;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* sf = smem + wid * (S + A);
+  float* af = sf + S;
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < n; base += (int64_t)gridDim.x * 4) {
+    const int64_t traj = base + wid;
+    const bool active = traj < n;
+    __syncthreads();
+    if (active) {
+      const float* s = states + traj * (int64_t)ts * sd;
+      const float* a = actions + traj * (int64_t)ta * ad;
+      for (int e = lane; e < S; e += 64) {
+        const int t = e / sfeat, c = e - t * sfeat;
+        const float* srow = s + (int64_t)t * sd;
+        sf[e] = use_diff ? (srow[c + 1] - srow[c]) : srow[c];
+      }
+      for (int e = lane; e < A; e += 64) {
+        const int t = e / ad, c = e - t * ad;
+        af[e] = a[(int64_t)min(t, ta - 1) * ad + c];
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    float part = 0.f;
+    for (int i = lane; i < S; i += 64) part += sf[i];
+    const float mean = wave_sum(part) / (float)S;
+    part = 0.f;
+    for (int i = lane; i < S; i += 64) {
+      const float dlt = sf[i] - mean;
+      part += dlt * dlt;
+    }
+    const float ss = wave_sum(part);
+    const float sdev = (S < 2) ? 0.f : sqrtf(ss / (float)(S - 1));
+    float* o = out + traj * ld_out;
+    const int total = S * A;
+    bool bad = false;
+    const int step_i = 64 / A, step_j = 64 % A;
+    int i = lane / A, j = lane % A;
+    for (int e = lane; e < total; e += 64) {
+      const float v = sf[i] * af[j];
+      bad |= !isfinite(v);
+      o[e] = v;
+      i += step_i; j += step_j;
+      if (j >= A) { j -= A; ++i; }
+    }
+    if (lane == 0) {
+      o[total] = mean;
+      o[total + 1] = sdev;
+      bad |= !(isfinite(mean) && isfinite(sdev));
+    }
+    if (bad && nonfinite) atomicOr(nonfinite, 1);
+  }
+}
+
 // ------------------------------------------------------------------ K3
 // summary_signatory: summarizers.py:144-168.  Path X_l = [l+1 | s_l | a_l]
 // (:152-155), signature levels 1..depth in signatory's layout.  Chen's
@@ -148,8 +212,10 @@ __global__ void signature3_kernel(const float* __restrict__ states,
                                   int sd, int ad, int64_t ld_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d = 1 + sd + ad;
-  float* path = smem;                  // [length * d]
-  float* stage = smem + length * d;    // [d*d*d]
+  const int dp = (d + 3) & ~3;                 // increment rows padded to float4
+  float* path = smem;                          // [length * d]
+  float* delta = smem + ((length * d + 3) & ~3);   // [(length-1) * dp], zero padded
+  float* stage = delta + (length - 1) * dp;    // [d*d*d]
   const int tid = threadIdx.x, nt = blockDim.x;
   const int npairs = d * d;
   const int i = tid / d, j = tid % d;
@@ -159,11 +225,19 @@ __global__ void signature3_kernel(const float* __restrict__ states,
     const float* a = actions + traj * (int64_t)length * ad;
     float* o = out + traj * ld_out;
     __syncthreads();
-    for (int l = 0; l < length; ++l) {
-      float* row = path + l * d;
-      if (tid == 0) row[0] = (float)(l + 1);
-      for (int c = tid; c < sd; c += nt) row[1 + c] = s[(int64_t)l * sd + c];
-      for (int c = tid; c < ad; c += nt) row[1 + sd + c] = a[(int64_t)l * ad + c];
+    for (int e = tid; e < length * sd; e += nt) {
+      const int l = e / sd, c = e - l * sd;
+      path[l * d + 1 + c] = s[e];
+    }
+    for (int e = tid; e < length * ad; e += nt) {
+      const int l = e / ad, c = e - l * ad;
+      path[l * d + 1 + sd + c] = a[e];
+    }
+    for (int l = tid; l < length; l += nt) path[l * d] = (float)(l + 1);
+    __syncthreads();
+    for (int e = tid; e < (length - 1) * dp; e += nt) {
+      const int l = e / dp, c = e - l * dp;
+      delta[e] = c < d ? path[(l + 1) * d + c] - path[l * d + c] : 0.f;
     }
     __syncthreads();
     float s2 = 0.f;
@@ -173,20 +247,32 @@ __global__ void signature3_kernel(const float* __restrict__ states,
     if (active) {
       const float x0i = path[i];
       for (int l = 0; l + 1 < length; ++l) {
-        const float* p0 = path + l * d;
-        const float* p1 = p0 + d;
-        const float di = p1[i] - p0[i];
-        const float dj = p1[j] - p0[j];
-        const float s1i = p0[i] - x0i;
+        const float* dl = delta + l * dp;
+        const float di = dl[i], dj = dl[j];
+        const float s1i = path[l * d + i] - x0i;
         const float coef = s2 + (s1i + di * (1.0f / 3.0f)) * dj * 0.5f;
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k)
-          if (k < d) s3[k] = fmaf(coef, p1[k] - p0[k], s3[k]);
+        for (int k4 = 0; k4 < DMAX / 4; ++k4) {        // broadcast ds_read_b128
+          if (4 * k4 < d) {
+            const float4 q = *reinterpret_cast<const float4*>(dl + 4 * k4);
+            s3[4 * k4 + 0] = fmaf(coef, q.x, s3[4 * k4 + 0]);
+            s3[4 * k4 + 1] = fmaf(coef, q.y, s3[4 * k4 + 1]);
+            s3[4 * k4 + 2] = fmaf(coef, q.z, s3[4 * k4 + 2]);
+            s3[4 * k4 + 3] = fmaf(coef, q.w, s3[4 * k4 + 3]);
+          }
+        }
         s2 = fmaf(s1i + di * 0.5f, dj, s2);
       }
+      if ((d & 1) == 0) {   // 8-byte aligned row of the stage: ds_write_b64
 #pragma unroll
-      for (int k = 0; k < DMAX; ++k)
-        if (k < d) stage[tid * d + k] = s3[k];
+        for (int k = 0; k < DMAX; k += 2)
+          if (k < d)
+            *reinterpret_cast<float2*>(stage + tid * d + k) = make_float2(s3[k], s3[k + 1]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k)
+          if (k < d) stage[tid * d + k] = s3[k];
+      }
       o[d + tid] = s2;                                   // level 2
     }
     for (int c = tid; c < d; c += nt)                    // level 1
@@ -322,7 +408,16 @@ extern "C" int bsig_crosscorr(const float* states, const float* actions, float* 
     return BSIG_EUNSUPPORTED;
   }
   if (n == 0) return BSIG_OK;
-  const int vec4 = (ld_out % 4 == 0) && aligned(out, 16) && (4 * 256 >= A ? 1 : 1);
+  if (S * A <= 2048 && (S + A) * 4 * sizeof(float) <= 32 * 1024) {
+    const int64_t blocks = ceil_div<int64_t>(n, 4);
+    hipLaunchKernelGGL(crosscorr_wave_kernel, dim3((int)std::min<int64_t>(blocks, 65536)),
+                       dim3(256), (size_t)(S + A) * 4 * sizeof(float), as_stream(stream), states,
+                       actions, out, n, t_states, t_actions, sd, ad, w, use_state_diff, ld_out,
+                       nonfinite);
+    BSIG_CHECK_LAUNCH("crosscorr_wave");
+    return BSIG_OK;
+  }
+  const int vec4 = (ld_out % 4 == 0) && aligned(out, 16);
   hipLaunchKernelGGL(crosscorr_kernel, dim3(grid_for(n)), dim3(256), lds, as_stream(stream),
                      states, actions, out, n, t_states, t_actions, sd, ad, w,
                      use_state_diff, ld_out, vec4, nonfinite);
@@ -348,7 +443,8 @@ extern "C" int bsig_signature(const float* states, const float* actions, float* 
       set_error("signature: depth 3 needs path dim <= 32 (got %d)", d);
       return BSIG_EUNSUPPORTED;
     }
-    const size_t lds = ((size_t)length * d + (size_t)d * d * d) * sizeof(float);
+    const size_t lds = ((size_t)((length * d + 3) & ~3) + (size_t)(length - 1) * ((d + 3) & ~3) +
+                        (size_t)d * d * d) * sizeof(float);
     if (lds > 150 * 1024) {
       set_error("signature: %zu B of LDS needed", lds);
       return BSIG_EUNSUPPORTED;
