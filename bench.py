@@ -169,66 +169,118 @@ def nll_check(pkg, cfg, theta, states, actions, device):
         pkg.MDNN.EPS_NOISE = old
 
 
-def time_dominant_kernel(pkg, cfg, bsim, device, reps=200):
-    """HIP-event timing of the dominant kernel of this workload, launched
-    through the C ABI with the shapes of one update, on the stream the fit
-    uses.  cfg with RFF: the projection GEMM (MFMA-bound).  Otherwise the
-    summarizer (HBM-bound)."""
-    lib = pkg._lib.load()
+def _event_time(fn, reps, warm=5):
     stream = torch.cuda.current_stream()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if cfg['model'] == 'MDRFF':
-        rff = bsim.model.rff
-        b, i, mf = 100, rff.d, rff.m_feat
-        x = torch.randn(1000, pkg._lib.round_up(i, 4), device=device)
-        ids = torch.randint(0, 800, (b,), device=device, dtype=torch.int32)
-        co = rff.coeff()
-        feats = torch.empty(b, 2 * mf, device=device)
-        ws = torch.empty(int(lib.bsig_gemm_workspace_bytes(b, mf, i)) // 4 + 1, device=device)
-
-        def launch():
-            pkg._lib.check(lib.bsig_rff_project(
-                pkg._lib.ptr(x), x.stride(0), pkg._lib.ptr(ids), pkg._lib.ptr(co), co.stride(0),
-                None, pkg._lib.ptr(feats), feats.stride(0), b, i, mf, float(rff.a), 0,
-                pkg._lib.ptr(ws), ws.numel() * 4, pkg._lib.stream()))
-        flops = 2.0 * b * i * mf
-        for _ in range(20):
-            launch()
-        start.record(stream)
-        for _ in range(reps):
-            launch()
-        stop.record(stream)
-        stop.synchronize()
-        us = start.elapsed_time(stop) * 1e3 / reps
-        ach = flops / (us * 1e-6) / 1e12
-        return {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel (RFF projection %dx%dx%d + split-K '
-                'reduce/sincos epilogue)' % (b, mf, i), 'achieved': ach,
-                'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
-                'traffic': None, 'avg_us': us,
-                'algorithmic': '2*B*I*M = %.3e flop per launch' % flops}
-    n = 1000
-    th, st, ac = synth_pairs(cfg, n, 999, device)
-    for _ in range(5):
-        out = bsim._summarize(st, ac)
+    for _ in range(warm):
+        fn()
     start.record(stream)
-    for _ in range(reps // 4):
-        out = bsim._summarize(st, ac)
+    for _ in range(reps):
+        fn()
     stop.record(stream)
     stop.synchronize()
-    us = start.elapsed_time(stop) * 1e3 / (reps // 4)
+    return start.elapsed_time(stop) * 1e3 / reps
+
+
+def time_dominant_kernel(pkg, cfg, bsim, device):
+    """HIP-event timing (torch events on the stream the fit launches on) of the
+    dominant kernel of this workload, launched through the C ABI with the
+    shapes the fit uses.
+      MDRFF: the RFF projection of one run_training call — ONE fp32-MFMA GEMM
+             over the n_updates*B gathered minibatch rows (csrc/estimator.hip
+             hoists it out of the update loop) with the fused cos/sin epilogue.
+      MDNN : the first trunk layer GEMM of one update (gathered minibatch)."""
+    lib = pkg._lib.load()
+    L = pkg._lib
+    if cfg['model'] == 'MDRFF':
+        rff = bsim.model.rff
+        rows, i, mf = 100 * 100, rff.d, rff.m_feat
+        x = torch.randn(1000, L.round_up(i, 4), device=device)
+        ids = torch.randint(0, 800, (rows,), device=device, dtype=torch.int32)
+        co = rff.coeff()
+        feats = torch.empty(rows, 2 * mf, device=device)
+        ws = torch.empty(int(lib.bsig_gemm_workspace_bytes(rows, mf, i)) // 4 + 1, device=device)
+
+        def launch():
+            L.check(lib.bsig_rff_project(
+                L.ptr(x), x.stride(0), L.ptr(ids), L.ptr(co), co.stride(0), None, L.ptr(feats),
+                feats.stride(0), rows, i, mf, float(rff.a), 0, L.ptr(ws), ws.numel() * 4,
+                L.stream()))
+        us = _event_time(launch, 20)
+        flops = 2.0 * rows * i * mf
+        ach = flops / (us * 1e-6) / 1e12
+        return {'bound': 'mfma',
+                'kernel': 'gemm_mfma_kernel<2,2,2,2> RFF projection %dx%dx%d (all minibatch rows '
+                          'of one run_training call, gathered) + fused cos/sin epilogue'
+                          % (rows, mf, i),
+                'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_F32_TFLOPS, 'traffic': None, 'avg_us': us,
+                'algorithmic': '2*rows*I*M = %.3e flop per launch' % flops}
+    m = bsim.model
+    b, i, h0 = 100, m.input_dim, m._hidden[0]
+    x = torch.randn(1000, L.round_up(i, 4), device=device)
+    ids = torch.randint(0, 800, (b,), device=device, dtype=torch.int32)
+    w, bias = m.net[0].weight, m.net[0].bias
+    out = torch.empty(b, h0, device=device)
+    ws = torch.empty(int(lib.bsig_gemm_workspace_bytes(b, h0, i)) // 4 + 1, device=device)
+
+    def launch():
+        L.check(lib.bsig_gemm_f32(L.ptr(x), x.stride(0), 0, L.ptr(ids), L.ptr(w), w.stride(0), 0,
+                                  None, L.ptr(out), h0, b, h0, i, L.EPI_BIAS_ACT, L.ACT_TANH,
+                                  L.ptr(bias), None, 0, 1.0, L.ptr(ws), ws.numel() * 4,
+                                  L.stream()))
+    us = _event_time(launch, 200, 20)
+    flops = 2.0 * b * i * h0
+    ach = flops / (us * 1e-6) / 1e12
+    return {'bound': 'mfma',
+            'kernel': 'gemm_mfma_kernel trunk layer 1 %dx%dx%d (gathered minibatch, split-K + '
+                      'bias/tanh reduce) — latency bound at minibatch 100' % (b, h0, i),
+            'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': ach / PEAK_F32_TFLOPS, 'traffic': None, 'avg_us': us,
+            'algorithmic': '2*B*I*H = %.3e flop per launch' % flops}
+
+
+def summarizer_roofline(pkg, cfg, bsim, n, device):
+    """Secondary roofline: the summarizer over all of this rank's trajectories
+    in one launch (HBM bound)."""
+    th, st, ac = synth_pairs(cfg, n, 999, device)
+    out = bsim._summarize(st, ac)
+    us = _event_time(lambda: bsim._summarize(st, ac), 10, 2)
     sd, ad = cfg['sd'], cfg['ad']
     if cfg['summarizer'] in ('summary_start', 'summary_waypts'):
-        per_traj = 2 * 4 * 10 * (sd + ad)                       # read + write
+        per_traj = 2 * 4 * 10 * (sd + ad)
     elif cfg['summarizer'] in ('summary_corr', 'summary_corrdiff'):
         w = min(5 if sd > 50 else 10, cfg['t'])
         per_traj = 4 * (w * (sd + ad) + out.shape[1])
     else:
-        per_traj = 4 * (cfg['t'] * (1 + sd + ad) + out.shape[1])
-    nbytes = float(per_traj) * n
-    ach = nbytes / (us * 1e-6) / 1e9
-    return {'bound': 'hbm', 'kernel': cfg['summarizer'], 'achieved': ach, 'peak': PEAK_HBM_GBS,
-            'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None, 'avg_us': us,
-            'algorithmic': '%.3e bytes per launch (1000 trajectories)' % nbytes}
+        rows = 2 if out.shape[1] == 1 + sd + ad else cfg['t']
+        per_traj = 4 * (rows * (sd + ad) + out.shape[1])
+    ach = per_traj * n / (us * 1e-6) / 1e9
+    return {'bound': 'hbm', 'kernel': '%s over %d trajectories' % (cfg['summarizer'], n),
+            'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS,
+            'avg_us': us, 'algorithmic': '%d B per trajectory' % per_traj}
+
+
+def scaled_batch(pkg, cfg, theta, states, actions, device, batch=8192, epochs=10):
+    """Clearly separate from the headline: the same pairs as ONE chunk with a
+    large minibatch (B=8192, 10 epochs, one optimizer) — the regime where the
+    GEMMs are MFMA bound rather than latency bound."""
+    bs = build_gpu_model(pkg, cfg, device, 4321)
+    n = theta.shape[0]
+    n_updates = max(epochs * n // batch, 1)
+    np.random.seed(4321)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        summ = bs._summarize(states, actions)
+        logs = bs.model.run_training(summ, theta, n_updates, batch, test_frac=0.2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {'pairs_per_s': n / best, 'sgd_visits_per_s': n_updates * batch / best,
+            'batch': batch, 'n_updates': n_updates, 'heldout_nll': logs['test_loss'][-1],
+            'protocol': 'all %d pairs as one chunk, %d epochs of minibatch %d' % (n, epochs, batch)}
 
 
 T0 = time.perf_counter()
@@ -243,6 +295,7 @@ def main():
     ap.add_argument('--pairs', type=int, default=0, help='pairs per GPU (default: config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-scaled-batch', action='store_true')
     ap.add_argument('--watchdog', type=int, default=int(os.environ.get('BENCH_WATCHDOG', 1700)),
                     help='dump tracebacks and exit after this many seconds')
     ap.add_argument('--verbose', action='store_true')
@@ -332,10 +385,14 @@ def main():
         }
         note('timed region done: %.3f s' % dt)
         out['roofline'] = time_dominant_kernel(pkg, cfg, bsim, device)
+        out['roofline_summarizer'] = summarizer_roofline(pkg, cfg, bsim, min(n, 50000), device)
         note('roofline done')
         if world == 1:
             out['nll_match'] = nll_check(pkg, cfg, theta, states, actions, device)
             note('nll check done')
+            if not args.no_scaled_batch:
+                out['scaled_batch_mode'] = scaled_batch(pkg, cfg, theta, states, actions, device)
+                note('scaled batch done')
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(cfg, theta[:12000], states[:12000],
                                                    actions[:12000])
