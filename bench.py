@@ -323,9 +323,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
     dist = None
-    if world > 1:
+    force_dp = os.environ.get('BENCH_FORCE_DP') == '1'   # exercise the DP path with one rank
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device(device))
 
@@ -335,7 +337,7 @@ def main():
     theta, states, actions = synth_pairs(cfg, n, 1234 + rank, device)
     note('building model')
     bsim = build_gpu_model(pkg, cfg, device, 1234)
-    if world > 1:
+    if dist is not None:
         bsim.model.enable_data_parallel()
 
     def barrier():
@@ -379,6 +381,7 @@ def main():
                                100, ' per rank (global %d, grad all-reduce)' % (100 * world)
                                if world > 1 else ''),
                 'pairs_per_gpu': n, 'parallelism': 'dp%d' % world,
+                'gradient_exchange': 'rccl all-reduce' if dist is not None else 'none',
                 'hip_graph': not args.no_graph},
             'sgd_visits_per_sec': value * 10.0,
             'heldout_nll_last_step_mean': final_test,

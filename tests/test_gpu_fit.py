@@ -282,3 +282,35 @@ def test_rff_gemm_full_size_against_torch(B):
     torch.testing.assert_close(feats[:, :mf] ** 2 + feats[:, mf:] ** 2,
                                torch.full((b, mf), float(rff.a) ** 2, device=DEV),
                                rtol=1e-5, atol=1e-8)
+
+
+def test_data_parallel_path_single_rank_equals_fused(B):
+    """The data-parallel engine path (gradient graph -> RCCL all-reduce of the
+    flat gradient buffer -> flat Adam graph) on a 1-rank nccl group must
+    reproduce the fused single-rank path (same kernels for the gradient, Adam
+    as a separate kernel instead of a GEMM epilogue)."""
+    import os
+    import torch.distributed as dist
+    g = golden('chunk_mdrff_corrdiff.npz')
+    B.MDNN.EPS_NOISE = 0.0
+    states = torch.from_numpy(g['states']).to(DEV)
+    actions = torch.from_numpy(g['actions']).to(DEV)
+    theta = torch.from_numpy(g['theta']).to(DEV)
+    summ = B.summary_corrdiff(states, actions)
+    m1 = _chunk_model(B, 'mdrff_corrdiff', g, summ.shape[1])
+    l1 = m1.run_training(summ, theta, 100, 100, ids_table=g['ids'])
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29577')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        m2 = _chunk_model(B, 'mdrff_corrdiff', g, summ.shape[1]).enable_data_parallel()
+        l2 = m2.run_training(summ, theta, 100, 100, ids_table=g['ids'])
+    finally:
+        if created:
+            dist.destroy_process_group()
+    np.testing.assert_allclose(l2['test_loss'], l1['test_loss'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(l2['train_loss'], l1['train_loss'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(l2['test_loss'], g['test_loss'], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(m2._flat, m1._flat, rtol=1e-4, atol=1e-6)
