@@ -100,10 +100,125 @@ __device__ inline void epilogue_store(const GemmParams& p, int row, int col, flo
   }
 }
 
-// Epilogue of one 32x32 accumulator tile read back from the wave's LDS patch:
-// lane (h, l31) owns column `col` of rows rbase + 2*it, it = 0..15.  All
-// operand loads of the 16 rows are issued before the first store so that they
-// overlap (the pointers may alias as far as the compiler knows).
+// Epilogue of one 32x32 accumulator tile read back from the wave's LDS patch.
+// Vector form (tile fully inside N, 16-byte aligned pitches): lane l owns the
+// four consecutive columns 4*(l&7).. of rows (l>>3) + 8*it, it = 0..3 — every
+// global access is a 16-byte access, eight lanes cover one 128-byte row segment.
+// Scalar form (edge tiles / unaligned outputs): lane (h, l31) owns column l31 of
+// rows h + 2*it, it = 0..15.  In both, all operand loads are issued before the
+// first store so that they overlap (the pointers may alias for the compiler).
+struct F4 { float v[4]; };
+__device__ inline F4 ld4(const float* p) {
+  const float4 q = *reinterpret_cast<const float4*>(p);
+  return F4{{q.x, q.y, q.z, q.w}};
+}
+__device__ inline void st4(float* p, const F4& a) {
+  *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+
+template <int EPI>
+__device__ inline void tile_epilogue_vec(const GemmParams& p, const float* __restrict__ patch,
+                                         int row0, int col0, int lane, float& exp_acc) {
+  const int r8 = lane >> 3, c4 = (lane & 7) * 4;
+  const int col = col0 + c4;
+  F4 v[4];
+  bool ok[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    v[it] = ld4(patch + (it * 8 + r8) * 32 + c4);
+    ok[it] = row0 + it * 8 + r8 < p.m;
+  }
+  if constexpr (EPI == EPI_ADAM) {
+    F4 pm[4], pv[4], pp[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t e = ok[it] ? (int64_t)(row0 + it * 8 + r8) * p.ldc + col : 0;
+      pm[it] = ld4(p.adam_m + e); pv[it] = ld4(p.adam_v + e); pp[it] = ld4(p.c + e);
+    }
+    const float ss = p.adam_dyn[0], ib = p.adam_dyn[1];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (ok[it]) {
+        const int64_t e = (int64_t)(row0 + it * 8 + r8) * p.ldc + col;
+        if (p.grad_out) st4(p.grad_out + e, v[it]);
+        F4 m1, v1, p1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float g = v[it].v[q];
+          m1.v[q] = pm[it].v[q] + (g - pm[it].v[q]) * (1.0f - p.beta1);
+          v1.v[q] = pv[it].v[q] * p.beta2 + (1.0f - p.beta2) * g * g;
+          p1.v[q] = pp[it].v[q] - ss * (m1.v[q] / (sqrtf(v1.v[q]) * ib + p.adam_eps));
+        }
+        st4(p.adam_m + e, m1); st4(p.adam_v + e, v1); st4(p.c + e, p1);
+      }
+    }
+    if (col == 0 && p.bias_p) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 8 + r8;
+        if (ok[it]) {
+          const float g = p.bias_g[row];
+          const float bm = p.bias_m[row] + (g - p.bias_m[row]) * (1.0f - p.beta1);
+          const float bv = p.bias_v[row] * p.beta2 + (1.0f - p.beta2) * g * g;
+          p.bias_m[row] = bm;
+          p.bias_v[row] = bv;
+          p.bias_p[row] = p.bias_p[row] - ss * (bm / (sqrtf(bv) * ib + p.adam_eps));
+        }
+      }
+    }
+  } else if constexpr (EPI == BSIG_EPI_MUL_DACT) {
+    F4 hv[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      hv[it] = ld4(p.aux + (ok[it] ? (int64_t)(row0 + it * 8 + r8) * p.ldaux + col : 0));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (ok[it]) {
+        F4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o.v[q] = v[it].v[q] * act_bwd_from_out(hv[it].v[q], p.act);
+        st4(p.c + (int64_t)(row0 + it * 8 + r8) * p.ldc + col, o);
+      }
+    }
+  } else if constexpr (EPI < 0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (ok[it])
+        st4(p.partial + ((int64_t)blockIdx.z * p.m + row0 + it * 8 + r8) * p.n + col, v[it]);
+  } else {
+    F4 bias{{0.f, 0.f, 0.f, 0.f}};
+    if constexpr (EPI == BSIG_EPI_BIAS || EPI == BSIG_EPI_BIAS_ACT || EPI == BSIG_EPI_COS_OFF)
+      bias = ld4(p.bias + col);
+    const bool want_exp = EPI == BSIG_EPI_BIAS && p.expsum != nullptr;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (ok[it]) {
+        float* dst = p.c + (int64_t)(row0 + it * 8 + r8) * p.ldc + col;
+        F4 o, o2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float x = v[it].v[q];
+          if constexpr (EPI == BSIG_EPI_NONE) o.v[q] = x;
+          else if constexpr (EPI == BSIG_EPI_BIAS) {
+            o.v[q] = x + bias.v[q];
+            if (want_exp && col + q >= p.expsum_col0 && col + q < p.expsum_col0 + p.expsum_ncols)
+              exp_acc += expf(o.v[q]);
+          } else if constexpr (EPI == BSIG_EPI_BIAS_ACT) o.v[q] = act_fwd(x + bias.v[q], p.act);
+          else if constexpr (EPI == BSIG_EPI_COS_OFF) o.v[q] = p.alpha * cosf(x + bias.v[q]);
+          else {
+            float sn, cs;
+            sincosf(x, &sn, &cs);
+            o.v[q] = p.alpha * cs;
+            o2.v[q] = p.alpha * sn;
+          }
+        }
+        st4(dst, o);
+        if constexpr (EPI == BSIG_EPI_COS_SIN) st4(dst + p.n, o2);
+      }
+    }
+  }
+}
+
 template <int EPI>
 __device__ inline void tile_epilogue(const GemmParams& p, const float* __restrict__ patch,
                                      int rbase, int col, int h, int l31, float& exp_acc) {
@@ -112,26 +227,29 @@ __device__ inline void tile_epilogue(const GemmParams& p, const float* __restric
   for (int it = 0; it < 16; ++it) v[it] = patch[(2 * it + h) * 32 + l31];
   const bool colok = col < p.n;
   if constexpr (EPI == EPI_ADAM) {
-    float pm[16], pv[16], pp[16];
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = rbase + 2 * it;
-      const int64_t e = (colok && row < p.m) ? (int64_t)row * p.ldc + col : 0;
-      pm[it] = p.adam_m[e]; pv[it] = p.adam_v[e]; pp[it] = p.c[e];
-    }
     const float ss = p.adam_dyn[0], ib = p.adam_dyn[1];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = rbase + 2 * it;
-      if (colok && row < p.m) {
-        const int64_t e = (int64_t)row * p.ldc + col;
-        const float g = v[it];
-        if (p.grad_out) p.grad_out[e] = g;
-        const float m1 = pm[it] + (g - pm[it]) * (1.0f - p.beta1);
-        const float v1 = pv[it] * p.beta2 + (1.0f - p.beta2) * g * g;
-        p.adam_m[e] = m1;
-        p.adam_v[e] = v1;
-        p.c[e] = pp[it] - ss * (m1 / (sqrtf(v1) * ib + p.adam_eps));
+    for (int half = 0; half < 2; ++half) {     // 8 rows' optimizer state in flight
+      float pm[8], pv[8], pp[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = rbase + 2 * (half * 8 + u);
+        const int64_t e = (colok && row < p.m) ? (int64_t)row * p.ldc + col : 0;
+        pm[u] = p.adam_m[e]; pv[u] = p.adam_v[e]; pp[u] = p.c[e];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = rbase + 2 * (half * 8 + u);
+        if (colok && row < p.m) {
+          const int64_t e = (int64_t)row * p.ldc + col;
+          const float g = v[half * 8 + u];
+          if (p.grad_out) p.grad_out[e] = g;
+          const float m1 = pm[u] + (g - pm[u]) * (1.0f - p.beta1);
+          const float v1 = pv[u] * p.beta2 + (1.0f - p.beta2) * g * g;
+          p.adam_m[e] = m1;
+          p.adam_v[e] = v1;
+          p.c[e] = pp[u] - ss * (m1 / (sqrtf(v1) * ib + p.adam_eps));
+        }
       }
     }
     if (col == 0 && p.bias_p) {
@@ -197,18 +315,43 @@ __device__ inline void tile_epilogue(const GemmParams& p, const float* __restric
   }
 }
 
+// can this launch use 16-byte epilogue accesses?  (uniform over the grid)
+__device__ inline bool epilogue_vec_ok(const GemmParams& p) {
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (p.splits > 1) return (p.n & 3) == 0 && al(p.partial);
+  bool ok = (p.ldc & 3) == 0 && al(p.c);
+  switch (p.epilogue) {
+    case BSIG_EPI_BIAS: case BSIG_EPI_BIAS_ACT: case BSIG_EPI_COS_OFF: ok = ok && al(p.bias); break;
+    case BSIG_EPI_COS_SIN: ok = ok && (p.n & 3) == 0; break;
+    case BSIG_EPI_MUL_DACT: ok = ok && (p.ldaux & 3) == 0 && al(p.aux); break;
+    case EPI_ADAM:
+      ok = ok && al(p.adam_m) && al(p.adam_v) && (!p.grad_out || al(p.grad_out));
+      break;
+    default: break;
+  }
+  return ok;
+}
+
+#define BSIG_EPI_DISPATCH(FN, ...)                                                   \
+  switch (p.splits > 1 ? -1 : p.epilogue) {                                          \
+    case -1: FN<-1>(__VA_ARGS__); break;                                             \
+    case BSIG_EPI_NONE: FN<BSIG_EPI_NONE>(__VA_ARGS__); break;                       \
+    case BSIG_EPI_BIAS: FN<BSIG_EPI_BIAS>(__VA_ARGS__); break;                       \
+    case BSIG_EPI_BIAS_ACT: FN<BSIG_EPI_BIAS_ACT>(__VA_ARGS__); break;               \
+    case BSIG_EPI_COS_SIN: FN<BSIG_EPI_COS_SIN>(__VA_ARGS__); break;                 \
+    case BSIG_EPI_COS_OFF: FN<BSIG_EPI_COS_OFF>(__VA_ARGS__); break;                 \
+    case BSIG_EPI_MUL_DACT: FN<BSIG_EPI_MUL_DACT>(__VA_ARGS__); break;               \
+    default: FN<EPI_ADAM>(__VA_ARGS__); break;                                       \
+  }
+
 __device__ __forceinline__ void run_tile_epilogue(const GemmParams& p, const float* patch,
-                                                  int rbase, int col, int h, int l31,
+                                                  int row0, int col0, int lane, bool vec,
                                                   float& exp_acc) {
-  switch (p.splits > 1 ? -1 : p.epilogue) {
-    case -1: tile_epilogue<-1>(p, patch, rbase, col, h, l31, exp_acc); break;
-    case BSIG_EPI_NONE: tile_epilogue<BSIG_EPI_NONE>(p, patch, rbase, col, h, l31, exp_acc); break;
-    case BSIG_EPI_BIAS: tile_epilogue<BSIG_EPI_BIAS>(p, patch, rbase, col, h, l31, exp_acc); break;
-    case BSIG_EPI_BIAS_ACT: tile_epilogue<BSIG_EPI_BIAS_ACT>(p, patch, rbase, col, h, l31, exp_acc); break;
-    case BSIG_EPI_COS_SIN: tile_epilogue<BSIG_EPI_COS_SIN>(p, patch, rbase, col, h, l31, exp_acc); break;
-    case BSIG_EPI_COS_OFF: tile_epilogue<BSIG_EPI_COS_OFF>(p, patch, rbase, col, h, l31, exp_acc); break;
-    case BSIG_EPI_MUL_DACT: tile_epilogue<BSIG_EPI_MUL_DACT>(p, patch, rbase, col, h, l31, exp_acc); break;
-    default: tile_epilogue<EPI_ADAM>(p, patch, rbase, col, h, l31, exp_acc); break;
+  if (vec && col0 + 32 <= p.n) {
+    BSIG_EPI_DISPATCH(tile_epilogue_vec, p, patch, row0, col0, lane, exp_acc)
+  } else {
+    const int h = lane >> 5, l31 = lane & 31;
+    BSIG_EPI_DISPATCH(tile_epilogue, p, patch, row0 + h, col0 + l31, h, l31, exp_acc)
   }
 }
 
@@ -424,14 +567,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   // the epilogue itself is a runtime switch.
   float* patch = smem + wid * (32 * 32);
   float exp_acc = 0.f;
+  const bool vec_epi = epilogue_vec_ok(p);
   // (i, j) enumerated explicitly: the accumulator indices must be constants
 #define BSIG_TILE_EPILOGUE(I, J)                                                          \
   if constexpr ((I) < TM && (J) < TN) {                                                   \
     _Pragma("unroll") for (int q = 0; q < 16; ++q)                                        \
         patch[((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + l31] = acc[I][J][q];                \
     __builtin_amdgcn_wave_barrier();                                                      \
-    run_tile_epilogue(p, patch, m0 + (wm * TM + (I)) * 32 + h,                            \
-                      n0 + (wn * TN + (J)) * 32 + l31, h, l31, exp_acc);                  \
+    run_tile_epilogue(p, patch, m0 + (wm * TM + (I)) * 32, n0 + (wn * TN + (J)) * 32,     \
+                      lane, vec_epi, exp_acc);                                            \
     __builtin_amdgcn_wave_barrier();                                                      \
   }
   BSIG_TILE_EPILOGUE(0, 0)
