@@ -6,7 +6,7 @@ Host-side mirror of the reference's Python interface for this path
 (include/bsig.h, csrc/*.hip).  ``compat.install()`` registers the
 reference's module paths (``bayes_sim_ig.models.mdnn`` ...) as aliases.
 """
-from . import _lib, pdf, summarizers          # noqa: F401
+from . import _lib, pairs, pdf, summarizers   # noqa: F401
 from .bayes_sim import BayesSim               # noqa: F401
 from .mdnn import MDNN                        # noqa: F401
 from .mdrff import MDRFF                      # noqa: F401
