@@ -152,17 +152,23 @@ __device__ inline void tile_epilogue_vec(const GemmParams& p, const float* __res
         st4(p.adam_m + e, m1); st4(p.adam_v + e, v1); st4(p.c + e, p1);
       }
     }
-    if (col == 0 && p.bias_p) {
+    if (col == 0 && p.bias_p) {   // this lane also owns the bias of its 4 rows
+      float bg[4], bm0[4], bv0[4], bp0[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int row = row0 + it * 8 + r8;
+        const int row = ok[it] ? row0 + it * 8 + r8 : 0;
+        bg[it] = p.bias_g[row]; bm0[it] = p.bias_m[row];
+        bv0[it] = p.bias_v[row]; bp0[it] = p.bias_p[row];
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
         if (ok[it]) {
-          const float g = p.bias_g[row];
-          const float bm = p.bias_m[row] + (g - p.bias_m[row]) * (1.0f - p.beta1);
-          const float bv = p.bias_v[row] * p.beta2 + (1.0f - p.beta2) * g * g;
+          const int row = row0 + it * 8 + r8;
+          const float bm = bm0[it] + (bg[it] - bm0[it]) * (1.0f - p.beta1);
+          const float bv = bv0[it] * p.beta2 + (1.0f - p.beta2) * bg[it] * bg[it];
           p.bias_m[row] = bm;
           p.bias_v[row] = bv;
-          p.bias_p[row] = p.bias_p[row] - ss * (bm / (sqrtf(bv) * ib + p.adam_eps));
+          p.bias_p[row] = bp0[it] - ss * (bm / (sqrtf(bv) * ib + p.adam_eps));
         }
       }
     }

@@ -290,24 +290,37 @@ __global__ void mdn_nll_kernel(HeadArgs a) {
 }
 
 // ---- diagonal covariance, one wavefront per row ------------------------------
+// A wave never depends on another wave's LDS data here (each row is private),
+// so the phases are ordered by the in-order LDS pipeline of the wave itself
+// (wave_barrier only pins the compiler); the one workgroup barrier is the final
+// hand-over of the per-wave sums.  Per-component sums over the dimensions are
+// strided wavefront shuffles; the jitter draws use all four Philox outputs.
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int D = a.D, K = a.K, Nh = a.Nh;
   const int DK = D * K;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int per_wave = Nh + D + 2 * 64 + 2 * K;
-  float* red = smem;                       // [16]
-  float* tile = smem + 16 + wid * per_wave;  // [Nh]
+  const int per_wave = Nh + D + 3 * K;
+  float* wsum = smem;                      // [2][WPB] per-wave lse / uds
+  float* tile = smem + 32 + wid * per_wave;  // [Nh]
   float* yv = tile + Nh;                   // [D]
-  float* pq = yv + D;                      // [64] partial quad
-  float* pl = pq + 64;                     // [64] partial logdet
-  float* rk = pl + 64;                     // [K] clamp(logp)+log clamp(w)
+  float* rk = yv + D;                      // [K] clamp(logp)+log clamp(w)
   float* lpk = rk + K;                     // [K] raw logp (clamp indicator)
+  float* dlg = lpk + K;                    // [K] d loss / d logits
   const int row = blockIdx.x * WPB + wid;
   const bool active = row < a.batch;
 
   // every independent global load is issued before anything waits
+  const bool want_eps = !a.from_tuple && a.eps_noise != 0.f;
+  float sp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (want_eps) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = lane + 64 * u;
+      sp[u] = i < a.n_sig ? a.sig_partials[i] : 0.f;
+    }
+  }
   if (active) {
     const int64_t yoff = a.y_dyn ? (int64_t)a.y_dyn[0] * a.y_dyn_stride : 0;
     const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
@@ -316,9 +329,15 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
     for (int j = lane; j < DK; j += 64) tile[K + DK + j] = a.seg_sg[(int64_t)row * a.ld_sg + j];
     for (int j = lane; j < D; j += 64) yv[j] = a.y[yrow * a.ldy + j];
   }
+  // jitter scale eps = EPS_NOISE * mean(exp(pre)): every wave adds the same
+  // partial sums in the same order
   float eps = 0.f;
-  if (!a.from_tuple && a.eps_noise != 0.f) eps = jitter_eps(a, red);
-  __syncthreads();
+  if (want_eps) {
+    float s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+    for (int i = lane + 256; i < a.n_sig; i += 64) s += a.sig_partials[i];
+    eps = a.eps_noise * (wave_sum(s) / ((float)a.batch * (float)DK));
+  }
+  __builtin_amdgcn_wave_barrier();
 
   const int groups = 64 / K;               // d-slots per sweep
   const int TPR = groups * K;
@@ -328,10 +347,16 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
   // per-element values kept for the backward half
   float ez[kElemsPerLane], esg[kElemsPerLane], esg0[kElemsPerLane], eu[kElemsPerLane];
   float quad = 0.f, logdet = 0.f;
+  Philox4 ph{{0u, 0u, 0u, 0u}};
+  const bool draw = eps != 0.f && a.noise == nullptr;
+  const uint64_t rng_seed = a.dyn_rng ? a.dyn_rng[0] : a.seed;
+  const uint64_t rng_sid = a.dyn_rng ? a.dyn_rng[1] : a.stream_id;
 #pragma unroll
   for (int q = 0; q < kElemsPerLane; ++q) {
     const int d = d0 + q * groups;
     ez[q] = 0.f; esg[q] = 1.f; esg0[q] = 1.f; eu[q] = 0.f;
+    if ((q & 3) == 0 && draw && elem)
+      ph = philox4x32_10(rng_seed, rng_sid, ((uint64_t)row * 64 + lane) * 2 + (q >> 2));
     if (elem && d < D) {
       const float mu = tile[K + d * K + k];
       const float sraw = tile[K + DK + d * K + k];
@@ -340,7 +365,10 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
       else {
         sg0 = expf(sraw);
         sg = sg0;
-        if (eps != 0.f) { u = jitter_u(a, row, d, k); sg += u * eps; }
+        if (eps != 0.f) {
+          u = a.noise ? a.noise[((int64_t)row * D + d) * K + k] : u01(ph.v[q & 3]);
+          sg += u * eps;
+        }
       }
       bad |= !(isfinite(mu) && isfinite(sg));
       const float z = (yv[d] - mu) / sg;
@@ -349,8 +377,14 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
       ez[q] = z; esg[q] = sg; esg0[q] = sg0; eu[q] = u;
     }
   }
-  pq[lane] = quad;
-  pl[lane] = logdet;
+  // sum over the dimensions of each component: lanes k, k+K, k+2K, ...
+  for (int off = 32; off >= 1; off >>= 1) {
+    if (off < groups || off == 1) {
+      const float tq = __shfl_down(quad, off * K, 64);
+      const float tl = __shfl_down(logdet, off * K, 64);
+      if (d0 + off < groups && lane + off * K < 64) { quad += tq; logdet += tl; }
+    }
+  }
   // mixture weights (every lane, redundantly: K is small)
   float mx = 0.f, den = 1.f, csum = 1.f;
   if (active && !a.from_tuple) {
@@ -361,11 +395,8 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
     csum = 0.f;
     for (int j = 0; j < K; ++j) csum += fminf(fmaxf(expf(tile[j] - mx) / den, a.min_w), 1.0f);
   }
-  __syncthreads();
   if (active && lane < K) {
-    float q = 0.f, ld = 0.f;
-    for (int j = lane; j < TPR; j += K) { q += pq[j]; ld += pl[j]; }
-    const float logp = -0.5f * q - ld - (float)D * kHalfLog2Pi;
+    const float logp = -0.5f * quad - logdet - (float)D * kHalfLog2Pi;
     const float w = a.from_tuple ? tile[lane]
                                  : fminf(fmaxf(expf(tile[lane] - mx) / den, a.min_w), 1.0f) / csum;
     const float lp = fminf(fmaxf(logp, -a.ll_limit), a.ll_limit);
@@ -374,7 +405,7 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
     rk[lane] = rv;
     lpk[lane] = logp;
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   float lse = 0.f;
   if (active) {
     float m2 = rk[0];
@@ -383,11 +414,9 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
     for (int j = 0; j < K; ++j) se += expf(rk[j] - m2);
     lse = m2 + logf(se);
   }
-  const float lse_sum = block_sum((active && lane == 0) ? lse : 0.f, red);
-  if (tid == 0) a.block_lse[blockIdx.x] = lse_sum;
 
   const bool bwd = a.d_out != nullptr;
-  float uds = 0.f, dlogit = 0.f;
+  float uds = 0.f;
   if (bwd && elem) {
     const float sc = -expf(rk[k] - lse) * a.inv_norm;
     const float lp0 = lpk[k];
@@ -404,6 +433,7 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
     }
   }
   if (bwd && active && lane < K) {          // mixture-weight path, lane = component
+    float dlogit;
     if (a.from_tuple) {
       const float w = tile[lane];
       const float sc = -expf(rk[lane] - lse) * a.inv_norm;
@@ -429,16 +459,24 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
       }
       dlogit = s_k * (gs_k - s2);
     }
+    dlg[lane] = dlogit;                     // separate slot: the logits stay readable
   }
-  const float uds_sum = block_sum(uds, red);   // barrier: logits are read before they change
-  if (tid == 0 && a.block_uds) a.block_uds[blockIdx.x] = uds_sum;
-  if (bwd) {
-    if (active && lane < K) tile[lane] = dlogit;
-    __syncthreads();
-    if (active) {
-      float* o = a.d_out + (int64_t)row * a.ld_dout;
-      for (int j = lane; j < Nh; j += 64) o[j] = tile[j];
-    }
+  __builtin_amdgcn_wave_barrier();
+  if (bwd && active) {
+    float* o = a.d_out + (int64_t)row * a.ld_dout;
+    for (int j = lane; j < K; j += 64) o[j] = dlg[j];
+    for (int j = K + lane; j < Nh; j += 64) o[j] = tile[j];
+  }
+  // per-wave sums -> one partial per workgroup, fixed order
+  const float uds_w = wave_sum(uds);
+  if (lane == 0) { wsum[wid] = active ? lse : 0.f; wsum[WPB + wid] = uds_w; }
+  __syncthreads();
+  if (tid == 0) {
+    float sl = 0.f, su = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) { sl += wsum[w]; su += wsum[WPB + w]; }
+    a.block_lse[blockIdx.x] = sl;
+    if (a.block_uds) a.block_uds[blockIdx.x] = su;
   }
   if (bad && a.nonfinite) atomicOr(a.nonfinite, 1);
 }
@@ -605,7 +643,7 @@ static int head_geom(const bsig_head_dims* d, int64_t batch, HeadGeom* g) {
   const int groups = 64 / g->K;
   g->wave_per_row = g->Ls == 0 && ceil_div(g->D, groups) <= kElemsPerLane;
   const size_t wave_lds =
-      (16 + (size_t)kWavesPerBlock * (g->Nh + g->D + 128 + 2 * g->K)) * sizeof(float);
+      (32 + (size_t)kWavesPerBlock * (g->Nh + g->D + 3 * g->K)) * sizeof(float);
   if (g->wave_per_row && wave_lds > 60 * 1024) g->wave_per_row = false;
   if (g->wave_per_row) {
     g->R = kWavesPerBlock; g->threads = kWavesPerBlock * 64; g->lds = wave_lds;
