@@ -118,7 +118,8 @@ __device__ inline void st4(float* p, const F4& a) {
 
 template <int EPI>
 __device__ inline void tile_epilogue_vec(const GemmParams& p, const float* __restrict__ patch,
-                                         int row0, int col0, int lane, float& exp_acc) {
+                                         int row0, int col0, int lane, float& exp_acc,
+                                         float adam_ss, float adam_ib) {
   const int r8 = lane >> 3, c4 = (lane & 7) * 4;
   const int col = col0 + c4;
   F4 v[4];
@@ -129,37 +130,48 @@ __device__ inline void tile_epilogue_vec(const GemmParams& p, const float* __res
     ok[it] = row0 + it * 8 + r8 < p.m;
   }
   if constexpr (EPI == EPI_ADAM) {
-    F4 pm[4], pv[4], pp[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int64_t e = ok[it] ? (int64_t)(row0 + it * 8 + r8) * p.ldc + col : 0;
-      pm[it] = ld4(p.adam_m + e); pv[it] = ld4(p.adam_v + e); pp[it] = ld4(p.c + e);
-    }
-    const float ss = p.adam_dyn[0], ib = p.adam_dyn[1];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      if (ok[it]) {
-        const int64_t e = (int64_t)(row0 + it * 8 + r8) * p.ldc + col;
-        if (p.grad_out) st4(p.grad_out + e, v[it]);
-        F4 m1, v1, p1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float g = v[it].v[q];
-          m1.v[q] = pm[it].v[q] + (g - pm[it].v[q]) * (1.0f - p.beta1);
-          v1.v[q] = pv[it].v[q] * p.beta2 + (1.0f - p.beta2) * g * g;
-          p1.v[q] = pp[it].v[q] - ss * (m1.v[q] / (sqrtf(v1.v[q]) * ib + p.adam_eps));
-        }
-        st4(p.adam_m + e, m1); st4(p.adam_v + e, v1); st4(p.c + e, p1);
-      }
-    }
-    if (col == 0 && p.bias_p) {   // this lane also owns the bias of its 4 rows
-      float bg[4], bm0[4], bv0[4], bp0[4];
+    // every optimizer-state load (weights and, for the column-0 lanes, the
+    // layer bias) is in flight before the first dependent instruction
+    const bool own_bias = col == 0 && p.bias_p != nullptr;
+    float bg[4] = {0.f, 0.f, 0.f, 0.f}, bm0[4] = {0.f, 0.f, 0.f, 0.f};
+    float bv0[4] = {0.f, 0.f, 0.f, 0.f}, bp0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (own_bias) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = ok[it] ? row0 + it * 8 + r8 : 0;
         bg[it] = p.bias_g[row]; bm0[it] = p.bias_m[row];
         bv0[it] = p.bias_v[row]; bp0[it] = p.bias_p[row];
       }
+    }
+    const float ss = adam_ss, ib = adam_ib;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {   // two rows' state in flight: bounded registers
+      F4 pm[2], pv[2], pp[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int it = half * 2 + u;
+        const int64_t e = ok[it] ? (int64_t)(row0 + it * 8 + r8) * p.ldc + col : 0;
+        pm[u] = ld4(p.adam_m + e); pv[u] = ld4(p.adam_v + e); pp[u] = ld4(p.c + e);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int it = half * 2 + u;
+        if (ok[it]) {
+          const int64_t e = (int64_t)(row0 + it * 8 + r8) * p.ldc + col;
+          if (p.grad_out) st4(p.grad_out + e, v[it]);
+          F4 m1, v1, p1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float g = v[it].v[q];
+            m1.v[q] = pm[u].v[q] + (g - pm[u].v[q]) * (1.0f - p.beta1);
+            v1.v[q] = pv[u].v[q] * p.beta2 + (1.0f - p.beta2) * g * g;
+            p1.v[q] = pp[u].v[q] - ss * (m1.v[q] / (sqrtf(v1.v[q]) * ib + p.adam_eps));
+          }
+          st4(p.adam_m + e, m1); st4(p.adam_v + e, v1); st4(p.c + e, p1);
+        }
+      }
+    }
+    if (own_bias) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         if (ok[it]) {
@@ -227,28 +239,29 @@ __device__ inline void tile_epilogue_vec(const GemmParams& p, const float* __res
 
 template <int EPI>
 __device__ inline void tile_epilogue(const GemmParams& p, const float* __restrict__ patch,
-                                     int rbase, int col, int h, int l31, float& exp_acc) {
+                                     int rbase, int col, int h, int l31, float& exp_acc,
+                                     float adam_ss, float adam_ib) {
   float v[16];
 #pragma unroll
   for (int it = 0; it < 16; ++it) v[it] = patch[(2 * it + h) * 32 + l31];
   const bool colok = col < p.n;
   if constexpr (EPI == EPI_ADAM) {
-    const float ss = p.adam_dyn[0], ib = p.adam_dyn[1];
+    const float ss = adam_ss, ib = adam_ib;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {     // 8 rows' optimizer state in flight
-      float pm[8], pv[8], pp[8];
+    for (int half = 0; half < 4; ++half) {     // 4 rows' optimizer state in flight
+      float pm[4], pv[4], pp[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int row = rbase + 2 * (half * 8 + u);
+      for (int u = 0; u < 4; ++u) {
+        const int row = rbase + 2 * (half * 4 + u);
         const int64_t e = (colok && row < p.m) ? (int64_t)row * p.ldc + col : 0;
         pm[u] = p.adam_m[e]; pv[u] = p.adam_v[e]; pp[u] = p.c[e];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int row = rbase + 2 * (half * 8 + u);
+      for (int u = 0; u < 4; ++u) {
+        const int row = rbase + 2 * (half * 4 + u);
         if (colok && row < p.m) {
           const int64_t e = (int64_t)row * p.ldc + col;
-          const float g = v[half * 8 + u];
+          const float g = v[half * 4 + u];
           if (p.grad_out) p.grad_out[e] = g;
           const float m1 = pm[u] + (g - pm[u]) * (1.0f - p.beta1);
           const float v1 = pv[u] * p.beta2 + (1.0f - p.beta2) * g * g;
@@ -352,12 +365,13 @@ __device__ inline bool epilogue_vec_ok(const GemmParams& p) {
 
 __device__ __forceinline__ void run_tile_epilogue(const GemmParams& p, const float* patch,
                                                   int row0, int col0, int lane, bool vec,
-                                                  float& exp_acc) {
+                                                  float& exp_acc, float adam_ss, float adam_ib) {
   if (vec && col0 + 32 <= p.n) {
-    BSIG_EPI_DISPATCH(tile_epilogue_vec, p, patch, row0, col0, lane, exp_acc)
+    BSIG_EPI_DISPATCH(tile_epilogue_vec, p, patch, row0, col0, lane, exp_acc, adam_ss, adam_ib)
   } else {
     const int h = lane >> 5, l31 = lane & 31;
-    BSIG_EPI_DISPATCH(tile_epilogue, p, patch, row0 + h, col0 + l31, h, l31, exp_acc)
+    BSIG_EPI_DISPATCH(tile_epilogue, p, patch, row0 + h, col0 + l31, h, l31, exp_acc, adam_ss,
+                      adam_ib)
   }
 }
 
@@ -499,12 +513,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   // minibatch-sized problems (M or K ~ 100) are latency bound — a dependent
   // global round trip costs more than a whole K step of MFMAs — so the loads of
   // PD K steps are issued back to back and consumed in order.
-  constexpr int PD = (TM * TN == 1) ? 4 : 2;
+#ifndef BSIG_PD_BIG
+#define BSIG_PD_BIG 1
+#endif
+#ifndef BSIG_PD_SMALL
+#define BSIG_PD_SMALL 4
+#endif
+  constexpr int PD = (TM * TN == 1) ? BSIG_PD_SMALL : BSIG_PD_BIG;
   TileLoader<BM, AKM, AVEC, NT> la;
   TileLoader<BN, BKM, BVEC, NT> lb;
   typename TileLoader<BM, AKM, AVEC, NT>::Regs ra[PD];
   typename TileLoader<BN, BKM, BVEC, NT>::Regs rb[PD];
   const int nkt = (kend - kbeg + BK - 1) / BK;
+  // device-resolved scalars first: their round trips overlap the operand loads
+  float adam_ss = 0.f, adam_ib = 0.f;
+  if (p.epilogue == EPI_ADAM) { adam_ss = p.adam_dyn[0]; adam_ib = p.adam_dyn[1]; }
   const int64_t dstep = p.dyn ? (int64_t)(p.dyn[0] + p.dyn_delta) : 0;
   la.init(p.a_rows, m0, p.m, tid, dstep * p.a_dyn_stride + p.a_dyn_base);
   lb.init(p.b_rows, n0, p.n, tid, dstep * p.b_dyn_stride + p.b_dyn_base);
@@ -552,6 +575,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
               for (int u = 0; u < 4; ++u) bf[j][u] = Bs[(kg * 8 + h * 4 + u) * BN + col];
             }
           }
+#ifdef BSIG_SETPRIO
+          __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
           for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -560,6 +586,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
               for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], bf[j][u], acc[i][j],
                                                                  0, 0, 0);
+#ifdef BSIG_SETPRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
         }
         __syncthreads();
       }
@@ -581,7 +610,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
         patch[((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + l31] = acc[I][J][q];                \
     __builtin_amdgcn_wave_barrier();                                                      \
     run_tile_epilogue(p, patch, m0 + (wm * TM + (I)) * 32, n0 + (wn * TN + (J)) * 32,     \
-                      lane, vec_epi, exp_acc);                                            \
+                      lane, vec_epi, exp_acc, adam_ss, adam_ib);                          \
     __builtin_amdgcn_wave_barrier();                                                      \
   }
   BSIG_TILE_EPILOGUE(0, 0)

@@ -35,7 +35,11 @@ def run(m, n, k, akm, bkm, epi=0, reps=100):
     return s.elapsed_time(e) * 1e3 / reps
 
 
-shapes = [('rff  100x2048x2310 NT cos/sin', 100, 2048, 2310, 0, 0, L.EPI_COS_SIN),
+shapes = [('dW2  128x128x100 TN', 128, 128, 100, 1, 1, 0),
+          ('dWh  175x128x100 TN', 175, 128, 100, 1, 1, 0),
+          ('dX   100x128x175 NN', 100, 128, 175, 0, 1, 0),
+          ('fwd2 100x128x128 NT', 100, 128, 128, 0, 0, 0),
+          ('rff  100x2048x2310 NT cos/sin', 100, 2048, 2310, 0, 0, L.EPI_COS_SIN),
           ('head 100x260x4096 NT', 100, 260, 4096, 0, 0, 0),
           ('dW   260x4096x100 TN', 260, 4096, 100, 1, 1, 0),
           ('tr1  100x128x11802 NT', 100, 128, 11802, 0, 0, 0),
