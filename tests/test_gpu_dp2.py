@@ -1,0 +1,69 @@
+"""Two-rank data-parallel fit on the HIP engine (two processes sharing the one
+GPU of the test box, gloo as the exchange backend since RCCL refuses two ranks
+on one device): sharded minibatches + summed flat gradients must reproduce the
+single-process fit on the union minibatch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+N, I, D, K, B, NU = 120, 130, 3, 4, 24, 12      # per rank: 120 pairs, minibatch 24
+N_TRAIN = 96
+
+
+def _data(rank):
+    gen = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(N, I, generator=gen)
+    y = torch.rand(N, D, generator=gen)
+    ids = np.random.RandomState(200 + rank).randint(0, N_TRAIN, (NU, B))
+    return x, y, ids
+
+
+def _model(pkg):
+    torch.manual_seed(3)
+    np.random.seed(3)
+    pkg.MDNN.VERBOSE = False
+    pkg.MDNN.EPS_NOISE = 0.0
+    return pkg.MDRFF(input_dim=I, output_dim=D, output_lows=np.zeros(D), output_highs=np.ones(D),
+                     n_gaussians=K, lr=2e-3, activation=torch.nn.Tanh, full_covariance=False,
+                     n_feat=64, sigma=3.0, device='cuda:0')
+
+
+def _worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    import bayes_sim_ig_amd as pkg
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    m = _model(pkg).enable_data_parallel()
+    x, y, ids = _data(rank)
+    logs = m.run_training(x.cuda(), y.cuda(), NU, B, test_frac=0.2, ids_table=ids)
+    if rank == 0:
+        torch.save({'logs': logs, 'flat': m._flat.cpu()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fit_equals_union_minibatch(tmp_path):
+    import bayes_sim_ig_amd as pkg
+    out = str(tmp_path / 'dp2.pt')
+    mp.spawn(_worker, args=(2, 29600 + os.getpid() % 1000, out), nprocs=2, join=True)
+    res = torch.load(out)
+    (x0, y0, i0), (x1, y1, i1) = _data(0), _data(1)
+    # single process: [train0; train1; test0; test1], minibatch = both ranks' rows
+    x = torch.cat([x0[:N_TRAIN], x1[:N_TRAIN], x0[N_TRAIN:], x1[N_TRAIN:]])
+    y = torch.cat([y0[:N_TRAIN], y1[:N_TRAIN], y0[N_TRAIN:], y1[N_TRAIN:]])
+    ids = np.concatenate([i0, i1 + N_TRAIN], axis=1)
+    m = _model(pkg)
+    logs = m.run_training(x.cuda(), y.cuda(), NU, 2 * B, test_frac=0.2, ids_table=ids)
+    pkg.MDNN.EPS_NOISE = 1e-5
+    np.testing.assert_allclose(res['logs']['train_loss'], logs['train_loss'], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(res['logs']['test_loss'], logs['test_loss'], rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(res['flat'], m._flat.cpu(), rtol=1e-4, atol=1e-6)
