@@ -25,6 +25,27 @@ _ACT_CODES = {nn.Tanh: _lib.ACT_TANH, nn.ReLU: _lib.ACT_RELU,
               nn.Identity: _lib.ACT_IDENTITY}
 
 
+class _FusedNLL(torch.autograd.Function):
+    """Autograd node behind ``mdn_loss_fn(*model(x), y)``: the value is the
+    loss already computed; backward runs the fused HIP forward+NLL+backward
+    (bsig_mdn_loss_grad) into a scratch flat buffer and hands autograd one
+    gradient per parameter, so ``loss.backward(); optimizer.step()`` behaves as
+    in the reference (mdnn.py:231-234)."""
+
+    @staticmethod
+    def forward(ctx, loss_value, model, x, y, noise, seed, *params):
+        ctx.model, ctx.x, ctx.y, ctx.noise, ctx.seed = model, x, y, noise, seed
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        m = ctx.model
+        tmp = torch.empty_like(m._flat_grad)
+        m.loss_and_grad(ctx.x, ctx.y, noise=ctx.noise, seed=ctx.seed, grads_out=tmp)
+        grads = [tmp[o:o + n].view(shape) * grad_out for o, n, shape in m._param_slices]
+        return (None, None, None, None, None, None, *grads)
+
+
 class MDNN(nn.Module):
     LL_LIMIT = 1.0e5     # limit log likelihood to avoid large gradients
     MIN_WEIGHT = 1.0e-5  # minimum component weights to enable updates
@@ -116,10 +137,12 @@ class MDNN(nn.Module):
         _lib.check(lib.bsig_mdn_param_offsets(C.byref(cfg), offs, n_off))
         flat = torch.zeros(total, dtype=torch.float32, device=device)
         grads = torch.zeros(total, dtype=torch.float32, device=device)
+        self._param_slices = []
         with torch.no_grad():
             for i, mod in enumerate(self._linears()):
                 for j, prm in enumerate((mod.weight, mod.bias)):
                     o = int(offs[2 * i + j])
+                    self._param_slices.append((o, prm.numel(), tuple(prm.shape)))
                     view = flat[o:o + prm.numel()].view(prm.shape)
                     view.copy_(prm.detach().to(dtype=torch.float32))
                     prm.data = view
@@ -212,11 +235,14 @@ class MDNN(nn.Module):
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         ws = self._buf('head_ws', 64 + int(lib.bsig_head_workspace_bytes(C.byref(cfg.head), b)) // 4)
         nz = None if noise is None else noise.to(dev, torch.float32).contiguous()
+        seed = self._seed()
         _lib.check(lib.bsig_mdn_head_outputs(
             C.byref(cfg.head), _lib.ptr(out), out.stride(0), b, _lib.ptr(nz),
-            self._seed(), 0, _lib.ptr(weights), _lib.ptr(mu), _lib.ptr(l_d),
+            seed, 0, _lib.ptr(weights), _lib.ptr(mu), _lib.ptr(l_d),
             _lib.ptr(low), _lib.ptr(flag), _lib.ptr(ws), ws.numel() * 4, _lib.stream()))
         assert int(flag.item()) == 0      # isfinite asserts, mdnn.py:120-124
+        # remembered so that mdn_loss_fn(*model(x), y).backward() works (below)
+        self._fwd_ctx = (weights, x, nz, seed) if torch.is_grad_enabled() else None
         return weights, mu, l_d, low
 
     def mdn_loss_fn(self, weights, mu, L_d, L, y):
@@ -240,9 +266,15 @@ class MDNN(nn.Module):
             _lib.ptr(ys), ldy, b, _lib.ptr(loss), _lib.ptr(flag), _lib.ptr(ws),
             ws.numel() * 4, _lib.stream()))
         assert int(flag.item()) == 0      # mdnn.py:172-174
+        ctx = getattr(self, '_fwd_ctx', None)
+        if torch.is_grad_enabled() and ctx is not None and ctx[0] is weights:
+            # the reference pattern loss = mdn_loss_fn(*model(x), y); loss.backward():
+            # the backward is the fused forward+NLL+backward pass on the same x, y, noise
+            return _FusedNLL.apply(loss[0], self, ctx[1], ys, ctx[2], ctx[3], *self.parameters())
         return loss[0]
 
-    def loss_and_grad(self, x, y, rows=None, noise=None, norm_batch=None):
+    def loss_and_grad(self, x, y, rows=None, noise=None, norm_batch=None, seed=None,
+                      grads_out=None):
         """forward + mdn_loss_fn + backward for one minibatch
         (mdnn.py:229-233): returns the 0-dim loss; gradients land in every
         parameter's ``.grad`` (views of the flat gradient buffer).  ``y`` is
@@ -266,8 +298,9 @@ class MDNN(nn.Module):
         _lib.check(lib.bsig_mdn_loss_grad(
             C.byref(cfg), _lib.ptr(self._flat), _lib.ptr(coeff), ldc, _lib.ptr(off),
             _lib.ptr(xs), ldx, _lib.ptr(ys), ldy, _lib.ptr(ridx), b,
-            int(norm_batch or b), _lib.ptr(nz), self._seed(), 0,
-            _lib.ptr(self._flat_grad), _lib.ptr(loss), _lib.ptr(flag), _lib.ptr(ws),
+            int(norm_batch or b), _lib.ptr(nz), self._seed() if seed is None else int(seed), 0,
+            _lib.ptr(self._flat_grad if grads_out is None else grads_out), _lib.ptr(loss),
+            _lib.ptr(flag), _lib.ptr(ws),
             ws.numel() * 4, _lib.stream()))
         assert int(flag.item()) == 0
         return loss[0]

@@ -343,3 +343,29 @@ def test_one_step_grads_and_adam_match_reference(B, tag):
         # update = lr * g / (|g| + 1e-8): agree to 1e-4 of the step size
         np.testing.assert_allclose(v.cpu().numpy(), g['w1.' + k], rtol=0, atol=1e-4 * lr,
                                    err_msg=k)
+
+
+@pytest.mark.parametrize('tag', ['diag_eps1e5', 'full_eps1e5', 'mdrff_eps0'])
+def test_reference_autograd_pattern(B, tag):
+    """loss = mdn_loss_fn(*model(x), y); loss.backward(); Adam.step() — the
+    reference's own training idiom (mdnn.py:230-234) — works on the HIP model
+    and reproduces the reference's gradients and updated weights."""
+    g = golden('mdn_step_%s.npz' % tag)
+    m = _build(B, tag, g)
+    x, y = torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['y']).to(DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=float(g['lr']))
+    opt.zero_grad()
+    loss = m.mdn_loss_fn(*m.forward(x, noise=torch.from_numpy(g['noise']).to(DEV)), y)
+    assert loss.requires_grad
+    loss.backward()
+    assert float(loss.item()) == pytest.approx(float(g['loss']), rel=1e-5)
+    for k, p in m.named_parameters():
+        ref = g['grad.' + k]
+        scale = max(np.abs(ref).max(), 1e-8)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * scale,
+                                   err_msg=k)
+    opt.step()
+    assert not torch.equal(m._flat, torch.zeros_like(m._flat))
+    with torch.no_grad():                      # inference path: plain tensors
+        out = m.mdn_loss_fn(*m.forward(x, noise=torch.from_numpy(g['noise']).to(DEV)), y)
+    assert not out.requires_grad
