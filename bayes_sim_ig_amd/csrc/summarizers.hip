@@ -87,9 +87,23 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
     }
     const float ss = block_sum(part, red);
     const float sdev = (S < 2) ? 0.f : sqrtf(ss / (float)(S - 1));
+    // isfinite(feats) (summarizers.py:120) without touching every product: all
+    // inputs finite and max|sf| * max|af| far from overflow => every product is
+    // finite; otherwise fall back to checking each product.
+    float ms = 0.f, ma = 0.f;
+    bool in_bad = false;
+    for (int i = tid; i < S; i += nt) { ms = fmaxf(ms, fabsf(sf[i])); in_bad |= !isfinite(sf[i]); }
+    for (int i = tid; i < A; i += nt) { ma = fmaxf(ma, fabsf(af[i])); in_bad |= !isfinite(af[i]); }
+    ms = wave_max(ms); ma = wave_max(ma);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = ms; red[4 + (tid >> 6)] = ma; }
+    __syncthreads();
+    ms = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    ma = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    const bool check_each = !(ms < 1e18f && ma < 1e18f);
     // streaming outer product
     const int64_t total = (int64_t)S * A;
-    bool bad = false;
+    bool bad = in_bad;
     if (vec4) {
       // rows are 16-B aligned (ld_out % 4 == 0): one float4 per lane
       const int64_t nvec = total >> 2;
@@ -103,8 +117,11 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
         v.y = sf[ii] * af[jj]; if (++jj == A) { jj = 0; ++ii; }
         v.z = sf[ii] * af[jj]; if (++jj == A) { jj = 0; ++ii; }
         v.w = sf[ii] * af[jj];
-        bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
-        *reinterpret_cast<float4*>(o + 4 * q) = v;
+        if (check_each) bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+        __builtin_nontemporal_store(v.x, o + 4 * q + 0);
+        __builtin_nontemporal_store(v.y, o + 4 * q + 1);
+        __builtin_nontemporal_store(v.z, o + 4 * q + 2);
+        __builtin_nontemporal_store(v.w, o + 4 * q + 3);
         i += step_i; j += step_j;
         if (j >= A) { j -= A; ++i; }
       }
@@ -119,7 +136,7 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
       for (int64_t e = tid; e < total; e += nt) {
         const float v = sf[i] * af[j];
         bad |= !isfinite(v);
-        o[e] = v;
+        __builtin_nontemporal_store(v, o + e);
         i += step_i; j += step_j;
         if (j >= A) { j -= A; ++i; }
       }
@@ -280,7 +297,7 @@ __global__ void signature3_kernel(const float* __restrict__ states,
     __syncthreads();
     float* o3 = o + d + npairs;
     const int n3 = npairs * d;
-    for (int e = tid; e < n3; e += nt) o3[e] = stage[e];
+    for (int e = tid; e < n3; e += nt) __builtin_nontemporal_store(stage[e], o3 + e);
   }
 }
 
@@ -382,7 +399,7 @@ extern "C" int bsig_summary_start(const float* states, const float* actions, flo
   if (n == 0) return BSIG_OK;
   const int width = sd + ad;
   const int threads = width >= 192 ? 256 : (width >= 96 ? 128 : 64);
-  hipLaunchKernelGGL((summary_start_kernel<5>), dim3(grid_for(n)), dim3(threads), 0,
+  hipLaunchKernelGGL((summary_start_kernel<10>), dim3(grid_for(n)), dim3(threads), 0,
                      as_stream(stream), states, actions, out, n, t_states, t_actions, sd,
                      ad, max_t, ld_out);
   BSIG_CHECK_LAUNCH("summary_start");
