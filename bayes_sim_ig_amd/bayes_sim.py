@@ -87,7 +87,7 @@ class BayesSim(object):
             return self.summarizer_fxn(states, actions, depth=self._sig_depth)
         return self.summarizer_fxn(states, actions)
 
-    def run_training(self, params, traj_states, traj_actions):
+    def run_training(self, params, traj_states, traj_actions, _defer=False):
         """One chunk: summarize, then NUM_GRAD_UPDATES Adam updates of
         MINIBATCH_SIZE (reference bayes_sim.py:91-114)."""
         traj_summaries = self._summarize(traj_states, traj_actions)
@@ -95,21 +95,23 @@ class BayesSim(object):
             x_data=traj_summaries, y_data=params,
             n_updates=BayesSim.NUM_GRAD_UPDATES,
             batch_size=BayesSim.MINIBATCH_SIZE,
-            test_frac=BayesSim.TEST_FRACTION)
+            test_frac=BayesSim.TEST_FRACTION, _defer=_defer)
 
     def fit(self, params, traj_states, traj_actions):
         """The caller-side loop of bayes_sim_main.py:157-167 over
         pre-recorded pairs: consecutive chunks of at most
         NUM_TRAIN_TRAJ_PER_BATCH pairs, ``run_training`` on each.
         Returns the list of per-chunk log dicts."""
-        n, done, logs = params.shape[0], 0, []
+        n, done, pending = params.shape[0], 0, []
         while done < n:
             m = BayesSim.get_n_trajs_per_batch(n, done)
-            logs.append(self.run_training(params[done:done + m],
-                                          traj_states[done:done + m],
-                                          traj_actions[done:done + m]))
+            pending.append(self.run_training(params[done:done + m],
+                                             traj_states[done:done + m],
+                                             traj_actions[done:done + m], _defer=True))
             done += m
-        return logs
+        # one host synchronisation for the whole fit: the chunks' logs (and the
+        # isfinite asserts) are read back after the last chunk is enqueued
+        return [p.result() for p in pending]
 
     def predict(self, states, actions, threshold=0.005):
         """Posterior for the given real trajectories (reference

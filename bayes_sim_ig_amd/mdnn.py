@@ -25,6 +25,27 @@ _ACT_CODES = {nn.Tanh: _lib.ACT_TANH, nn.ReLU: _lib.ACT_RELU,
               nn.Identity: _lib.ACT_IDENTITY}
 
 
+class PendingLogs:
+    """The 6+6 losses and the non-finite flag of one run_training call, still on
+    the device; ``result()`` is the call's single host read-back.  BayesSim.fit
+    defers it to the end of the chunk loop so the GPU never waits for the host."""
+
+    def __init__(self, packed, n_e, n_test, verbose):
+        self.packed, self.n_e, self.n_test, self.verbose = packed, n_e, n_test, verbose
+
+    def result(self):
+        host = self.packed.cpu().tolist()
+        n_e = self.n_e
+        train_list, test_list, bad = host[:n_e], host[n_e:2 * n_e], host[2 * n_e]
+        assert bad == 0, 'non-finite value in forward / loss (mdnn.py:120-124,162-174)'
+        if self.n_test == 0:
+            test_list = [float('nan')] * n_e   # mean over an empty test split
+        if self.verbose:
+            for a, b in zip(train_list, test_list):
+                print(f'loss: train {a:0.4f} test {b:0.4f}')
+        return {'train_loss': train_list, 'test_loss': test_list}
+
+
 class _FusedNLL(torch.autograd.Function):
     """Autograd node behind ``mdn_loss_fn(*model(x), y)``: the value is the
     loss already computed; backward runs the fused HIP forward+NLL+backward
@@ -325,7 +346,7 @@ class MDNN(nn.Module):
         return self
 
     def run_training(self, x_data, y_data, n_updates, batch_size, test_frac=0.2,
-                     ids_table=None):
+                     ids_table=None, _defer=False):
         """Reference mdnn.py:180-243.  Returns {'train_loss': [...],
         'test_loss': [...]} with the same 6 logging points.  ``ids_table``
         [n_updates, batch] (optional) overrides the numpy-RNG minibatch draw
@@ -365,12 +386,28 @@ class MDNN(nn.Module):
         else:
             ids_np = np.asarray(ids_table)
             assert ids_np.shape == (n_updates, batch_size)
-        ids_host = torch.from_numpy(ids_np.astype(np.int32))
-        ids_dev = self._buf('ids', max(ids_host.numel(), 1), torch.int32)
-        ids_dev[:ids_host.numel()].copy_(ids_host.reshape(-1), non_blocking=True)
+        # truly asynchronous upload: pinned staging ring (a pageable source would
+        # make the copy wait for the stream to drain)
+        n_ids = n_updates * batch_size
+        ring = self._bufs.setdefault('ids_ring', {'slots': [], 'next': 0})
+        if not ring['slots'] or ring['slots'][0][0].numel() < n_ids:
+            ring['slots'] = [[torch.empty(max(n_ids, 1), dtype=torch.int32, pin_memory=True), None]
+                             for _ in range(4)]
+        slot = ring['slots'][ring['next'] % 4]
+        ring['next'] += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0][:n_ids].copy_(torch.from_numpy(ids_np.astype(np.int32)).reshape(-1))
+        ids_dev = self._buf('ids', max(n_ids, 1), torch.int32)
+        ids_dev[:n_ids].copy_(slot[0][:n_ids], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
         every = max(n_updates // 5, 1)
         eval_its = [it for it in range(n_updates)
                     if it % every == 0 or it + 1 == n_updates]
+        eval_key = ('eval_idx', n_updates)
+        if eval_key not in self._bufs:
+            self._bufs[eval_key] = torch.tensor(eval_its, dtype=torch.int64, device=dev)
         train_loss = self._buf('train_loss', n_updates)
         test_loss = self._buf('test_loss', len(eval_its))
         state = self._buf('state', 16, torch.int32)
@@ -421,17 +458,9 @@ class MDNN(nn.Module):
         te = test_loss[:len(eval_its)]
         if self._dp is not None:
             tl, te = self._dp.mean_losses(tl, te, n_test)
-        host = torch.cat([tl[eval_its] if eval_its else tl[:0], te,
-                          state[2:3].to(torch.float32)]).cpu().tolist()
-        n_e = len(eval_its)
-        train_list, test_list, bad = host[:n_e], host[n_e:2 * n_e], host[2 * n_e]
-        assert bad == 0, 'non-finite value in forward / loss (mdnn.py:120-124,162-174)'
-        if n_test == 0:
-            test_list = [float('nan')] * n_e   # mean over an empty test split
-        if type(self).VERBOSE:
-            for a, b in zip(train_list, test_list):
-                print(f'loss: train {a:0.4f} test {b:0.4f}')
-        return {'train_loss': train_list, 'test_loss': test_list}
+        packed = torch.cat([tl[self._bufs[eval_key]], te, state[2:3].to(torch.float32)])
+        pending = PendingLogs(packed, len(eval_its), n_test, type(self).VERBOSE)
+        return pending if _defer else pending.result()
 
     fit = run_training   # the north-star name for the same call
 
