@@ -169,6 +169,28 @@ def nll_check(pkg, cfg, theta, states, actions, device):
         pkg.MDNN.EPS_NOISE = old
 
 
+def pmc_traffic(kernel_substr):
+    """Per-launch HBM traffic of a kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_FETCH_SIZE.txt / *_pmc_WRITE_SIZE.txt, latest round):
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950."""
+    import glob
+    out = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_%s.txt' % ctr)))
+        if not files:
+            return None, None
+        for line in open(files[-1]):
+            if kernel_substr in line and ctr in line:
+                out[ctr] = float(line.split(ctr)[1].split()[1])
+                break
+        else:
+            return None, None
+        out['src_' + ctr] = os.path.basename(files[-1])
+    return (2.0 * out['FETCH_SIZE'] + out['WRITE_SIZE']) * 1024.0, \
+        '%s, %s' % (out['src_FETCH_SIZE'], out['src_WRITE_SIZE'])
+
+
 def _event_time(fn, reps, warm=5):
     stream = torch.cuda.current_stream()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -209,13 +231,15 @@ def time_dominant_kernel(pkg, cfg, bsim, device):
         us = _event_time(launch, 20)
         flops = 2.0 * rows * i * mf
         ach = flops / (us * 1e-6) / 1e12
+        traffic, tsrc = pmc_traffic('gemm_mfma_kernel<2, 2, 2, 2, false, false, 4, 4>')
         return {'bound': 'mfma',
                 'kernel': 'gemm_mfma_kernel<2,2,2,2> RFF projection %dx%dx%d (all minibatch rows '
                           'of one run_training call, gathered) + fused cos/sin epilogue'
                           % (rows, mf, i),
                 'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_F32_TFLOPS, 'traffic': None, 'avg_us': us,
-                'algorithmic': '2*rows*I*M = %.3e flop per launch' % flops}
+                'frac': ach / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
+                'avg_us': us, 'algorithmic': '2*rows*I*M = %.3e flop per launch; %.3e B '
+                '(4(I+2M) per row + coefficients)' % (flops, 4.0 * rows * (i + 2 * mf) + 4.0 * mf * i)}
     m = bsim.model
     b, i, h0 = 100, m.input_dim, m._hidden[0]
     x = torch.randn(1000, L.round_up(i, 4), device=device)
