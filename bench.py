@@ -420,6 +420,22 @@ def main():
             if not args.no_scaled_batch:
                 out['scaled_batch_mode'] = scaled_batch(pkg, cfg, theta, states, actions, device)
                 note('scaled batch done')
+            if cfg['model'] == 'MDRFF':
+                # transparency: the same fit with the RFF projection launched inside
+                # every update (one M=100 GEMM per step) instead of hoisted per call
+                os.environ['BSIG_NO_RFF_HOIST'] = '1'
+                try:
+                    b2 = build_gpu_model(pkg, cfg, device, 1234)
+                    np.random.seed(1234)
+                    b2.fit(theta, states, actions)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    b2.fit(theta, states, actions)
+                    torch.cuda.synchronize()
+                    out['rff_in_loop_pairs_per_s'] = n / (time.perf_counter() - t1)
+                finally:
+                    del os.environ['BSIG_NO_RFF_HOIST']
+                note('in-loop RFF variant done')
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(cfg, theta[:12000], states[:12000],
                                                    actions[:12000])
