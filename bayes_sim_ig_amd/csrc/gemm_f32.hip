@@ -490,7 +490,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int kAs = lds_floats<BM, AKM>(), kBs = lds_floats<BN, BKM>();
   constexpr int kEpi = WM * WN * 32 * 32;  // per-wave [32][32] epilogue patches
-  __shared__ __attribute__((aligned(16))) float smem[(kAs + kBs) > kEpi ? (kAs + kBs) : kEpi];
+#ifdef BSIG_LDS_DB
+  constexpr bool kDoubleLds = TM * TN == 4;   // 128x128 tiles: two LDS images, one barrier per K step
+#else
+  constexpr bool kDoubleLds = false;
+#endif
+  constexpr int kOps = (kDoubleLds ? 2 : 1) * (kAs + kBs);
+  __shared__ __attribute__((aligned(16))) float smem[kOps > kEpi ? kOps : kEpi];
   float* As = smem;
   float* Bs = smem + kAs;
 
@@ -537,60 +543,90 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
       la.fetch(ra[s], p.a, p.lda, p.a_rows, m0, p.m, kbeg + s * BK, kend, p.k, tid);
       lb.fetch(rb[s], p.b, p.ldb, p.b_rows, n0, p.n, kbeg + s * BK, kend, p.k, tid);
     }
-  for (int kt0 = 0; kt0 < nkt; kt0 += PD) {
+  // MFMAs of one staged K tile (BK = 32 -> 4 groups of 8 k; TM*TN*4 MFMAs each)
+  auto compute_tile = [&](const float* __restrict__ At, const float* __restrict__ Bt) {
 #pragma unroll
-    for (int s = 0; s < PD; ++s) {
-      const int kt = kt0 + s;
-      if (kt < nkt) {          // block-uniform
-        la.commit(ra[s], As, tid);
-        lb.commit(rb[s], Bs, tid);
-        __syncthreads();
-        if (kt + PD < nkt) {   // refill this register slot
-          const int k0 = kbeg + (kt + PD) * BK;
-          la.fetch(ra[s], p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid);
-          lb.fetch(rb[s], p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid);
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + l31;
+        if constexpr (!AKM) {
+          const float4 q = *reinterpret_cast<const float4*>(&At[row * BKP + kg * 8 + h * 4]);
+          af[i][0] = q.x; af[i][1] = q.y; af[i][2] = q.z; af[i][3] = q.w;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) af[i][u] = At[(kg * 8 + h * 4 + u) * BM + row];
         }
+      }
 #pragma unroll
-        for (int kg = 0; kg < BK / 8; ++kg) {
-          float af[TM][4], bf[TN][4];
+      for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 32 + l31;
+        if constexpr (!BKM) {
+          const float4 q = *reinterpret_cast<const float4*>(&Bt[col * BKP + kg * 8 + h * 4]);
+          bf[j][0] = q.x; bf[j][1] = q.y; bf[j][2] = q.z; bf[j][3] = q.w;
+        } else {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int row = (wm * TM + i) * 32 + l31;
-            if constexpr (!AKM) {
-              const float4 q = *reinterpret_cast<const float4*>(&As[row * BKP + kg * 8 + h * 4]);
-              af[i][0] = q.x; af[i][1] = q.y; af[i][2] = q.z; af[i][3] = q.w;
-            } else {
-#pragma unroll
-              for (int u = 0; u < 4; ++u) af[i][u] = As[(kg * 8 + h * 4 + u) * BM + row];
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int col = (wn * TN + j) * 32 + l31;
-            if constexpr (!BKM) {
-              const float4 q = *reinterpret_cast<const float4*>(&Bs[col * BKP + kg * 8 + h * 4]);
-              bf[j][0] = q.x; bf[j][1] = q.y; bf[j][2] = q.z; bf[j][3] = q.w;
-            } else {
-#pragma unroll
-              for (int u = 0; u < 4; ++u) bf[j][u] = Bs[(kg * 8 + h * 4 + u) * BN + col];
-            }
-          }
+          for (int u = 0; u < 4; ++u) bf[j][u] = Bt[(kg * 8 + h * 4 + u) * BN + col];
+        }
+      }
 #ifdef BSIG_SETPRIO
-          __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], bf[j][u], acc[i][j],
-                                                                 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], bf[j][u], acc[i][j],
+                                                             0, 0, 0);
 #ifdef BSIG_SETPRIO
-          __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(0);
 #endif
+    }
+  };
+
+  if constexpr (kDoubleLds) {
+    // two LDS images: the next tile is committed while the others still read
+    // the current one -> one barrier per K step
+    if (nkt > 0) {
+      la.commit(ra[0], As, tid);
+      lb.commit(rb[0], Bs, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      float* cur = smem + (kt & 1) * (kAs + kBs);
+      float* nxt = smem + ((kt + 1) & 1) * (kAs + kBs);
+      if (kt + 1 < nkt) {
+        const int k0 = kbeg + (kt + 1) * BK;
+        la.fetch(ra[0], p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid);
+        lb.fetch(rb[0], p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid);
+      }
+      compute_tile(cur, cur + kAs);
+      if (kt + 1 < nkt) {
+        la.commit(ra[0], nxt, tid);
+        lb.commit(rb[0], nxt + kAs, tid);
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int kt0 = 0; kt0 < nkt; kt0 += PD) {
+#pragma unroll
+      for (int s = 0; s < PD; ++s) {
+        const int kt = kt0 + s;
+        if (kt < nkt) {          // block-uniform
+          la.commit(ra[s], As, tid);
+          lb.commit(rb[s], Bs, tid);
+          __syncthreads();
+          if (kt + PD < nkt) {   // refill this register slot
+            const int k0 = kbeg + (kt + PD) * BK;
+            la.fetch(ra[s], p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid);
+            lb.fetch(rb[s], p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid);
+          }
+          compute_tile(As, Bs);
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
   }

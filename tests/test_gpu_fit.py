@@ -416,3 +416,16 @@ def test_full_size_chunk_protocol_fit(B):
         finals.append((flat, bs.model._flat.clone()))
     np.testing.assert_array_equal(finals[0][0], finals[1][0])
     assert torch.equal(finals[0][1], finals[1][1])
+
+
+@pytest.mark.parametrize('name', ['cfg5', 'cfg3', 'cfg2'])
+def test_baseline_shaped_chunk_matches_oracle(B, name):
+    """One teacher-forced 1000-pair chunk at the BASELINE shapes (ShadowHand
+    MDRFF-4096 / Ant MDNN on 11802-wide cross-correlations / Cartpole MDRFF-1024)
+    against the oracle: held-out NLL within the north-star 1e-4 relative."""
+    import bench
+    cfg = dict(bench.CONFIGS[name])
+    theta, states, actions = bench.synth_pairs(cfg, 1000, 3, DEV)
+    torch.set_num_threads(8)
+    res = bench.nll_check(B, cfg, theta, states, actions, DEV)
+    assert res['rel_diff'] < 1e-4, res
