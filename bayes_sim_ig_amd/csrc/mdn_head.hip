@@ -26,6 +26,8 @@ constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr int kSigMax = 4096;       // capacity of the exp(pre) partial-sum array
 constexpr int kSigBlocks = 512;     // blocks of the stand-alone sigma0_sum kernel
 constexpr int kElemsPerLane = 8;    // wave kernel: register-cached elements per lane
+constexpr int kGranMax = 64;        // fused kernel: at most this many workgroups
+constexpr int kFusedThreads = 1024; // fused kernel: 16 wavefronts per workgroup
 
 struct HeadArgs {
   const float* seg_w; int64_t ld_w;    // logits (fused) or weights (tuple), K / row
@@ -45,6 +47,13 @@ struct HeadArgs {
   float* block_lse;                    // [gridDim.x]
   float* block_uds;                    // [gridDim.x]  sum u * dL/dsigma
   int32_t* nonfinite;
+  // fused variant only (fit engine, single rank): the raw head outputs arrive as
+  // split-K slabs, pre[row, col] = sum_z slabs[z][row][col] + bias[col]
+  const float* slabs; int n_slabs; const float* bias;
+  unsigned long long* gran;            // [3][kGranMax] {tag, value} cross-workgroup granules
+  float* colpart;                      // [gridDim.x][Nh] column sums of the block's d_out rows
+  float* loss; const int32_t* loss_slot;
+  FinishHook hook;
 };
 
 __device__ inline float jitter_u(const HeadArgs& a, int row, int d, int k) {
@@ -292,60 +301,28 @@ __global__ void mdn_nll_kernel(HeadArgs a) {
 // ---- diagonal covariance, one wavefront per row ------------------------------
 // A wave never depends on another wave's LDS data here (each row is private),
 // so the phases are ordered by the in-order LDS pipeline of the wave itself
-// (wave_barrier only pins the compiler); the one workgroup barrier is the final
-// hand-over of the per-wave sums.  Per-component sums over the dimensions are
-// strided wavefront shuffles; the jitter draws use all four Philox outputs.
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int D = a.D, K = a.K, Nh = a.Nh;
+// (wave_barrier only pins the compiler).  Per-component sums over the dimensions
+// are strided wavefront shuffles; the jitter draws use all four Philox outputs.
+//
+// diag_row: forward + backward of one row by one wavefront.  In: tile[Nh] raw
+// head outputs, yv[D] target.  Out: gradients in tile[K..Nh) and dlg[K]
+// (without the jitter-scale term), the row's logsumexp, sum(u * dL/dsigma),
+// and exp(pre) of the lane's elements (for the jitter-scale correction).
+struct RowOut { float lse, uds; bool bad; float esg0[kElemsPerLane]; };
+
+__device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active, int lane,
+                                         float* tile, const float* yv, float* rk, float* lpk,
+                                         float* dlg, float eps, RowOut& out) {
+  const int D = a.D, K = a.K;
   const int DK = D * K;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int per_wave = Nh + D + 3 * K;
-  float* wsum = smem;                      // [2][WPB] per-wave lse / uds
-  float* tile = smem + 32 + wid * per_wave;  // [Nh]
-  float* yv = tile + Nh;                   // [D]
-  float* rk = yv + D;                      // [K] clamp(logp)+log clamp(w)
-  float* lpk = rk + K;                     // [K] raw logp (clamp indicator)
-  float* dlg = lpk + K;                    // [K] d loss / d logits
-  const int row = blockIdx.x * WPB + wid;
-  const bool active = row < a.batch;
-
-  // every independent global load is issued before anything waits
-  const bool want_eps = !a.from_tuple && a.eps_noise != 0.f;
-  float sp[4] = {0.f, 0.f, 0.f, 0.f};
-  if (want_eps) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = lane + 64 * u;
-      sp[u] = i < a.n_sig ? a.sig_partials[i] : 0.f;
-    }
-  }
-  if (active) {
-    const int64_t yoff = a.y_dyn ? (int64_t)a.y_dyn[0] * a.y_dyn_stride : 0;
-    const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
-    for (int j = lane; j < K; j += 64) tile[j] = a.seg_w[(int64_t)row * a.ld_w + j];
-    for (int j = lane; j < DK; j += 64) tile[K + j] = a.seg_mu[(int64_t)row * a.ld_mu + j];
-    for (int j = lane; j < DK; j += 64) tile[K + DK + j] = a.seg_sg[(int64_t)row * a.ld_sg + j];
-    for (int j = lane; j < D; j += 64) yv[j] = a.y[yrow * a.ldy + j];
-  }
-  // jitter scale eps = EPS_NOISE * mean(exp(pre)): every wave adds the same
-  // partial sums in the same order
-  float eps = 0.f;
-  if (want_eps) {
-    float s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-    for (int i = lane + 256; i < a.n_sig; i += 64) s += a.sig_partials[i];
-    eps = a.eps_noise * (wave_sum(s) / ((float)a.batch * (float)DK));
-  }
-  __builtin_amdgcn_wave_barrier();
-
   const int groups = 64 / K;               // d-slots per sweep
   const int TPR = groups * K;
   const int k = lane % K, d0 = lane / K;
   const bool elem = active && lane < TPR;
   bool bad = false;
   // per-element values kept for the backward half
-  float ez[kElemsPerLane], esg[kElemsPerLane], esg0[kElemsPerLane], eu[kElemsPerLane];
+  float ez[kElemsPerLane], esg[kElemsPerLane], eu[kElemsPerLane];
+  float (&esg0)[kElemsPerLane] = out.esg0;
   float quad = 0.f, logdet = 0.f;
   Philox4 ph{{0u, 0u, 0u, 0u}};
   const bool draw = eps != 0.f && a.noise == nullptr;
@@ -462,14 +439,79 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
     dlg[lane] = dlogit;                     // separate slot: the logits stay readable
   }
   __builtin_amdgcn_wave_barrier();
+  out.lse = lse; out.uds = uds; out.bad = bad;
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D = a.D, K = a.K, Nh = a.Nh;
+  const int DK = D * K;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int per_wave = Nh + D + 3 * K;
+  float* wsum = smem;                      // [2][WPB] per-wave lse / uds
+  float* tile = smem + 32 + wid * per_wave;  // [Nh]
+  float* yv = tile + Nh;                   // [D]
+  float* rk = yv + D;                      // [K] clamp(logp)+log clamp(w)
+  float* lpk = rk + K;                     // [K] raw logp (clamp indicator)
+  float* dlg = lpk + K;                    // [K] d loss / d logits
+  const int row = blockIdx.x * WPB + wid;
+  const bool active = row < a.batch;
+
+  // every independent global load is issued before anything waits
+  const bool want_eps = !a.from_tuple && a.eps_noise != 0.f;
+  float sp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (want_eps) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = lane + 64 * u;
+      sp[u] = i < a.n_sig ? a.sig_partials[i] : 0.f;
+    }
+  }
+  if (active) {
+    const int64_t yoff = a.y_dyn ? (int64_t)a.y_dyn[0] * a.y_dyn_stride : 0;
+    const int64_t yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
+    const bool one_run = a.seg_mu == a.seg_w + K && a.seg_sg == a.seg_mu + DK &&
+                         a.ld_mu == a.ld_w && a.ld_sg == a.ld_w && Nh <= 64 * 8;
+    if (one_run) {        // the row is one contiguous run: eight loads in flight
+      const float* src = a.seg_w + (int64_t)row * a.ld_w;
+      float r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = src[min(lane + 64 * u, Nh - 1)];
+      const float yq = a.y[yrow * a.ldy + min(lane, D - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (lane + 64 * u < Nh) tile[lane + 64 * u] = r[u];
+      if (lane < D) yv[lane] = yq;
+      for (int j = lane + 64; j < D; j += 64) yv[j] = a.y[yrow * a.ldy + j];
+    } else {
+      for (int j = lane; j < K; j += 64) tile[j] = a.seg_w[(int64_t)row * a.ld_w + j];
+      for (int j = lane; j < DK; j += 64) tile[K + j] = a.seg_mu[(int64_t)row * a.ld_mu + j];
+      for (int j = lane; j < DK; j += 64) tile[K + DK + j] = a.seg_sg[(int64_t)row * a.ld_sg + j];
+      for (int j = lane; j < D; j += 64) yv[j] = a.y[yrow * a.ldy + j];
+    }
+  }
+  // jitter scale eps = EPS_NOISE * mean(exp(pre)): every wave adds the same
+  // partial sums in the same order
+  float eps = 0.f;
+  if (want_eps) {
+    float s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+    for (int i = lane + 256; i < a.n_sig; i += 64) s += a.sig_partials[i];
+    eps = a.eps_noise * (wave_sum(s) / ((float)a.batch * (float)DK));
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  RowOut ro;
+  diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, eps, ro);
+  const bool bwd = a.d_out != nullptr;
   if (bwd && active) {
     float* o = a.d_out + (int64_t)row * a.ld_dout;
     for (int j = lane; j < K; j += 64) o[j] = dlg[j];
     for (int j = K + lane; j < Nh; j += 64) o[j] = tile[j];
   }
   // per-wave sums -> one partial per workgroup, fixed order
-  const float uds_w = wave_sum(uds);
-  if (lane == 0) { wsum[wid] = active ? lse : 0.f; wsum[WPB + wid] = uds_w; }
+  const float uds_w = wave_sum(ro.uds);
+  if (lane == 0) { wsum[wid] = active ? ro.lse : 0.f; wsum[WPB + wid] = uds_w; }
   __syncthreads();
   if (tid == 0) {
     float sl = 0.f, su = 0.f;
@@ -478,7 +520,188 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
     a.block_lse[blockIdx.x] = sl;
     if (a.block_uds) a.block_uds[blockIdx.x] = su;
   }
-  if (bad && a.nonfinite) atomicOr(a.nonfinite, 1);
+  if (ro.bad && a.nonfinite) atomicOr(a.nonfinite, 1);
+}
+
+// Fit-engine state advance (single writer; every reader of these words runs
+// in an earlier or a later kernel, or has published its last dependent value).
+__device__ inline void run_finish_hook(const FinishHook& hook) {
+  int32_t* st = hook.state;
+  if (hook.kind == 1) {           // end of the forward half of update `step`
+    // beta^t as running products (double): no pow() on the device
+    double* bp = reinterpret_cast<double*>(st + 12);
+    const double b1t = bp[0] * hook.beta1, b2t = bp[1] * hook.beta2;
+    bp[0] = b1t; bp[1] = b2t;
+    reinterpret_cast<float*>(st)[4] = (float)(hook.lr / (1.0 - b1t));
+    reinterpret_cast<float*>(st)[5] = (float)(1.0 / sqrt(1.0 - b2t));
+    st[0] = st[0] + 1;
+  } else {                        // end of a held-out evaluation
+    st[1] = st[1] + 1;
+  }
+  reinterpret_cast<uint64_t*>(st + 8)[1] += 1;   // jitter RNG stream
+}
+
+// ---- fused variant: split-K reduce + NLL + backward + finish in one launch -----
+// Used by the single-rank fit engine for diagonal covariances when the head
+// GEMM ran split-K.  Grid = G <= 64 workgroups of 16 wavefronts, R rows each
+// (all co-resident: 256 CUs).  Phase A: all 1024 threads sum the slabs of the
+// workgroup's R rows into LDS (+ bias) and the workgroup publishes its
+// sum(exp(pre)); wave r < R then runs diag_row on row r.  The three batch-wide
+// sums (exp(pre) for the jitter scale, u*dL/dsigma for its gradient term, the
+// logsumexp for the loss) cross workgroups as 8-byte {tag, value} granules:
+// one relaxed agent-scope atomic store each, polled by lane g of every
+// consuming wave and summed in granule order (bitwise reproducible).  The tag
+// encodes (update, phase), granules are zeroed when a fit call begins, so a
+// stale value is never taken; the poll is bounded and raises the nonfinite
+// flag (bit 1) instead of hanging.
+__device__ inline void granule_publish(unsigned long long* g, uint32_t tag, float v) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float granule_gather(unsigned long long* g, int G, uint32_t tag, int lane,
+                                       int32_t* flag) {
+  float v = 0.f;
+  bool ok = lane >= G;
+  for (unsigned spin = 0;; ++spin) {
+    if (!ok) {
+      const unsigned long long x =
+          __hip_atomic_load(g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(x >> 32) == tag) { ok = true; v = __uint_as_float((uint32_t)x); }
+    }
+    if (__all(ok)) break;
+    if (spin > (1u << 18)) {
+      if (flag && lane == 0) atomicOr(flag, 2);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return wave_sum(v);
+}
+
+__global__ __launch_bounds__(kFusedThreads) void mdn_fused_diag_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D = a.D, K = a.K, Nh = a.Nh, R = a.R;
+  const int DK = D * K;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int per_wave = Nh + D + 3 * K;
+  float* red = smem;                         // [48] wave partials: exp | lse | uds
+  float* tile = smem + 64 + wid * per_wave;  // rows of waves 0..R-1
+  float* yv = tile + Nh;
+  float* rk = yv + D;
+  float* lpk = rk + K;
+  float* dlg = lpk + K;
+  const int G = gridDim.x;
+  const int step = a.y_dyn[0];
+  const uint32_t tag = (uint32_t)step * 4u + 4u;
+  unsigned long long* gran_exp = a.gran;
+  unsigned long long* gran_uds = a.gran + kGranMax;
+  unsigned long long* gran_lse = a.gran + 2 * kGranMax;
+  const int row = blockIdx.x * R + wid;
+  const bool owner = wid < R;
+  const bool active = owner && row < a.batch;
+  const float norm = (float)a.batch * (float)DK;
+
+  float yq = 0.f;
+  int64_t yrow = 0;
+  if (active) {
+    const int64_t yoff = (int64_t)step * a.y_dyn_stride;
+    yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
+    yq = a.y[yrow * a.ldy + min(lane, D - 1)];
+  }
+  // phase A: pre = sum of slabs (slab order) + bias
+  const int64_t total = (int64_t)a.batch * Nh;
+  const int64_t base = (int64_t)blockIdx.x * R * Nh;
+  const int nelem = (int)min((int64_t)R * Nh, total - base);
+  float eacc = 0.f;
+  for (int e = tid; e < nelem; e += kFusedThreads) {
+    const float* src = a.slabs + base + e;
+    float v = 0.f;
+    for (int z = 0; z < a.n_slabs; z += 16) {
+      float q[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) q[u] = src[(int64_t)min(z + u, a.n_slabs - 1) * total];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (z + u < a.n_slabs) v += q[u];
+    }
+    const int r = e / Nh, col = e - r * Nh;
+    v += a.bias[col];
+    smem[64 + r * per_wave + col] = v;
+    if (col >= K + DK && col < K + 2 * DK) eacc += expf(v);
+  }
+  eacc = wave_sum(eacc);
+  if (lane == 0) red[wid] = eacc;
+  __syncthreads();
+  if (tid == 0) {
+    float sx = 0.f;
+    for (int w = 0; w < kFusedThreads / 64; ++w) sx += red[w];
+    granule_publish(gran_exp + blockIdx.x, tag + 1, sx);
+  }
+
+  RowOut ro;
+  ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
+#pragma unroll
+  for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
+  if (owner) {
+    if (active) {
+      if (lane < D) yv[lane] = yq;
+      for (int j = lane + 64; j < D; j += 64) yv[j] = a.y[yrow * a.ldy + j];
+    }
+    float eps = 0.f;
+    if (a.eps_noise != 0.f)
+      eps = a.eps_noise * (granule_gather(gran_exp, G, tag + 1, lane, a.nonfinite) / norm);
+    __builtin_amdgcn_wave_barrier();
+    diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, eps, ro);
+    const float uds_w = wave_sum(ro.uds);
+    if (lane == 0) { red[16 + wid] = active ? ro.lse : 0.f; red[32 + wid] = uds_w; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float sl = 0.f, su = 0.f;
+    for (int w = 0; w < R; ++w) { sl += red[16 + w]; su += red[32 + w]; }
+    granule_publish(gran_uds + blockIdx.x, tag + 2, su);
+    granule_publish(gran_lse + blockIdx.x, tag + 3, sl);
+  }
+  if (owner) {
+    // jitter-scale gradient term: d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
+    float c = 0.f;
+    if (a.eps_noise != 0.f)
+      c = a.eps_noise / norm * granule_gather(gran_uds, G, tag + 2, lane, a.nonfinite);
+    if (active) {
+      const int groups = 64 / K;
+      const int k = lane % K, d0 = lane / K;
+      if (c != 0.f && lane < groups * K) {
+#pragma unroll
+        for (int q = 0; q < kElemsPerLane; ++q) {
+          const int d = d0 + q * groups;
+          if (d < D) tile[K + DK + d * K + k] += c * ro.esg0[q];
+        }
+      }
+      for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
+      __builtin_amdgcn_wave_barrier();
+      float* o = a.d_out + (int64_t)row * a.ld_dout;
+      for (int j = lane; j < Nh; j += 64) o[j] = tile[j];
+    } else {
+      for (int j = lane; j < Nh; j += 64) tile[j] = 0.f;
+    }
+  }
+  __syncthreads();
+  // head bias gradients: column sums of the workgroup's rows
+  for (int col = tid; col < Nh; col += kFusedThreads) {
+    float t = 0.f;
+    for (int r = 0; r < R; ++r) t += smem[64 + r * per_wave + col];
+    a.colpart[(int64_t)blockIdx.x * Nh + col] = t;
+  }
+  if (blockIdx.x == 0 && wid == 0) {
+    const float s = granule_gather(gran_lse, G, tag + 3, lane, a.nonfinite);
+    if (lane == 0) {
+      const float l = -s / (float)a.batch;
+      if (a.loss) a.loss[a.loss_slot ? *a.loss_slot : 0] = l;
+      if (!isfinite(l) && a.nonfinite) atomicOr(a.nonfinite, 1);
+      if (a.hook.state) run_finish_hook(a.hook);
+    }
+  }
+  if (ro.bad && a.nonfinite) atomicOr(a.nonfinite, 1);
 }
 
 // Finishing kernel: loss = -(sum of block partials) / batch; jitter-scale
@@ -505,23 +728,7 @@ __global__ __launch_bounds__(64 * kFinishLanes) void mdn_finish_kernel(
       if (!isfinite(l) && nonfinite) atomicOr(nonfinite, 1);
     }
   }
-  // Fit-engine state advance (single writer: block (0,0), thread 0; every
-  // reader of these words runs in an earlier or a later kernel).
-  if (hook.state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    int32_t* st = hook.state;
-    if (hook.kind == 1) {           // end of the forward half of update `step`
-      // beta^t as running products (double): no pow() on the device
-      double* bp = reinterpret_cast<double*>(st + 12);
-      const double b1t = bp[0] * hook.beta1, b2t = bp[1] * hook.beta2;
-      bp[0] = b1t; bp[1] = b2t;
-      reinterpret_cast<float*>(st)[4] = (float)(hook.lr / (1.0 - b1t));
-      reinterpret_cast<float*>(st)[5] = (float)(1.0 / sqrt(1.0 - b2t));
-      st[0] = st[0] + 1;
-    } else {                        // end of a held-out evaluation
-      st[1] = st[1] + 1;
-    }
-    reinterpret_cast<uint64_t*>(st + 8)[1] += 1;   // jitter RNG stream
-  }
+  if (hook.state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) run_finish_hook(hook);
   if (!d_out) return;
   float c = 0.f;
   if (eps_noise != 0.f) {
@@ -671,8 +878,77 @@ static int head_geom(const bsig_head_dims* d, int64_t batch, HeadGeom* g) {
 }
 
 // workspace floats: [sig partials kSigMax][block_lse nblk][block_uds nblk][colsum slabs x Nh]
+static size_t head_ws_main_floats(const HeadGeom& g) {
+  return round_up<size_t>(kSigMax + 2 * (size_t)g.blocks + (size_t)kMaxSlabs * g.Nh, 4);
+}
+// ... followed by the fused kernel's granules: [3][kGranMax] x 8 bytes
 static size_t head_ws_floats(const HeadGeom& g) {
-  return kSigMax + 2 * (size_t)g.blocks + (size_t)kMaxSlabs * g.Nh;
+  return head_ws_main_floats(g) + 3 * (size_t)kGranMax * 2;
+}
+
+// geometry of the fused kernel: R rows per workgroup so that G <= kGranMax
+static bool fused_geom(const HeadGeom& g, int64_t batch, int* rows_per_wg, int* wgs, size_t* lds) {
+  if (!g.wave_per_row) return false;
+  const int64_t R = ceil_div<int64_t>(batch, kGranMax);
+  if (R > kFusedThreads / 64) return false;
+  *rows_per_wg = (int)R;
+  *wgs = (int)ceil_div<int64_t>(batch, R);
+  *lds = (64 + (size_t)R * (g.Nh + g.D + 3 * g.K)) * sizeof(float);
+  return *lds <= 60 * 1024;
+}
+
+bool mdn_head_fused_ok(const bsig_head_dims* dims, int64_t batch) {
+  HeadGeom g;
+  int r, w; size_t lds;
+  if (batch < 1 || head_geom(dims, batch, &g) != BSIG_OK) return false;
+  return fused_geom(g, batch, &r, &w, &lds);
+}
+
+int mdn_head_sync_reset(const bsig_head_dims* dims, int64_t batch, void* workspace,
+                        size_t workspace_bytes, hipStream_t st) {
+  HeadGeom g;
+  BSIG_TRY(head_geom(dims, batch, &g));
+  BSIG_REQUIRE(workspace && workspace_bytes >= head_ws_floats(g) * sizeof(float),
+               "mdn head: workspace too small");
+  BSIG_HIP(hipMemsetAsync(reinterpret_cast<float*>(workspace) + head_ws_main_floats(g), 0,
+                          3 * (size_t)kGranMax * 8, st));
+  return BSIG_OK;
+}
+
+int mdn_head_fused_launch(const bsig_head_dims* dims, const float* slabs, int n_slabs,
+                          const float* bias, const float* y, int64_t ldy,
+                          const int32_t* y_rows, int64_t batch, int64_t norm_batch,
+                          const uint64_t* dyn_rng, float* loss, const int32_t* loss_slot,
+                          float* d_out, int64_t ld_dout, int32_t* nonfinite, void* workspace,
+                          size_t workspace_bytes, hipStream_t st, const HeadDyn* dyn,
+                          const float** colpart, int* n_colparts) {
+  HeadGeom g;
+  BSIG_TRY(head_geom(dims, batch, &g));
+  int R = 0, G = 0; size_t lds = 0;
+  BSIG_REQUIRE(fused_geom(g, batch, &R, &G, &lds), "mdn head: shape not covered by the fused kernel");
+  BSIG_REQUIRE(slabs && n_slabs >= 1 && bias && y && d_out && dyn && dyn->y_dyn && colpart &&
+                   n_colparts, "mdn head (fused): null argument");
+  BSIG_REQUIRE(workspace && workspace_bytes >= head_ws_floats(g) * sizeof(float),
+               "mdn head: workspace too small (%zu < %zu)", workspace_bytes,
+               head_ws_floats(g) * sizeof(float));
+  float* ws = reinterpret_cast<float*>(workspace);
+  HeadArgs a{};
+  a.y = y; a.ldy = ldy; a.y_rows = y_rows;
+  a.y_dyn = dyn->y_dyn; a.y_dyn_stride = dyn->y_dyn_stride;
+  a.batch = (int)batch; a.inv_norm = 1.0f / (float)norm_batch;
+  a.D = g.D; a.K = g.K; a.Ls = 0; a.Nh = g.Nh; a.R = R;
+  a.from_tuple = 0;
+  a.noise = nullptr; a.seed = 0; a.stream_id = 0; a.dyn_rng = dyn_rng;
+  a.eps_noise = dims->eps_noise; a.min_w = dims->min_weight; a.ll_limit = dims->ll_limit;
+  a.d_out = d_out; a.ld_dout = ld_dout; a.nonfinite = nonfinite;
+  a.slabs = slabs; a.n_slabs = n_slabs; a.bias = bias;
+  a.gran = reinterpret_cast<unsigned long long*>(ws + head_ws_main_floats(g));
+  a.colpart = ws + kSigMax + 2 * (size_t)g.blocks;     // the slab-sum area of the finish kernel
+  a.loss = loss; a.loss_slot = loss_slot; a.hook = dyn->hook;
+  hipLaunchKernelGGL(mdn_fused_diag_kernel, dim3(G), dim3(kFusedThreads), lds, st, a);
+  BSIG_CHECK_LAUNCH("mdn_fused");
+  *colpart = a.colpart; *n_colparts = G;
+  return BSIG_OK;
 }
 
 int head_sig_capacity() { return kSigMax; }
@@ -709,7 +985,7 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
                        (int)batch, DK, sig_partials);
     BSIG_CHECK_LAUNCH("sigma0_sum");
   }
-  HeadArgs a;
+  HeadArgs a{};
   a.seg_w = seg_w; a.ld_w = ld_w; a.seg_mu = seg_mu; a.ld_mu = ld_mu;
   a.seg_sg = seg_sg; a.ld_sg = ld_sg; a.seg_lo = seg_lo; a.ld_lo = ld_lo;
   a.y = y; a.ldy = ldy; a.y_rows = y_rows;
