@@ -28,6 +28,7 @@
 // all-reduces it, then one flat Adam kernel runs (bsig_fit_grad / _apply).
 #include "gemm.h"
 #include "head.h"
+#include "persist.h"
 
 #include <algorithm>
 #include <cmath>
@@ -366,6 +367,8 @@ struct bsig_fit_plan {
   size_t train_ws_bytes, test_ws_bytes, feats_bytes, big_gemm_ws_bytes, iota_bytes;
   bool use_graph, split_adam;
   bool fused_head;             // single-rank updates use the fused head kernel
+  bool persistent;             // single-rank updates run in the persistent kernel (persist.h)
+  size_t persist_bytes;
   hipStream_t cap_stream;
   hipGraphExec_t g_step, g_grad, g_apply, g_eval;
 };
@@ -374,10 +377,10 @@ namespace bsig {
 
 static size_t plan_ws_bytes(const bsig_fit_plan* p) {
   return p->train_ws_bytes + p->test_ws_bytes + p->feats_bytes + p->big_gemm_ws_bytes +
-         p->iota_bytes;
+         p->iota_bytes + p->persist_bytes;
 }
 
-struct PlanMem { Scratch tr, te; float* feats; float* big_ws; int32_t* iota; };
+struct PlanMem { Scratch tr, te; float* feats; float* big_ws; int32_t* iota; void* persist_ws; };
 
 static void plan_mem(const bsig_fit_plan* p, PlanMem* m) {
   char* base = reinterpret_cast<char*>(p->buf.workspace);
@@ -387,7 +390,31 @@ static void plan_mem(const bsig_fit_plan* p, PlanMem* m) {
   base += p->test_ws_bytes;
   m->feats = reinterpret_cast<float*>(base); base += p->feats_bytes;
   m->big_ws = reinterpret_cast<float*>(base); base += p->big_gemm_ws_bytes;
-  m->iota = reinterpret_cast<int32_t*>(base);
+  m->iota = reinterpret_cast<int32_t*>(base); base += p->iota_bytes;
+  m->persist_ws = base;
+}
+
+static PersistShape persist_shape(const bsig_fit_plan* p) {
+  return PersistShape{(int)p->batch, (int)p->L.feat_dim, p->cfg.head.out_dim, p->cfg.head.n_comp};
+}
+
+// n consecutive updates in the persistent kernel
+static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st) {
+  PlanMem m; plan_mem(p, &m);
+  const bsig_fit_buffers& b = p->buf;
+  PersistBuffers pb;
+  pb.feats = m.feats; pb.ld_feats = p->cfg.rff_feats;
+  pb.y = b.y_train; pb.ldy = b.ldy_train; pb.ids = b.ids_table;
+  pb.params = b.params; pb.exp_avg = b.exp_avg; pb.exp_avg_sq = b.exp_avg_sq;
+  pb.w_off = p->L.head_w_off; pb.b_off = p->L.head_b_off;
+  pb.state = b.state; pb.train_loss = b.train_loss;
+  pb.workspace = m.persist_ws; pb.workspace_bytes = p->persist_bytes;
+  PersistHyper hy;
+  hy.lr = p->cfg.lr; hy.beta1 = p->cfg.beta1; hy.beta2 = p->cfg.beta2;
+  hy.adam_eps = p->cfg.adam_eps; hy.eps_noise = p->cfg.head.eps_noise;
+  hy.min_weight = p->cfg.head.min_weight; hy.ll_limit = p->cfg.head.ll_limit;
+  hy.norm_batch = p->norm_batch;
+  return persist_run(persist_shape(p), pb, hy, n, st);
 }
 
 static Inputs train_inputs(const bsig_fit_plan* p, const PlanMem& m) {
@@ -638,6 +665,11 @@ extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t m
   const char* fused = getenv("BSIG_FUSED_HEAD");
   p->fused_head = (fused && fused[0] == '1') && cfg->head.full_cov == 0 &&
                   mdn_head_fused_ok(&cfg->head, batch);
+  const char* no_persist = getenv("BSIG_NO_PERSISTENT");
+  p->persistent = p->hoist && p->L.n_layers == 0 && cfg->head.full_cov == 0 &&
+                  !(no_persist && no_persist[0] == '1') && persist_supported(persist_shape(p));
+  if (p->persistent)
+    p->persist_bytes = round_up<size_t>(persist_workspace_bytes(persist_shape(p)), 256);
   if (p->hoist) {
     p->feats_bytes = round_up<size_t>(feats, 256);
     const int64_t mf = cfg->rff_cos_only ? cfg->rff_feats : cfg->rff_feats / 2;
@@ -702,6 +734,10 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
     BSIG_TRY(mdn_head_sync_reset(&p->cfg.head, p->batch, m.tr.head_ws, m.tr.head_ws_bytes, st));
   }
   BSIG_CHECK_LAUNCH("fit_begin");
+  if (p->persistent) {
+    PlanMem m; plan_mem(p, &m);
+    BSIG_TRY(persist_reset(persist_shape(p), m.persist_ws, p->persist_bytes, st));
+  }
   // fresh optimizer state for every run_training call (mdnn.py:203)
   BSIG_HIP(hipMemsetAsync(p->buf.exp_avg, 0, (size_t)p->L.total * sizeof(float), st));
   BSIG_HIP(hipMemsetAsync(p->buf.exp_avg_sq, 0, (size_t)p->L.total * sizeof(float), st));
@@ -735,6 +771,19 @@ extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t s
   hipStream_t st = as_stream(stream);
   if (p->use_graph) BSIG_TRY(ensure_graphs(p));
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
+  if (p->persistent && !p->split_adam) {
+    // runs of updates between two held-out evaluations: one launch each
+    int64_t done = 0;
+    for (int64_t it = 0; it < n_updates; ++it) {
+      if (it % every == 0 || it + 1 == n_updates) {
+        BSIG_TRY(enqueue_persistent(p, (int)(it + 1 - done), st));
+        done = it + 1;
+        if (p->use_graph) BSIG_HIP(hipGraphLaunch(p->g_eval, st));
+        else BSIG_TRY(enqueue_eval(p, st));
+      }
+    }
+    return BSIG_OK;
+  }
   for (int64_t it = 0; it < n_updates; ++it) {
     if (p->use_graph) {
       if (p->split_adam) {

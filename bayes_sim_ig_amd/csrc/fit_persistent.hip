@@ -1,0 +1,471 @@
+// Persistent update kernel: a run of consecutive SGD updates of a linear
+// mixture-density head on precomputed features in ONE launch
+// (MDRFF.run_training's inner loop, mdnn.py:219-233, with the RFF projection
+// hoisted: forward mdnn.py:108-119, NLL :127-178, its backward, Adam :203/:229).
+//
+// At the reference's minibatch of 100 rows an update is a chain of five tiny
+// dependent kernels (head GEMM, split-K reduce, NLL, finish, dW+Adam), each
+// bounded by launch + first-load latency, and the weights and both Adam
+// moments stream from HBM every update.  Here the head matrix W [Nh, F] is
+// tiled over the chip once: workgroup (nb, ks) owns the 32 x 256 tile
+// W[32nb.., 256ks..] and keeps it, with its Adam moments, in REGISTERS (in the
+// 32x32 MFMA accumulator layout) for the whole run.  Per update:
+//   1. every workgroup loads its [B, 256] slice of the minibatch features into
+//      LDS, multiplies it with its W tile (fp32 MFMA 32x32x2, operands from
+//      LDS) and writes the [B, 32] partial product (a split-K slab) through to
+//      memory, then raises its flag;
+//   2. the first n_owner workgroups each own R minibatch rows: they wait for
+//      every flag, sum the k-slices of their rows, and run the row-wise
+//      NLL forward/backward (diag_row, one wavefront per row); the three
+//      batch-wide sums (jitter scale, its gradient term, the loss) cross
+//      workgroups as {tag, value} granules; d_out rows are written through
+//      and the owner raises its flag;
+//   3. every workgroup waits for the owners, loads its [B, 32] block of d_out
+//      (transposed into LDS), forms dW = d_out^T F on the MFMA units and
+//      applies Adam to its register tile; the k-slice-0 workgroups also own
+//      the 32 biases of their block.
+// The write-through / cache-bypassing accesses (agent-scope relaxed atomics)
+// are what makes data cross the per-XCD L2s inside a launch without fences
+// (tools/micro/grid_barrier_bench.hip: an agent-scope fence costs ~0.13 us per
+// workgroup here, the flag hop ~3 us).  All polls are bounded; a time-out
+// raises bit 1 of the state block's nonfinite word.
+#include "persist.h"
+
+#include <algorithm>
+
+#include "head_device.h"
+
+namespace bsig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kPT = 512;            // threads per workgroup (8 wavefronts)
+constexpr int kPC = 256;            // feature columns per workgroup
+constexpr int kPitch = kPC + 4;     // LDS row pitch of the feature / weight tiles
+constexpr int kNB = 32;             // head rows per workgroup
+constexpr int kPbufPitch = 33;
+constexpr int kLdsLimit = 160 * 1024;
+
+struct PersistArgs {
+  int B, FR, Fdim, Nh, NhP, D, K;
+  int n_blocks, k_slices, G, n_owner, R;
+  int n_updates, x_floats;
+  const float* feats; int64_t ld_feats;
+  const float* y; int64_t ldy; const int32_t* ids;
+  float* params; float* m1; float* m2; int64_t w_off, b_off;
+  int32_t* state; float* train_loss;
+  double lr, beta1, beta2;
+  float adam_eps, eps_noise, min_w, ll_limit, inv_norm;
+  float* slabs; float* d_out; unsigned* flag_fwd; unsigned* flag_do; unsigned long long* gran;
+};
+
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Fl = smem;                          // [FR][kPitch] minibatch features (this k-slice)
+  float* Wl = Fl + p.FR * kPitch;            // [32][kPitch] weight tile as an MFMA operand
+  float* X = Wl + kNB * kPitch;              // scratch: forward halves | owner rows | d_out^T
+  float* red = X + p.x_floats;               // [64]
+  float* biasl = red + 64;                   // [3][32] bias, exp_avg, exp_avg_sq (k-slice 0)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wg = blockIdx.x, ks = wg % p.k_slices, nb = wg / p.k_slices;
+  const int n0 = nb * kNB, k0 = ks * kPC;
+  const int B = p.B, Nh = p.Nh, NhP = p.NhP, D = p.D, K = p.K, DK = D * K;
+  int32_t* flagp = p.state + 2;
+  const int step0 = p.state[0];
+  const uint64_t rng_seed = reinterpret_cast<const uint64_t*>(p.state + 8)[0];
+  const uint64_t rng_ctr0 = reinterpret_cast<const uint64_t*>(p.state + 8)[1];
+  double b1t = reinterpret_cast<const double*>(p.state + 12)[0];
+  double b2t = reinterpret_cast<const double*>(p.state + 12)[1];
+  float a0 = 0.f, a1 = 0.f;
+
+  // resident tile of W / exp_avg / exp_avg_sq in the dW accumulator layout:
+  // element i of lane (h, l31) of wave w  <->  W[n0 + acc_row(i, h)][k0 + 32w + l31]
+  float Wr[16], Mr[16], Vr[16];
+  const int kcol = 32 * w + l31;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + acc_row(i, h);
+    Wr[i] = 0.f; Mr[i] = 0.f; Vr[i] = 0.f;
+    if (n < Nh) {
+      const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
+      Wr[i] = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) Wl[acc_row(i, h) * kPitch + kcol] = Wr[i];
+  if (ks == 0 && tid < kNB) {
+    const int n = n0 + tid;
+    biasl[tid] = n < Nh ? p.params[p.b_off + n] : 0.f;
+    biasl[32 + tid] = n < Nh ? p.m1[p.b_off + n] : 0.f;
+    biasl[64 + tid] = n < Nh ? p.m2[p.b_off + n] : 0.f;
+  }
+  for (int idx = tid; idx < (p.FR - B) * kPitch; idx += kPT) Fl[B * kPitch + idx] = 0.f;
+
+  HeadArgs a{};
+  a.D = D; a.K = K; a.Nh = Nh; a.batch = B; a.from_tuple = 0;
+  a.min_w = p.min_w; a.ll_limit = p.ll_limit; a.inv_norm = p.inv_norm;
+  a.eps_noise = p.eps_noise; a.seed = rng_seed; a.d_out = p.d_out;
+  const float norm = (float)B * (float)DK;
+  const int per_wave = Nh + D + 3 * K;
+  const int DOP = p.FR + 4;
+  __syncthreads();
+
+  for (int t = 0; t < p.n_updates; ++t) {
+    const int step = step0 + t;
+    const unsigned epoch = (unsigned)step + 1u;
+    const uint32_t tag = epoch * 4u;
+    // a timed-out poll anywhere on the chip ends the run (workgroup-uniform exit)
+    if (tid == 0)
+      red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
+    __syncthreads();
+    if (red[63] != 0.f) break;
+
+    // ---- 1. feature tile of this minibatch -> LDS ---------------------------
+    {
+      const float* src = p.feats + (int64_t)step * B * p.ld_feats + k0;
+      const int nvec = B * (kPC / 4);
+      for (int base = 0; base < nvec; base += kPT * 8) {
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = min(base + u * kPT + tid, nvec - 1);
+          q[u] = *reinterpret_cast<const float4*>(src + (int64_t)(idx >> 6) * p.ld_feats +
+                                                  (idx & 63) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kPT + tid;
+          if (idx < nvec)
+            *reinterpret_cast<float4*>(Fl + (idx >> 6) * kPitch + (idx & 63) * 4) = q[u];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 2. partial forward: P[b, n] = sum_{k in slice} F[b, k] W[n, k] -------
+    {
+      const int mt = w & 3, kh = w >> 2;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = Fl + (mt * 32 + l31) * kPitch + kh * 128 + 4 * h;
+      const float* bp = Wl + l31 * kPitch + kh * 128 + 4 * h;
+#pragma unroll 4
+      for (int kk = 0; kk < 128; kk += 8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      }
+      if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h)) * kPbufPitch + l31] = acc[i];
+      }
+      __syncthreads();
+      if (kh == 0) {
+        const float bias = ks == 0 ? biasl[l31] : 0.f;
+        float* dst = p.slabs + (int64_t)ks * B * NhP + n0 + l31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mt * 32 + acc_row(i, h);
+          const float v = acc[i] + X[row * kPbufPitch + l31] + bias;
+          if (row < B) xwg_store(dst + (int64_t)row * NhP, v);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(p.flag_fwd + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- 3. row owners: reduce the k-slices, NLL forward / backward ----------
+    if (wg < p.n_owner) {
+      const int r0 = wg * p.R;
+      float* tile = X + w * per_wave;
+      float* yv = tile + Nh;
+      float* rk = yv + D;
+      float* lpk = rk + K;
+      float* dlg = lpk + K;
+      const int row = r0 + w;
+      const bool owner_wave = w < p.R;
+      const bool active = owner_wave && row < B;
+      int64_t yrow = 0;
+      if (active) yrow = p.ids[(int64_t)step * B + row];
+      if (w == 0) flags_wait(p.flag_fwd, p.G, epoch, lane, flagp);
+      __syncthreads();
+      float eacc = 0.f;
+      const int nelem = min(p.R, B - r0) * Nh;
+      const int64_t zs = (int64_t)B * NhP;
+      for (int idx = tid; idx < nelem; idx += kPT) {
+        const int r = idx / Nh, col = idx - r * Nh;
+        const float* src = p.slabs + (int64_t)(r0 + r) * NhP + col;
+        float v = 0.f;
+        for (int z = 0; z < p.k_slices; z += 16) {
+          float q[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) q[u] = xwg_load(src + (int64_t)min(z + u, p.k_slices - 1) * zs);
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (z + u < p.k_slices) v += q[u];
+        }
+        X[r * per_wave + col] = v;
+        if (col >= K + DK && col < K + 2 * DK) eacc += expf(v);
+      }
+      eacc = wave_sum(eacc);
+      if (lane == 0) red[w] = eacc;
+      __syncthreads();
+      if (tid == 0) {
+        float sx = 0.f;
+        for (int q = 0; q < kPT / 64; ++q) sx += red[q];
+        granule_publish(p.gran + wg, tag + 1, sx);
+      }
+      RowOut ro;
+      ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
+#pragma unroll
+      for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
+      if (owner_wave) {
+        if (active)
+          for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
+        float eps = 0.f;
+        if (p.eps_noise != 0.f)
+          eps = p.eps_noise * (granule_gather(p.gran, p.n_owner, tag + 1, lane, flagp) / norm);
+        __builtin_amdgcn_wave_barrier();
+        a.stream_id = rng_ctr0 + (uint64_t)t;
+        diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, eps, ro);
+        const float uds_w = wave_sum(ro.uds);
+        if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float sl = 0.f, su = 0.f;
+        for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
+        granule_publish(p.gran + kXwgMax + wg, tag + 2, su);
+        granule_publish(p.gran + 2 * kXwgMax + wg, tag + 3, sl);
+      }
+      if (owner_wave) {
+        // jitter-scale gradient term: d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
+        float c = 0.f;
+        if (p.eps_noise != 0.f)
+          c = p.eps_noise / norm *
+              granule_gather(p.gran + kXwgMax, p.n_owner, tag + 2, lane, flagp);
+        if (active) {
+          const int groups = 64 / K;
+          const int k = lane % K, d0 = lane / K;
+          if (c != 0.f && lane < groups * K) {
+#pragma unroll
+            for (int q = 0; q < kElemsPerLane; ++q) {
+              const int d = d0 + q * groups;
+              if (d < D) tile[K + DK + d * K + k] += c * ro.esg0[q];
+            }
+          }
+          for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
+          __builtin_amdgcn_wave_barrier();
+          float* o = p.d_out + (int64_t)row * NhP;
+          for (int j = lane; j < Nh; j += 64) xwg_store(o + j, tile[j]);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(p.flag_do + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wg == 0 && w == 0) {
+        const float s = granule_gather(p.gran + 2 * kXwgMax, p.n_owner, tag + 3, lane, flagp);
+        if (lane == 0) {
+          const float l = -s / (float)B;
+          p.train_loss[step] = l;
+          if (!isfinite(l)) atomicOr(flagp, 1);
+        }
+      }
+      if (ro.bad) atomicOr(flagp, 1);
+    }
+
+    // ---- 4. dW = d_out^T F on this tile, Adam in registers -------------------
+    if (w == 0) flags_wait(p.flag_do, p.n_owner, epoch, lane, flagp);
+    __syncthreads();
+    for (int base = 0; base < p.FR * kNB; base += kPT * 8) {
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kPT + tid;
+        const int b = idx >> 5, n = idx & 31;
+        q[u] = (idx < p.FR * kNB && b < B) ? xwg_load(p.d_out + (int64_t)b * NhP + n0 + n) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kPT + tid;
+        if (idx < p.FR * kNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u];
+      }
+    }
+    __syncthreads();
+    b1t *= p.beta1; b2t *= p.beta2;
+    a0 = (float)(p.lr / (1.0 - b1t));
+    a1 = (float)(1.0 / sqrt(1.0 - b2t));
+    const float ob1 = 1.0f - (float)p.beta1, b2f = (float)p.beta2, ob2 = 1.0f - (float)p.beta2;
+    if (ks == 0 && tid < kNB) {            // biases of this block: column sums of d_out
+      float g = 0.f;
+      for (int b = 0; b < B; ++b) g += X[tid * DOP + b];
+      const float bm = biasl[32 + tid] + (g - biasl[32 + tid]) * ob1;
+      const float bv = biasl[64 + tid] * b2f + ob2 * g * g;
+      biasl[32 + tid] = bm;
+      biasl[64 + tid] = bv;
+      biasl[tid] = biasl[tid] - a0 * (bm / (sqrtf(bv) * a1 + p.adam_eps));
+    }
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = X + l31 * DOP + 4 * h;
+      const float* bp = Fl + (4 * h) * kPitch + kcol;
+      for (int bb = 0; bb < p.FR; bb += 8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + bb);
+        const float f0 = bp[(bb + 0) * kPitch], f1 = bp[(bb + 1) * kPitch];
+        const float f2 = bp[(bb + 2) * kPitch], f3 = bp[(bb + 3) * kPitch];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, f0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, f1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, f2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, f3, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float g = acc[i];
+        const float m = Mr[i] + (g - Mr[i]) * ob1;
+        const float v = Vr[i] * b2f + ob2 * g * g;
+        Mr[i] = m; Vr[i] = v;
+        Wr[i] = Wr[i] - a0 * (m / (sqrtf(v) * a1 + p.adam_eps));
+        Wl[acc_row(i, h) * kPitch + kcol] = Wr[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write the tile back, advance the engine state -------------------------
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + acc_row(i, h);
+    if (n < Nh) {
+      const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
+      p.params[off] = Wr[i]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+    }
+  }
+  if (ks == 0 && tid < kNB && n0 + tid < Nh) {
+    p.params[p.b_off + n0 + tid] = biasl[tid];
+    p.m1[p.b_off + n0 + tid] = biasl[32 + tid];
+    p.m2[p.b_off + n0 + tid] = biasl[64 + tid];
+  }
+  if (wg == 0 && tid == 0 && p.n_updates > 0) {
+    int32_t* st = p.state;
+    reinterpret_cast<double*>(st + 12)[0] = b1t;
+    reinterpret_cast<double*>(st + 12)[1] = b2t;
+    reinterpret_cast<float*>(st)[4] = a0;
+    reinterpret_cast<float*>(st)[5] = a1;
+    reinterpret_cast<uint64_t*>(st + 8)[1] = rng_ctr0 + (uint64_t)p.n_updates;
+    st[0] = step0 + p.n_updates;
+  }
+}
+
+// ---------------------------------------------------------------- host side
+struct PersistGeom {
+  int FR, Nh, NhP, n_blocks, k_slices, G, n_owner, R, x_floats;
+  size_t lds;
+  size_t slab_floats, dout_floats;
+};
+
+static bool persist_geom(const PersistShape& s, PersistGeom* g) {
+  if (s.batch < 1 || s.feat_dim < kPC || s.feat_dim % kPC != 0 || s.out_dim < 1 ||
+      s.n_comp < 1 || s.n_comp > 64)
+    return false;
+  const int groups = 64 / s.n_comp;
+  if (ceil_div(s.out_dim, groups) > kElemsPerLane) return false;   // diag_row's register cache
+  g->FR = (int)round_up(s.batch, 8);
+  if (g->FR > 128) return false;
+  g->Nh = s.n_comp + 2 * s.out_dim * s.n_comp;
+  g->n_blocks = ceil_div(g->Nh, kNB);
+  g->NhP = g->n_blocks * kNB;
+  g->k_slices = s.feat_dim / kPC;
+  g->G = g->n_blocks * g->k_slices;
+  if (g->G > kXwgMax || g->k_slices > 32) return false;
+  g->R = ceil_div(s.batch, std::min(g->G, s.batch));
+  if (g->R > kPT / 64) return false;
+  g->n_owner = ceil_div(s.batch, g->R);
+  const int per_wave = g->Nh + s.out_dim + 3 * s.n_comp;
+  g->x_floats = (int)round_up(std::max(std::max(128 * kPbufPitch, kNB * (g->FR + 4)),
+                                       (kPT / 64) * per_wave), 4);
+  g->lds = ((size_t)g->FR * kPitch + (size_t)kNB * kPitch + g->x_floats + 64 + 96) * sizeof(float);
+  // the forward reads feature rows up to 127 (results of rows >= batch are dropped)
+  if ((size_t)128 * kPitch * sizeof(float) > g->lds || g->lds > (size_t)kLdsLimit) return false;
+  g->slab_floats = (size_t)g->k_slices * s.batch * g->NhP;
+  g->dout_floats = (size_t)s.batch * g->NhP;
+  return true;
+}
+
+bool persist_supported(const PersistShape& s) {
+  PersistGeom g;
+  return persist_geom(s, &g);
+}
+
+static size_t sync_bytes() { return 2 * kXwgMax * sizeof(unsigned) + 3 * kXwgMax * 8; }
+
+size_t persist_workspace_bytes(const PersistShape& s) {
+  PersistGeom g;
+  if (!persist_geom(s, &g)) return 0;
+  return round_up<size_t>((g.slab_floats + g.dout_floats) * sizeof(float), 256) + sync_bytes();
+}
+
+int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  PersistGeom g;
+  BSIG_REQUIRE(persist_geom(s, &g), "persistent updates: shape not covered");
+  BSIG_REQUIRE(workspace && workspace_bytes >= persist_workspace_bytes(s),
+               "persistent updates: workspace too small");
+  char* base = reinterpret_cast<char*>(workspace);
+  const size_t slab_bytes = g.slab_floats * sizeof(float);
+  // d_out (its padding columns stay zero), flags and granules
+  BSIG_HIP(hipMemsetAsync(base + slab_bytes, 0, persist_workspace_bytes(s) - slab_bytes, st));
+  return BSIG_OK;
+}
+
+int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyper& hy, int n,
+                hipStream_t st) {
+  PersistGeom g;
+  BSIG_REQUIRE(persist_geom(s, &g), "persistent updates: shape not covered");
+  BSIG_REQUIRE(b.feats && b.y && b.ids && b.params && b.exp_avg && b.exp_avg_sq && b.state &&
+                   b.train_loss && b.workspace, "persistent updates: null buffer");
+  BSIG_REQUIRE(b.workspace_bytes >= persist_workspace_bytes(s),
+               "persistent updates: workspace too small");
+  BSIG_REQUIRE(b.ld_feats % 4 == 0 && aligned(b.feats, 16) && b.ld_feats >= s.feat_dim,
+               "persistent updates: features must be 16-byte aligned rows");
+  if (n <= 0) return BSIG_OK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_head_updates_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+    attr_set = true;
+  }
+  PersistArgs p{};
+  p.B = s.batch; p.FR = g.FR; p.Fdim = s.feat_dim; p.Nh = g.Nh; p.NhP = g.NhP;
+  p.D = s.out_dim; p.K = s.n_comp;
+  p.n_blocks = g.n_blocks; p.k_slices = g.k_slices; p.G = g.G; p.n_owner = g.n_owner; p.R = g.R;
+  p.n_updates = n; p.x_floats = g.x_floats;
+  p.feats = b.feats; p.ld_feats = b.ld_feats; p.y = b.y; p.ldy = b.ldy; p.ids = b.ids;
+  p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq; p.w_off = b.w_off; p.b_off = b.b_off;
+  p.state = b.state; p.train_loss = b.train_loss;
+  p.lr = hy.lr; p.beta1 = hy.beta1; p.beta2 = hy.beta2;
+  p.adam_eps = hy.adam_eps; p.eps_noise = hy.eps_noise; p.min_w = hy.min_weight;
+  p.ll_limit = hy.ll_limit; p.inv_norm = 1.0f / (float)hy.norm_batch;
+  char* base = reinterpret_cast<char*>(b.workspace);
+  p.slabs = reinterpret_cast<float*>(base);
+  p.d_out = p.slabs + g.slab_floats;
+  char* sync = base + round_up<size_t>((g.slab_floats + g.dout_floats) * sizeof(float), 256);
+  p.flag_fwd = reinterpret_cast<unsigned*>(sync);
+  p.flag_do = p.flag_fwd + kXwgMax;
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 2 * kXwgMax * sizeof(unsigned));
+  hipLaunchKernelGGL(linear_head_updates_kernel, dim3(g.G), dim3(kPT), g.lds, st, p);
+  BSIG_CHECK_LAUNCH("linear_head_updates");
+  return BSIG_OK;
+}
+
+}  // namespace bsig

@@ -1,0 +1,253 @@
+// Device-side pieces of the mixture-density head shared by mdn_head.hip and the
+// persistent update kernel (fit_persistent.hip).
+#pragma once
+#include "head.h"
+
+namespace bsig {
+
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+constexpr int kSigMax = 4096;       // capacity of the exp(pre) partial-sum array
+constexpr int kSigBlocks = 512;     // blocks of the stand-alone sigma0_sum kernel
+constexpr int kElemsPerLane = 8;    // wave kernel: register-cached elements per lane
+constexpr int kGranMax = 64;        // fused kernel: at most this many workgroups
+constexpr int kXwgMax = 256;        // persistent kernel: at most this many workgroups
+constexpr int kFusedThreads = 1024; // fused kernel: 16 wavefronts per workgroup
+
+struct HeadArgs {
+  const float* seg_w; int64_t ld_w;    // logits (fused) or weights (tuple), K / row
+  const float* seg_mu; int64_t ld_mu;  // D*K / row
+  const float* seg_sg; int64_t ld_sg;  // pre-activation (fused) or L_d (tuple)
+  const float* seg_lo; int64_t ld_lo;  // Ls*K / row or nullptr
+  const float* y; int64_t ldy; const int32_t* y_rows;
+  const int32_t* y_dyn; int64_t y_dyn_stride;  // y_rows index offset = y_dyn[0]*stride (replay)
+  int batch; float inv_norm;
+  int D, K, Ls, Nh, R;
+  int from_tuple;
+  const float* noise; uint64_t seed, stream_id;
+  const uint64_t* dyn_rng;             // device {seed, stream}: overrides (graph replay)
+  float eps_noise, min_w, ll_limit;
+  const float* sig_partials; int n_sig;  // partial sums of exp(pre) over the minibatch
+  float* d_out; int64_t ld_dout;       // nullptr: forward only
+  float* block_lse;                    // [gridDim.x]
+  float* block_uds;                    // [gridDim.x]  sum u * dL/dsigma
+  int32_t* nonfinite;
+  // fused variant only (fit engine, single rank): the raw head outputs arrive as
+  // split-K slabs, pre[row, col] = sum_z slabs[z][row][col] + bias[col]
+  const float* slabs; int n_slabs; const float* bias;
+  unsigned long long* gran;            // [3][kGranMax] {tag, value} cross-workgroup granules
+  float* colpart;                      // [gridDim.x][Nh] column sums of the block's d_out rows
+  float* loss; const int32_t* loss_slot;
+  FinishHook hook;
+};
+
+// ---- diagonal covariance, one wavefront per row ------------------------------
+// A wave never depends on another wave's LDS data here (each row is private),
+// so the phases are ordered by the in-order LDS pipeline of the wave itself
+// (wave_barrier only pins the compiler).  Per-component sums over the dimensions
+// are strided wavefront shuffles; the jitter draws use all four Philox outputs.
+//
+// diag_row: forward + backward of one row by one wavefront.  In: tile[Nh] raw
+// head outputs, yv[D] target.  Out: gradients in tile[K..Nh) and dlg[K]
+// (without the jitter-scale term), the row's logsumexp, sum(u * dL/dsigma),
+// and exp(pre) of the lane's elements (for the jitter-scale correction).
+struct RowOut { float lse, uds; bool bad; float esg0[kElemsPerLane]; };
+
+__device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active, int lane,
+                                         float* tile, const float* yv, float* rk, float* lpk,
+                                         float* dlg, float eps, RowOut& out) {
+  const int D = a.D, K = a.K;
+  const int DK = D * K;
+  const int groups = 64 / K;               // d-slots per sweep
+  const int TPR = groups * K;
+  const int k = lane % K, d0 = lane / K;
+  const bool elem = active && lane < TPR;
+  bool bad = false;
+  // per-element values kept for the backward half
+  float ez[kElemsPerLane], esg[kElemsPerLane], eu[kElemsPerLane];
+  float (&esg0)[kElemsPerLane] = out.esg0;
+  float quad = 0.f, logdet = 0.f;
+  Philox4 ph{{0u, 0u, 0u, 0u}};
+  const bool draw = eps != 0.f && a.noise == nullptr;
+  const uint64_t rng_seed = a.dyn_rng ? a.dyn_rng[0] : a.seed;
+  const uint64_t rng_sid = a.dyn_rng ? a.dyn_rng[1] : a.stream_id;
+#pragma unroll
+  for (int q = 0; q < kElemsPerLane; ++q) {
+    const int d = d0 + q * groups;
+    ez[q] = 0.f; esg[q] = 1.f; esg0[q] = 1.f; eu[q] = 0.f;
+    if ((q & 3) == 0 && draw && elem)
+      ph = philox4x32_10(rng_seed, rng_sid, ((uint64_t)row * 64 + lane) * 2 + (q >> 2));
+    if (elem && d < D) {
+      const float mu = tile[K + d * K + k];
+      const float sraw = tile[K + DK + d * K + k];
+      float sg0 = 1.f, sg, u = 0.f;
+      if (a.from_tuple) sg = sraw;
+      else {
+        sg0 = expf(sraw);
+        sg = sg0;
+        if (eps != 0.f) {
+          u = a.noise ? a.noise[((int64_t)row * D + d) * K + k] : u01(ph.v[q & 3]);
+          sg += u * eps;
+        }
+      }
+      bad |= !(isfinite(mu) && isfinite(sg));
+      const float z = (yv[d] - mu) / sg;
+      quad += z * z;
+      logdet += logf(sg);
+      ez[q] = z; esg[q] = sg; esg0[q] = sg0; eu[q] = u;
+    }
+  }
+  // sum over the dimensions of each component: lanes k, k+K, k+2K, ...
+  for (int off = 32; off >= 1; off >>= 1) {
+    if (off < groups || off == 1) {
+      const float tq = __shfl_down(quad, off * K, 64);
+      const float tl = __shfl_down(logdet, off * K, 64);
+      if (d0 + off < groups && lane + off * K < 64) { quad += tq; logdet += tl; }
+    }
+  }
+  // mixture weights (every lane, redundantly: K is small)
+  float mx = 0.f, den = 1.f, csum = 1.f;
+  if (active && !a.from_tuple) {
+    mx = tile[0];
+    for (int j = 1; j < K; ++j) mx = fmaxf(mx, tile[j]);
+    den = 0.f;
+    for (int j = 0; j < K; ++j) den += expf(tile[j] - mx);
+    csum = 0.f;
+    for (int j = 0; j < K; ++j) csum += fminf(fmaxf(expf(tile[j] - mx) / den, a.min_w), 1.0f);
+  }
+  if (active && lane < K) {
+    const float logp = -0.5f * quad - logdet - (float)D * kHalfLog2Pi;
+    const float w = a.from_tuple ? tile[lane]
+                                 : fminf(fmaxf(expf(tile[lane] - mx) / den, a.min_w), 1.0f) / csum;
+    const float lp = fminf(fmaxf(logp, -a.ll_limit), a.ll_limit);
+    const float rv = lp + logf(fminf(fmaxf(w, a.min_w), 1.0f));
+    bad |= !(isfinite(w) && isfinite(logp) && isfinite(rv));
+    rk[lane] = rv;
+    lpk[lane] = logp;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float lse = 0.f;
+  if (active) {
+    float m2 = rk[0];
+    for (int j = 1; j < K; ++j) m2 = fmaxf(m2, rk[j]);
+    float se = 0.f;
+    for (int j = 0; j < K; ++j) se += expf(rk[j] - m2);
+    lse = m2 + logf(se);
+  }
+
+  const bool bwd = a.d_out != nullptr;
+  float uds = 0.f;
+  if (bwd && elem) {
+    const float sc = -expf(rk[k] - lse) * a.inv_norm;
+    const float lp0 = lpk[k];
+    const float g_lp = (lp0 >= -a.ll_limit && lp0 <= a.ll_limit) ? sc : 0.f;
+#pragma unroll
+    for (int q = 0; q < kElemsPerLane; ++q) {
+      const int d = d0 + q * groups;
+      if (d < D) {
+        const float dsg = g_lp * (ez[q] * ez[q] - 1.0f) / esg[q];
+        uds += eu[q] * dsg;
+        tile[K + d * K + k] = g_lp * ez[q] / esg[q];
+        tile[K + DK + d * K + k] = dsg * esg0[q];
+      }
+    }
+  }
+  if (bwd && active && lane < K) {          // mixture-weight path, lane = component
+    float dlogit;
+    if (a.from_tuple) {
+      const float w = tile[lane];
+      const float sc = -expf(rk[lane] - lse) * a.inv_norm;
+      dlogit = (w >= a.min_w && w <= 1.0f) ? sc / fminf(fmaxf(w, a.min_w), 1.0f) : 0.f;
+    } else {
+      float s1 = 0.f;
+      for (int j = 0; j < K; ++j) {
+        const float sj = expf(tile[j] - mx) / den;
+        const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
+        const float scj = -expf(rk[j] - lse) * a.inv_norm;
+        const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / fminf(fmaxf(wj, a.min_w), 1.0f) : 0.f;
+        s1 += gwj * wj;
+      }
+      float s2 = 0.f, gs_k = 0.f, s_k = 0.f;
+      for (int j = 0; j < K; ++j) {
+        const float sj = expf(tile[j] - mx) / den;
+        const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
+        const float scj = -expf(rk[j] - lse) * a.inv_norm;
+        const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / fminf(fmaxf(wj, a.min_w), 1.0f) : 0.f;
+        const float gsj = (sj >= a.min_w && sj <= 1.0f) ? (gwj - s1) / csum : 0.f;
+        s2 += gsj * sj;
+        if (j == lane) { gs_k = gsj; s_k = sj; }
+      }
+      dlogit = s_k * (gs_k - s2);
+    }
+    dlg[lane] = dlogit;                     // separate slot: the logits stay readable
+  }
+  __builtin_amdgcn_wave_barrier();
+  out.lse = lse; out.uds = uds; out.bad = bad;
+}
+
+// ---- cross-workgroup sums inside one launch -----------------------------------
+// 8-byte {tag, value} granules: one relaxed agent-scope atomic store each
+// (written through to memory: the per-XCD L2s are not coherent with each other
+// inside a kernel), polled by lane g (+64, +128, +192) of every consuming wave
+// and summed in granule order (bitwise reproducible).  The poll is bounded and
+// raises bit 1 of `flag` instead of hanging.
+__device__ inline void granule_publish(unsigned long long* g, uint32_t tag, float v) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float granule_gather(unsigned long long* g, int G, uint32_t tag, int lane,
+                                       int32_t* flag) {
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  bool ok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) ok[u] = lane + 64 * u >= G;
+  for (unsigned spin = 0;; ++spin) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) {
+        const unsigned long long x =
+            __hip_atomic_load(g + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(x >> 32) == tag) { ok[u] = true; v[u] = __uint_as_float((uint32_t)x); }
+      }
+    }
+    if (__all(ok[0] && ok[1] && ok[2] && ok[3])) break;
+    if (spin > (1u << 18)) {
+      if (flag && lane == 0) atomicOr(flag, 2);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return (wave_sum(v[0]) + wave_sum(v[1])) + (wave_sum(v[2]) + wave_sum(v[3]));
+}
+
+// wait until flags[0..G) >= epoch (G <= 256; one wavefront polls)
+__device__ inline void flags_wait(unsigned* flags, int G, unsigned epoch, int lane, int32_t* flag) {
+  bool ok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) ok[u] = lane + 64 * u >= G;
+  for (unsigned spin = 0;; ++spin) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (!ok[u])
+        ok[u] = __hip_atomic_load(flags + lane + 64 * u, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+    if (__all(ok[0] && ok[1] && ok[2] && ok[3])) break;
+    if (spin > (1u << 18)) {
+      if (flag && lane == 0) atomicOr(flag, 2);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// write-through store / cache-bypassing load for data that crosses workgroups
+// inside one launch
+__device__ inline void xwg_store(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float xwg_load(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+
+}  // namespace bsig

@@ -1,0 +1,39 @@
+// Persistent update kernel of the fit engine (fit_persistent.hip): a run of
+// consecutive Adam updates of a linear mixture-density head on precomputed
+// features (MDRFF with the hoisted RFF projection) in ONE launch.
+#pragma once
+#include "common.h"
+
+namespace bsig {
+
+struct PersistShape {
+  int batch, feat_dim, out_dim, n_comp;
+};
+
+struct PersistBuffers {
+  const float* feats; int64_t ld_feats;   // row (step*batch + i) = features of minibatch row i
+  const float* y; int64_t ldy;            // targets, gathered through ids
+  const int32_t* ids;                     // [n_updates*batch] minibatch row ids
+  float* params; float* exp_avg; float* exp_avg_sq;   // flat buffers
+  int64_t w_off, b_off;                   // head weights [Nh, feat_dim] / bias [Nh] inside them
+  int32_t* state;                         // the fit engine's 16-word state block
+  float* train_loss;                      // [n_updates]
+  void* workspace; size_t workspace_bytes;
+};
+
+struct PersistHyper {
+  double lr, beta1, beta2; float adam_eps, eps_noise, min_weight, ll_limit;
+  int64_t norm_batch;
+};
+
+// true when the shape is covered (diagonal covariance, feat_dim % 256 == 0, ...)
+bool persist_supported(const PersistShape& s);
+size_t persist_workspace_bytes(const PersistShape& s);
+// zero the cross-workgroup flags / gradient staging (once per fit call)
+int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes, hipStream_t st);
+// n consecutive updates starting at the state block's step counter; advances
+// the counter, the jitter RNG stream and the Adam bias-correction powers
+int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyper& h, int n,
+                hipStream_t st);
+
+}  // namespace bsig
