@@ -803,3 +803,6 @@ extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t s
   }
   return BSIG_OK;
 }
+
+// diagnostics (tools/persist_prof.py): phase time stamps of the persistent kernel
+extern "C" void bsig_debug_persist_profile(void* buffer) { persist_set_profile_buffer(buffer); }

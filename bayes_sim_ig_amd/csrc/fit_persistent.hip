@@ -56,46 +56,78 @@ struct PersistArgs {
   int32_t* state; float* train_loss;
   double lr, beta1, beta2;
   float adam_eps, eps_noise, min_w, ll_limit, inv_norm;
-  float* slabs; float* d_out; unsigned* flag_fwd; unsigned* flag_do; unsigned long long* gran;
+  float* slabs; float* d_out; float* e_out; unsigned* flag_fwd; unsigned long long* gran;
+  long long* prof;   // diagnostics: [G][kProfUpdates][16] wall-clock stamps, or null
 };
+
+constexpr int kProfUpdates = 8;
+#define BSIG_STAMP(k)                                                              \
+  do {                                                                             \
+    if (p.prof && threadIdx.x == 0 && t < kProfUpdates)                                    \
+      p.prof[((int64_t)wg * kProfUpdates + t) * 16 + (k)] = wall_clock64();        \
+  } while (0)
 
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-__global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// workgroup-uniform test of the time-out bit (set by any bounded poll on the chip)
+__device__ __forceinline__ bool run_aborted(int32_t* flagp, float* red, int tid) {
+  if (tid == 0)
+    red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
+  __syncthreads();
+  return red[63] != 0.f;
+}
+
+// one [<=104, 256] feature tile = 13 float4 per thread, kept in named registers
+// between the prefetch and the LDS write (an indexed array lands in scratch)
+#define BSIG_PF_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#define BSIG_PF_DECL(u) float4 pf##u;
+#define BSIG_PF_LOAD(u)                                                                   \
+  {                                                                                       \
+    const int idx = min((u) * kPT + tid, nvec - 1);                                       \
+    pf##u = *reinterpret_cast<const float4*>(src + (int64_t)(idx >> 6) * p.ld_feats +     \
+                                             (idx & 63) * 4);                             \
+  }
+#define BSIG_PF_STORE(u)                                                                  \
+  {                                                                                       \
+    const int idx = (u) * kPT + tid;                                                      \
+    if (idx < nvec) *reinterpret_cast<float4*>(Fl + (idx >> 6) * kPitch + (idx & 63) * 4) = pf##u; \
+  }
+
+// ---- tile workgroups: forward partial products, dW, Adam ----------------------
+__device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem) {
   float* Fl = smem;                          // [FR][kPitch] minibatch features (this k-slice)
-  float* Wl = Fl + p.FR * kPitch;            // [32][kPitch] weight tile as an MFMA operand
-  float* X = Wl + kNB * kPitch;              // scratch: forward halves | owner rows | d_out^T
+  float* Wl = Fl + p.FR * kPitch;            // [32][kPitch] weight tile (authoritative copy)
+  float* X = Wl + kNB * kPitch;              // scratch: forward k-halves | d_out^T
   float* red = X + p.x_floats;               // [64]
   float* biasl = red + 64;                   // [3][32] bias, exp_avg, exp_avg_sq (k-slice 0)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int wg = blockIdx.x, ks = wg % p.k_slices, nb = wg / p.k_slices;
   const int n0 = nb * kNB, k0 = ks * kPC;
-  const int B = p.B, Nh = p.Nh, NhP = p.NhP, D = p.D, K = p.K, DK = D * K;
+  const int B = p.B, Nh = p.Nh, NhP = p.NhP;
   int32_t* flagp = p.state + 2;
   const int step0 = p.state[0];
-  const uint64_t rng_seed = reinterpret_cast<const uint64_t*>(p.state + 8)[0];
-  const uint64_t rng_ctr0 = reinterpret_cast<const uint64_t*>(p.state + 8)[1];
   double b1t = reinterpret_cast<const double*>(p.state + 12)[0];
   double b2t = reinterpret_cast<const double*>(p.state + 12)[1];
   float a0 = 0.f, a1 = 0.f;
+  const float ob1 = 1.0f - (float)p.beta1, b2f = (float)p.beta2, ob2 = 1.0f - (float)p.beta2;
 
-  // resident tile of W / exp_avg / exp_avg_sq in the dW accumulator layout:
-  // element i of lane (h, l31) of wave w  <->  W[n0 + acc_row(i, h)][k0 + 32w + l31]
-  float Wr[16], Mr[16], Vr[16];
+  // resident Adam moments in the dW accumulator layout: element i of lane
+  // (h, l31) of wave w  <->  W[n0 + acc_row(i, h)][k0 + 32w + l31]; W itself
+  // lives in LDS (it is the B operand of the forward product)
+  float Mr[16], Vr[16];
   const int kcol = 32 * w + l31;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int n = n0 + acc_row(i, h);
-    Wr[i] = 0.f; Mr[i] = 0.f; Vr[i] = 0.f;
+    float wv = 0.f;
+    Mr[i] = 0.f; Vr[i] = 0.f;
     if (n < Nh) {
       const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
-      Wr[i] = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+      wv = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
     }
+    Wl[acc_row(i, h) * kPitch + kcol] = wv;
   }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) Wl[acc_row(i, h) * kPitch + kcol] = Wr[i];
   if (ks == 0 && tid < kNB) {
     const int n = n0 + tid;
     biasl[tid] = n < Nh ? p.params[p.b_off + n] : 0.f;
@@ -103,47 +135,30 @@ __global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p)
     biasl[64 + tid] = n < Nh ? p.m2[p.b_off + n] : 0.f;
   }
   for (int idx = tid; idx < (p.FR - B) * kPitch; idx += kPT) Fl[B * kPitch + idx] = 0.f;
-
-  HeadArgs a{};
-  a.D = D; a.K = K; a.Nh = Nh; a.batch = B; a.from_tuple = 0;
-  a.min_w = p.min_w; a.ll_limit = p.ll_limit; a.inv_norm = p.inv_norm;
-  a.eps_noise = p.eps_noise; a.seed = rng_seed; a.d_out = p.d_out;
-  const float norm = (float)B * (float)DK;
-  const int per_wave = Nh + D + 3 * K;
   const int DOP = p.FR + 4;
+  const int nvec = B * (kPC / 4);
+
+  // feature tile of the first update (later ones are fetched during the waits)
+  BSIG_PF_LIST(BSIG_PF_DECL)
+  {
+    const float* src = p.feats + (int64_t)step0 * B * p.ld_feats + k0;
+    BSIG_PF_LIST(BSIG_PF_LOAD)
+  }
   __syncthreads();
 
   for (int t = 0; t < p.n_updates; ++t) {
+    // lane-derived indices are laundered once per update so that the address
+    // arithmetic built on them is recomputed, not kept live across the waits
+    int tid_l = tid, l31_l = l31, h_l = h, kcol_l = kcol;
+    asm volatile("" : "+v"(tid_l), "+v"(l31_l), "+v"(h_l), "+v"(kcol_l));
     const int step = step0 + t;
     const unsigned epoch = (unsigned)step + 1u;
-    const uint32_t tag = epoch * 4u;
-    // a timed-out poll anywhere on the chip ends the run (workgroup-uniform exit)
-    if (tid == 0)
-      red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
+    if (run_aborted(flagp, red, tid_l)) break;
+    BSIG_STAMP(0);
+    // ---- 1. feature tile -> LDS ---------------------------------------------
+    BSIG_PF_LIST(BSIG_PF_STORE)
     __syncthreads();
-    if (red[63] != 0.f) break;
-
-    // ---- 1. feature tile of this minibatch -> LDS ---------------------------
-    {
-      const float* src = p.feats + (int64_t)step * B * p.ld_feats + k0;
-      const int nvec = B * (kPC / 4);
-      for (int base = 0; base < nvec; base += kPT * 8) {
-        float4 q[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = min(base + u * kPT + tid, nvec - 1);
-          q[u] = *reinterpret_cast<const float4*>(src + (int64_t)(idx >> 6) * p.ld_feats +
-                                                  (idx & 63) * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * kPT + tid;
-          if (idx < nvec)
-            *reinterpret_cast<float4*>(Fl + (idx >> 6) * kPitch + (idx & 63) * 4) = q[u];
-        }
-      }
-    }
-    __syncthreads();
+    BSIG_STAMP(1);
 
     // ---- 2. partial forward: P[b, n] = sum_{k in slice} F[b, k] W[n, k] -------
     {
@@ -151,8 +166,8 @@ __global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p)
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-      const float* ap = Fl + (mt * 32 + l31) * kPitch + kh * 128 + 4 * h;
-      const float* bp = Wl + l31 * kPitch + kh * 128 + 4 * h;
+      const float* ap = Fl + (mt * 32 + l31_l) * kPitch + kh * 128 + 4 * h_l;
+      const float* bp = Wl + l31_l * kPitch + kh * 128 + 4 * h_l;
 #pragma unroll 4
       for (int kk = 0; kk < 128; kk += 8) {
         const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
@@ -162,165 +177,86 @@ __global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
       }
+      BSIG_STAMP(2);
       if (kh == 1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h)) * kPbufPitch + l31] = acc[i];
+        for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h_l)) * kPbufPitch + l31_l] = acc[i];
       }
       __syncthreads();
       if (kh == 0) {
-        const float bias = ks == 0 ? biasl[l31] : 0.f;
-        float* dst = p.slabs + (int64_t)ks * B * NhP + n0 + l31;
+        const float bias = ks == 0 ? biasl[l31_l] : 0.f;
+        float* dst = p.slabs + (int64_t)ks * B * NhP + n0 + l31_l;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int row = mt * 32 + acc_row(i, h);
-          const float v = acc[i] + X[row * kPbufPitch + l31] + bias;
+          const int row = mt * 32 + acc_row(i, h_l);
+          const float v = acc[i] + X[row * kPbufPitch + l31_l] + bias;
           if (row < B) xwg_store(dst + (int64_t)row * NhP, v);
         }
       }
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
-      if (tid == 0)
+      if (tid_l == 0)
         __hip_atomic_store(p.flag_fwd + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      BSIG_STAMP(3);
     }
 
-    // ---- 3. row owners: reduce the k-slices, NLL forward / backward ----------
-    if (wg < p.n_owner) {
-      const int r0 = wg * p.R;
-      float* tile = X + w * per_wave;
-      float* yv = tile + Nh;
-      float* rk = yv + D;
-      float* lpk = rk + K;
-      float* dlg = lpk + K;
-      const int row = r0 + w;
-      const bool owner_wave = w < p.R;
-      const bool active = owner_wave && row < B;
-      int64_t yrow = 0;
-      if (active) yrow = p.ids[(int64_t)step * B + row];
-      if (w == 0) flags_wait(p.flag_fwd, p.G, epoch, lane, flagp);
-      __syncthreads();
-      float eacc = 0.f;
-      const int nelem = min(p.R, B - r0) * Nh;
-      const int64_t zs = (int64_t)B * NhP;
-      for (int idx = tid; idx < nelem; idx += kPT) {
-        const int r = idx / Nh, col = idx - r * Nh;
-        const float* src = p.slabs + (int64_t)(r0 + r) * NhP + col;
-        float v = 0.f;
-        for (int z = 0; z < p.k_slices; z += 16) {
-          float q[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) q[u] = xwg_load(src + (int64_t)min(z + u, p.k_slices - 1) * zs);
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            if (z + u < p.k_slices) v += q[u];
-        }
-        X[r * per_wave + col] = v;
-        if (col >= K + DK && col < K + 2 * DK) eacc += expf(v);
-      }
-      eacc = wave_sum(eacc);
-      if (lane == 0) red[w] = eacc;
-      __syncthreads();
-      if (tid == 0) {
-        float sx = 0.f;
-        for (int q = 0; q < kPT / 64; ++q) sx += red[q];
-        granule_publish(p.gran + wg, tag + 1, sx);
-      }
-      RowOut ro;
-      ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
-#pragma unroll
-      for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
-      if (owner_wave) {
-        if (active)
-          for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
-        float eps = 0.f;
-        if (p.eps_noise != 0.f)
-          eps = p.eps_noise * (granule_gather(p.gran, p.n_owner, tag + 1, lane, flagp) / norm);
-        __builtin_amdgcn_wave_barrier();
-        a.stream_id = rng_ctr0 + (uint64_t)t;
-        diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, eps, ro);
-        const float uds_w = wave_sum(ro.uds);
-        if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
-      }
-      __syncthreads();
-      if (tid == 0) {
-        float sl = 0.f, su = 0.f;
-        for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
-        granule_publish(p.gran + kXwgMax + wg, tag + 2, su);
-        granule_publish(p.gran + 2 * kXwgMax + wg, tag + 3, sl);
-      }
-      if (owner_wave) {
-        // jitter-scale gradient term: d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
-        float c = 0.f;
-        if (p.eps_noise != 0.f)
-          c = p.eps_noise / norm *
-              granule_gather(p.gran + kXwgMax, p.n_owner, tag + 2, lane, flagp);
-        if (active) {
-          const int groups = 64 / K;
-          const int k = lane % K, d0 = lane / K;
-          if (c != 0.f && lane < groups * K) {
-#pragma unroll
-            for (int q = 0; q < kElemsPerLane; ++q) {
-              const int d = d0 + q * groups;
-              if (d < D) tile[K + DK + d * K + k] += c * ro.esg0[q];
-            }
-          }
-          for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
-          __builtin_amdgcn_wave_barrier();
-          float* o = p.d_out + (int64_t)row * NhP;
-          for (int j = lane; j < Nh; j += 64) xwg_store(o + j, tile[j]);
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
-      if (tid == 0)
-        __hip_atomic_store(p.flag_do + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (wg == 0 && w == 0) {
-        const float s = granule_gather(p.gran + 2 * kXwgMax, p.n_owner, tag + 3, lane, flagp);
-        if (lane == 0) {
-          const float l = -s / (float)B;
-          p.train_loss[step] = l;
-          if (!isfinite(l)) atomicOr(flagp, 1);
-        }
-      }
-      if (ro.bad) atomicOr(flagp, 1);
+    // ---- while the row owners work: next feature tile, Adam scalars -----------
+    if (t + 1 < p.n_updates) {
+      const float* src = p.feats + (int64_t)(step + 1) * B * p.ld_feats + k0;
+      BSIG_PF_LIST(BSIG_PF_LOAD)
     }
-
-    // ---- 4. dW = d_out^T F on this tile, Adam in registers -------------------
-    if (w == 0) flags_wait(p.flag_do, p.n_owner, epoch, lane, flagp);
-    __syncthreads();
-    for (int base = 0; base < p.FR * kNB; base += kPT * 8) {
-      float q[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * kPT + tid;
-        const int b = idx >> 5, n = idx & 31;
-        q[u] = (idx < p.FR * kNB && b < B) ? xwg_load(p.d_out + (int64_t)b * NhP + n0 + n) : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * kPT + tid;
-        if (idx < p.FR * kNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u];
-      }
-    }
-    __syncthreads();
-    b1t *= p.beta1; b2t *= p.beta2;
+    b1t *= p.beta1; b2t *= p.beta2;      // beta^t as running products (double)
     a0 = (float)(p.lr / (1.0 - b1t));
     a1 = (float)(1.0 / sqrt(1.0 - b2t));
-    const float ob1 = 1.0f - (float)p.beta1, b2f = (float)p.beta2, ob2 = 1.0f - (float)p.beta2;
-    if (ks == 0 && tid < kNB) {            // biases of this block: column sums of d_out
+
+    // ---- 3. dW = d_out^T F on this tile, Adam ----------------------------------
+    // the owners' sum(u * dL/dsigma) granules double as their "d_out rows are
+    // out" flags; the jitter-scale gradient term
+    //   d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
+    // is applied here, to this block's columns, while the tile is loaded
+    if (w == 0) {
+      const float su = granule_gather(p.gran + kXwgMax, p.n_owner, epoch * 4u + 2u, lane, flagp);
+      if (lane == 0) red[62] = p.eps_noise != 0.f ? p.eps_noise / ((float)B * (float)(p.D * p.K)) * su : 0.f;
+    }
+    __syncthreads();
+    BSIG_STAMP(10);
+    {
+      const float c = red[62];
+      const int sg_lo = p.K + p.D * p.K, sg_hi = p.K + 2 * p.D * p.K;
+      for (int base = 0; base < p.FR * kNB; base += kPT * 8) {
+        float q[8], e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kPT + tid_l;
+          const int b = idx >> 5, n = n0 + (idx & 31);
+          const bool ok = idx < p.FR * kNB && b < B;
+          q[u] = ok ? xwg_load(p.d_out + (int64_t)b * NhP + n) : 0.f;
+          e[u] = (ok && c != 0.f && n >= sg_lo && n < sg_hi) ? xwg_load(p.e_out + (int64_t)b * NhP + n) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kPT + tid_l;
+          if (idx < p.FR * kNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u] + c * e[u];
+        }
+      }
+    }
+    __syncthreads();
+    BSIG_STAMP(11);
+    if (ks == 0 && tid_l < kNB) {            // biases of this block: column sums of d_out
       float g = 0.f;
-      for (int b = 0; b < B; ++b) g += X[tid * DOP + b];
-      const float bm = biasl[32 + tid] + (g - biasl[32 + tid]) * ob1;
-      const float bv = biasl[64 + tid] * b2f + ob2 * g * g;
-      biasl[32 + tid] = bm;
-      biasl[64 + tid] = bv;
-      biasl[tid] = biasl[tid] - a0 * (bm / (sqrtf(bv) * a1 + p.adam_eps));
+      for (int b = 0; b < B; ++b) g += X[tid_l * DOP + b];
+      const float bm = biasl[32 + tid_l] + (g - biasl[32 + tid_l]) * ob1;
+      const float bv = biasl[64 + tid_l] * b2f + ob2 * g * g;
+      biasl[32 + tid_l] = bm;
+      biasl[64 + tid_l] = bv;
+      biasl[tid_l] = biasl[tid_l] - a0 * (bm / (sqrtf(bv) * a1 + p.adam_eps));
     }
     {
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-      const float* ap = X + l31 * DOP + 4 * h;
-      const float* bp = Fl + (4 * h) * kPitch + kcol;
+      const float* ap = X + l31_l * DOP + 4 * h_l;
+      const float* bp = Fl + (4 * h_l) * kPitch + kcol_l;
       for (int bb = 0; bb < p.FR; bb += 8) {
         const float4 a4 = *reinterpret_cast<const float4*>(ap + bb);
         const float f0 = bp[(bb + 0) * kPitch], f1 = bp[(bb + 1) * kPitch];
@@ -336,11 +272,12 @@ __global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p)
         const float m = Mr[i] + (g - Mr[i]) * ob1;
         const float v = Vr[i] * b2f + ob2 * g * g;
         Mr[i] = m; Vr[i] = v;
-        Wr[i] = Wr[i] - a0 * (m / (sqrtf(v) * a1 + p.adam_eps));
-        Wl[acc_row(i, h) * kPitch + kcol] = Wr[i];
+        float* wp = Wl + acc_row(i, h_l) * kPitch + kcol_l;
+        *wp = *wp - a0 * (m / (sqrtf(v) * a1 + p.adam_eps));
       }
     }
     __syncthreads();
+    BSIG_STAMP(12);
   }
 
   // ---- write the tile back, advance the engine state -------------------------
@@ -349,7 +286,7 @@ __global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p)
     const int n = n0 + acc_row(i, h);
     if (n < Nh) {
       const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
-      p.params[off] = Wr[i]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+      p.params[off] = Wl[acc_row(i, h) * kPitch + kcol]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
     }
   }
   if (ks == 0 && tid < kNB && n0 + tid < Nh) {
@@ -358,14 +295,143 @@ __global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p)
     p.m2[p.b_off + n0 + tid] = biasl[64 + tid];
   }
   if (wg == 0 && tid == 0 && p.n_updates > 0) {
+    // (an aborted run leaves the counters of the planned run: the call fails anyway)
     int32_t* st = p.state;
     reinterpret_cast<double*>(st + 12)[0] = b1t;
     reinterpret_cast<double*>(st + 12)[1] = b2t;
     reinterpret_cast<float*>(st)[4] = a0;
     reinterpret_cast<float*>(st)[5] = a1;
-    reinterpret_cast<uint64_t*>(st + 8)[1] = rng_ctr0 + (uint64_t)p.n_updates;
+    reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)p.n_updates;
     st[0] = step0 + p.n_updates;
   }
+}
+
+// ---- row-owner workgroups: reduce the k-slices, NLL forward / backward ---------
+__device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* smem) {
+  float* X = smem;                           // [R][per_wave] rows
+  float* red = smem + p.x_floats;            // [64]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wg = blockIdx.x, o = wg - p.G;
+  const int B = p.B, Nh = p.Nh, NhP = p.NhP, D = p.D, K = p.K, DK = D * K;
+  int32_t* flagp = p.state + 2;
+  const int step0 = p.state[0];
+  const uint64_t rng_seed = reinterpret_cast<const uint64_t*>(p.state + 8)[0];
+  const uint64_t rng_ctr0 = reinterpret_cast<const uint64_t*>(p.state + 8)[1];
+  HeadArgs a{};
+  a.D = D; a.K = K; a.Nh = Nh; a.batch = B; a.from_tuple = 0;
+  a.min_w = p.min_w; a.ll_limit = p.ll_limit; a.inv_norm = p.inv_norm;
+  a.eps_noise = p.eps_noise; a.seed = rng_seed; a.d_out = p.d_out;
+  const float norm = (float)B * (float)DK;
+  const int per_wave = Nh + D + 3 * K;
+  const int r0 = o * p.R;
+  float* tile = X + w * per_wave;
+  float* yv = tile + Nh;
+  float* rk = yv + D;
+  float* lpk = rk + K;
+  float* dlg = lpk + K;
+  const int row = r0 + w;
+  const bool owner_wave = w < p.R;
+  const bool active = owner_wave && row < B;
+  const int nelem = min(p.R, B - r0) * Nh;
+  const int64_t zs = (int64_t)B * NhP;
+
+  for (int t = 0; t < p.n_updates; ++t) {
+    const int step = step0 + t;
+    const unsigned epoch = (unsigned)step + 1u;
+    const uint32_t tag = epoch * 4u;
+    if (run_aborted(flagp, red, tid)) break;
+    BSIG_STAMP(0);
+    if (active) {      // target row (independent of the forward product)
+      const int64_t yrow = p.ids[(int64_t)step * B + row];
+      for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
+    }
+    if (w == 0) flags_wait(p.flag_fwd, p.G, epoch, lane, flagp);
+    __syncthreads();
+    BSIG_STAMP(4);
+    float eacc = 0.f;
+    for (int idx = tid; idx < nelem; idx += kPT) {
+      const int r = idx / Nh, col = idx - r * Nh;
+      const float* src = p.slabs + (int64_t)(r0 + r) * NhP + col;
+      float v = 0.f;
+      for (int z = 0; z < p.k_slices; z += 16) {
+        float q[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) q[u] = xwg_load(src + (int64_t)min(z + u, p.k_slices - 1) * zs);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (z + u < p.k_slices) v += q[u];
+      }
+      X[r * per_wave + col] = v;
+      if (col >= K + DK && col < K + 2 * DK) eacc += expf(v);
+    }
+    eacc = wave_sum(eacc);
+    if (lane == 0) red[w] = eacc;
+    __syncthreads();
+    if (tid == 0) {
+      float sx = 0.f;
+      for (int q = 0; q < kPT / 64; ++q) sx += red[q];
+      granule_publish(p.gran + o, tag + 1, sx);
+    }
+    BSIG_STAMP(5);
+    RowOut ro;
+    ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
+#pragma unroll
+    for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
+    float uds_w = 0.f;
+    if (owner_wave) {
+      a.stream_id = rng_ctr0 + (uint64_t)t;
+      diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg,
+               [&] {
+                 BSIG_STAMP(6);
+                 return p.eps_noise != 0.f
+                            ? p.eps_noise * (granule_gather(p.gran, p.n_owner, tag + 1, lane, flagp) / norm)
+                            : 0.f;
+               },
+               ro);
+      uds_w = wave_sum(ro.uds);
+      if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
+      BSIG_STAMP(7);
+      if (active) {
+        // d_out row without the jitter-scale term, and exp(pre) of the row for the
+        // tile workgroups to add it (lane's elements are columns lane + q*TPR)
+        for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
+        __builtin_amdgcn_wave_barrier();
+        float* dst = p.d_out + (int64_t)row * NhP;
+        for (int j = lane; j < Nh; j += 64) xwg_store(dst + j, tile[j]);
+        if (p.eps_noise != 0.f) {
+          const int TPR = (64 / K) * K;
+          float* est = p.e_out + (int64_t)row * NhP + K + DK;
+#pragma unroll
+          for (int q = 0; q < kElemsPerLane; ++q)
+            if (lane < TPR && lane + q * TPR < DK) xwg_store(est + lane + q * TPR, ro.esg0[q]);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+      float sl = 0.f, su = 0.f;
+      for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
+      granule_publish(p.gran + kXwgMax + o, tag + 2, su);
+      granule_publish(p.gran + 2 * kXwgMax + o, tag + 3, sl);
+    }
+    BSIG_STAMP(9);
+    if (o == 0 && w == 0) {
+      const float s = granule_gather(p.gran + 2 * kXwgMax, p.n_owner, tag + 3, lane, flagp);
+      if (lane == 0) {
+        const float l = -s / (float)B;
+        p.train_loss[step] = l;
+        if (!isfinite(l)) atomicOr(flagp, 1);
+      }
+    }
+    if (ro.bad) atomicOr(flagp, 1);
+  }
+}
+
+__global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < p.G) tile_workgroup(p, smem);
+  else owner_workgroup(p, smem);
 }
 
 // ---------------------------------------------------------------- host side
@@ -387,9 +453,10 @@ static bool persist_geom(const PersistShape& s, PersistGeom* g) {
   g->n_blocks = ceil_div(g->Nh, kNB);
   g->NhP = g->n_blocks * kNB;
   g->k_slices = s.feat_dim / kPC;
-  g->G = g->n_blocks * g->k_slices;
-  if (g->G > kXwgMax || g->k_slices > 32) return false;
-  g->R = ceil_div(s.batch, std::min(g->G, s.batch));
+  g->G = g->n_blocks * g->k_slices;          // tile workgroups
+  if (g->G > kXwgMax - 8 || g->k_slices > 32) return false;
+  // row owners: further workgroups, every workgroup of the launch on its own CU
+  g->R = ceil_div(s.batch, std::min(kXwgMax - g->G, s.batch));
   if (g->R > kPT / 64) return false;
   g->n_owner = ceil_div(s.batch, g->R);
   const int per_wave = g->Nh + s.out_dim + 3 * s.n_comp;
@@ -408,12 +475,12 @@ bool persist_supported(const PersistShape& s) {
   return persist_geom(s, &g);
 }
 
-static size_t sync_bytes() { return 2 * kXwgMax * sizeof(unsigned) + 3 * kXwgMax * 8; }
+static size_t sync_bytes() { return kXwgMax * sizeof(unsigned) + 3 * kXwgMax * 8; }
 
 size_t persist_workspace_bytes(const PersistShape& s) {
   PersistGeom g;
   if (!persist_geom(s, &g)) return 0;
-  return round_up<size_t>((g.slab_floats + g.dout_floats) * sizeof(float), 256) + sync_bytes();
+  return round_up<size_t>((g.slab_floats + 2 * g.dout_floats) * sizeof(float), 256) + sync_bytes();
 }
 
 int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -427,6 +494,9 @@ int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes
   BSIG_HIP(hipMemsetAsync(base + slab_bytes, 0, persist_workspace_bytes(s) - slab_bytes, st));
   return BSIG_OK;
 }
+
+static long long* g_prof = nullptr;
+void persist_set_profile_buffer(void* buf) { g_prof = reinterpret_cast<long long*>(buf); }
 
 int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyper& hy, int n,
                 hipStream_t st) {
@@ -459,11 +529,12 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   char* base = reinterpret_cast<char*>(b.workspace);
   p.slabs = reinterpret_cast<float*>(base);
   p.d_out = p.slabs + g.slab_floats;
-  char* sync = base + round_up<size_t>((g.slab_floats + g.dout_floats) * sizeof(float), 256);
+  p.e_out = p.d_out + g.dout_floats;
+  char* sync = base + round_up<size_t>((g.slab_floats + 2 * g.dout_floats) * sizeof(float), 256);
   p.flag_fwd = reinterpret_cast<unsigned*>(sync);
-  p.flag_do = p.flag_fwd + kXwgMax;
-  p.gran = reinterpret_cast<unsigned long long*>(sync + 2 * kXwgMax * sizeof(unsigned));
-  hipLaunchKernelGGL(linear_head_updates_kernel, dim3(g.G), dim3(kPT), g.lds, st, p);
+  p.gran = reinterpret_cast<unsigned long long*>(sync + kXwgMax * sizeof(unsigned));
+  p.prof = g_prof;
+  hipLaunchKernelGGL(linear_head_updates_kernel, dim3(g.G + g.n_owner), dim3(kPT), g.lds, st, p);
   BSIG_CHECK_LAUNCH("linear_head_updates");
   return BSIG_OK;
 }

@@ -52,9 +52,13 @@ struct HeadArgs {
 // and exp(pre) of the lane's elements (for the jitter-scale correction).
 struct RowOut { float lse, uds; bool bad; float esg0[kElemsPerLane]; };
 
+// `eps_fn()` delivers the jitter scale; it is called (by the whole wave) after
+// everything that does not depend on it -- the Philox draws, exp(pre), the
+// mixture weights -- so that a caller can hide a cross-workgroup wait there.
+template <typename EpsFn>
 __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active, int lane,
                                          float* tile, const float* yv, float* rk, float* lpk,
-                                         float* dlg, float eps, RowOut& out) {
+                                         float* dlg, EpsFn&& eps_fn, RowOut& out) {
   const int D = a.D, K = a.K;
   const int DK = D * K;
   const int groups = 64 / K;               // d-slots per sweep
@@ -67,41 +71,19 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
   float (&esg0)[kElemsPerLane] = out.esg0;
   float quad = 0.f, logdet = 0.f;
   Philox4 ph{{0u, 0u, 0u, 0u}};
-  const bool draw = eps != 0.f && a.noise == nullptr;
+  const bool jitter = !a.from_tuple && a.eps_noise != 0.f;
+  const bool draw = jitter && a.noise == nullptr;
   const uint64_t rng_seed = a.dyn_rng ? a.dyn_rng[0] : a.seed;
   const uint64_t rng_sid = a.dyn_rng ? a.dyn_rng[1] : a.stream_id;
 #pragma unroll
   for (int q = 0; q < kElemsPerLane; ++q) {
     const int d = d0 + q * groups;
     ez[q] = 0.f; esg[q] = 1.f; esg0[q] = 1.f; eu[q] = 0.f;
-    if ((q & 3) == 0 && draw && elem)
+    if ((q & 3) == 0 && draw && elem && d < D)
       ph = philox4x32_10(rng_seed, rng_sid, ((uint64_t)row * 64 + lane) * 2 + (q >> 2));
-    if (elem && d < D) {
-      const float mu = tile[K + d * K + k];
-      const float sraw = tile[K + DK + d * K + k];
-      float sg0 = 1.f, sg, u = 0.f;
-      if (a.from_tuple) sg = sraw;
-      else {
-        sg0 = expf(sraw);
-        sg = sg0;
-        if (eps != 0.f) {
-          u = a.noise ? a.noise[((int64_t)row * D + d) * K + k] : u01(ph.v[q & 3]);
-          sg += u * eps;
-        }
-      }
-      bad |= !(isfinite(mu) && isfinite(sg));
-      const float z = (yv[d] - mu) / sg;
-      quad += z * z;
-      logdet += logf(sg);
-      ez[q] = z; esg[q] = sg; esg0[q] = sg0; eu[q] = u;
-    }
-  }
-  // sum over the dimensions of each component: lanes k, k+K, k+2K, ...
-  for (int off = 32; off >= 1; off >>= 1) {
-    if (off < groups || off == 1) {
-      const float tq = __shfl_down(quad, off * K, 64);
-      const float tl = __shfl_down(logdet, off * K, 64);
-      if (d0 + off < groups && lane + off * K < 64) { quad += tq; logdet += tl; }
+    if (elem && d < D && !a.from_tuple) {
+      esg0[q] = expf(tile[K + DK + d * K + k]);
+      if (jitter) eu[q] = a.noise ? a.noise[((int64_t)row * D + d) * K + k] : u01(ph.v[q & 3]);
     }
   }
   // mixture weights (every lane, redundantly: K is small)
@@ -113,6 +95,34 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
     for (int j = 0; j < K; ++j) den += expf(tile[j] - mx);
     csum = 0.f;
     for (int j = 0; j < K; ++j) csum += fminf(fmaxf(expf(tile[j] - mx) / den, a.min_w), 1.0f);
+  }
+  const float eps = eps_fn();
+#pragma unroll
+  for (int q = 0; q < kElemsPerLane; ++q) {
+    const int d = d0 + q * groups;
+    if (elem && d < D) {
+      const float mu = tile[K + d * K + k];
+      float sg;
+      if (a.from_tuple) sg = tile[K + DK + d * K + k];
+      else {
+        sg = esg0[q];
+        if (eps != 0.f) sg += eu[q] * eps;
+        else eu[q] = 0.f;
+      }
+      bad |= !(isfinite(mu) && isfinite(sg));
+      const float z = (yv[d] - mu) / sg;
+      quad += z * z;
+      logdet += logf(sg);
+      ez[q] = z; esg[q] = sg;
+    }
+  }
+  // sum over the dimensions of each component: lanes k, k+K, k+2K, ...
+  for (int off = 32; off >= 1; off >>= 1) {
+    if (off < groups || off == 1) {
+      const float tq = __shfl_down(quad, off * K, 64);
+      const float tl = __shfl_down(logdet, off * K, 64);
+      if (d0 + off < groups && lane + off * K < 64) { quad += tq; logdet += tl; }
+    }
   }
   if (active && lane < K) {
     const float logp = -0.5f * quad - logdet - (float)D * kHalfLog2Pi;

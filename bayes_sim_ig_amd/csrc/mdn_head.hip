@@ -325,7 +325,7 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
   __builtin_amdgcn_wave_barrier();
 
   RowOut ro;
-  diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, eps, ro);
+  diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, [&] { return eps; }, ro);
   const bool bwd = a.d_out != nullptr;
   if (bwd && active) {
     float* o = a.d_out + (int64_t)row * a.ld_dout;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kFusedThreads) void mdn_fused_diag_kernel(HeadArgs 
     if (a.eps_noise != 0.f)
       eps = a.eps_noise * (granule_gather(gran_exp, G, tag + 1, lane, a.nonfinite) / norm);
     __builtin_amdgcn_wave_barrier();
-    diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, eps, ro);
+    diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, [&] { return eps; }, ro);
     const float uds_w = wave_sum(ro.uds);
     if (lane == 0) { red[16 + wid] = active ? ro.lse : 0.f; red[32 + wid] = uds_w; }
   }

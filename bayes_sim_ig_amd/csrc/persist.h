@@ -36,4 +36,8 @@ int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes
 int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyper& h, int n,
                 hipStream_t st);
 
+// diagnostics: [256][8][16] int64 wall-clock stamps of the first 8 updates of every
+// following launch (null: off)
+void persist_set_profile_buffer(void* buf);
+
 }  // namespace bsig

@@ -267,6 +267,11 @@ int bsig_fit_grad(bsig_fit_plan* plan, bsig_stream_t stream);
 int bsig_fit_apply(bsig_fit_plan* plan, bsig_stream_t stream);
 int bsig_fit_eval(bsig_fit_plan* plan, bsig_stream_t stream);
 
+/* Diagnostics: device buffer of [256][8][16] int64 wall-clock stamps filled by the
+ * persistent update kernel (first 8 updates of every later launch); NULL = off.
+ * tools/persist_prof.py prints the phase breakdown. */
+void bsig_debug_persist_profile(void* device_buffer);
+
 #ifdef __cplusplus
 }
 #endif

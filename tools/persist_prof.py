@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the persistent update kernel (fit_persistent.hip) from its
+wall-clock stamps (bsig_debug_persist_profile): one cfg5-shaped chunk."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                     # noqa: E402
+import bayes_sim_ig_amd as B     # noqa: E402
+
+B.MDNN.VERBOSE = False
+dev = 'cuda:0'
+lib = B._lib.require_gpu()
+lib.bsig_debug_persist_profile.restype = None
+lib.bsig_debug_persist_profile.argtypes = [C.c_void_p]
+name = sys.argv[1] if len(sys.argv) > 1 else 'cfg5'
+cfg = dict(bench.CONFIGS[name])
+theta, states, actions = bench.synth_pairs(cfg, 1000, 3, dev)
+bs = bench.build_gpu_model(B, cfg, dev, 77)
+summ = bs._summarize(states, actions)
+bs.model.run_training(summ, theta, 100, 100)          # warm-up (plan, graphs)
+buf = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
+lib.bsig_debug_persist_profile(buf.data_ptr())
+bs.model.run_training(summ, theta, 100, 100)
+torch.cuda.synchronize()
+lib.bsig_debug_persist_profile(None)
+st = buf.cpu().numpy().reshape(256, 8, 16).astype(np.float64) / 100.0   # 100 MHz -> us
+live = [g for g in range(256) if st[g, 1, 0] > 0]
+owners = [g for g in live if st[g, 1, 4] > 0]
+tiles = [g for g in live if st[g, 1, 4] == 0]
+print('%s: %d tile workgroups + %d row owners; updates 1..7 of the last launch' % (name, len(tiles), len(owners)))
+for g in (tiles[0], tiles[-1]):
+    print('tile wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
+    for n, a, b in (('feat tile -> LDS', 0, 1), ('fwd mfma', 1, 2), ('slab store+flag', 2, 3),
+                    ('wait for owners', 3, 10), ('dO^T load', 10, 11), ('dW mfma+adam', 11, 12)):
+        print('    %-18s %6.2f us' % (n, (st[g, 1:8, b] - st[g, 1:8, a]).mean()))
+for g in (owners[0], owners[-1]):
+    print('owner wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
+    for n, a, b in (('y + wait fwd flags', 0, 4), ('slab sum', 4, 5), ('row: pre-eps part', 5, 6),
+                    ('eps gather + row', 6, 7), ('dO/E store+publish', 7, 9)):
+        print('    %-18s %6.2f us' % (n, (st[g, 1:8, b] - st[g, 1:8, a]).mean()))
+    print('    %-18s %6.2f us' % ('idle until next', (st[g, 2:8, 0] - st[g, 1:7, 9]).mean()))
