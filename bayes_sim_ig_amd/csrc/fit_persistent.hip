@@ -273,7 +273,8 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
         const float v = Vr[i] * b2f + ob2 * g * g;
         Mr[i] = m; Vr[i] = v;
         float* wp = Wl + acc_row(i, h_l) * kPitch + kcol_l;
-        *wp = *wp - a0 * (m / (sqrtf(v) * a1 + p.adam_eps));
+        // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences
+        *wp = *wp - a0 * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * a1 + p.adam_eps));
       }
     }
     __syncthreads();

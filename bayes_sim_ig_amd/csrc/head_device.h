@@ -86,15 +86,20 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
       if (jitter) eu[q] = a.noise ? a.noise[((int64_t)row * D + d) * K + k] : u01(ph.v[q & 3]);
     }
   }
-  // mixture weights (every lane, redundantly: K is small)
-  float mx = 0.f, den = 1.f, csum = 1.f;
+  // mixture weights (mdnn.py:109-111): lane j < K owns component j, the sums over
+  // the components are wavefront reductions
+  const bool comp = active && lane < K;
+  float s_own = 0.f, w_own = 0.f, csum = 1.f;
   if (active && !a.from_tuple) {
-    mx = tile[0];
+    float mx = tile[0];
     for (int j = 1; j < K; ++j) mx = fmaxf(mx, tile[j]);
-    den = 0.f;
-    for (int j = 0; j < K; ++j) den += expf(tile[j] - mx);
-    csum = 0.f;
-    for (int j = 0; j < K; ++j) csum += fminf(fmaxf(expf(tile[j] - mx) / den, a.min_w), 1.0f);
+    const float e_own = comp ? expf(tile[lane] - mx) : 0.f;
+    s_own = e_own / wave_sum(e_own);
+    const float c_own = comp ? fminf(fmaxf(s_own, a.min_w), 1.0f) : 0.f;
+    csum = wave_sum(c_own);
+    w_own = c_own / csum;
+  } else if (comp) {
+    w_own = tile[lane];
   }
   const float eps = eps_fn();
 #pragma unroll
@@ -124,10 +129,9 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
       if (d0 + off < groups && lane + off * K < 64) { quad += tq; logdet += tl; }
     }
   }
-  if (active && lane < K) {
+  if (comp) {
     const float logp = -0.5f * quad - logdet - (float)D * kHalfLog2Pi;
-    const float w = a.from_tuple ? tile[lane]
-                                 : fminf(fmaxf(expf(tile[lane] - mx) / den, a.min_w), 1.0f) / csum;
+    const float w = w_own;
     const float lp = fminf(fmaxf(logp, -a.ll_limit), a.ll_limit);
     const float rv = lp + logf(fminf(fmaxf(w, a.min_w), 1.0f));
     bad |= !(isfinite(w) && isfinite(logp) && isfinite(rv));
@@ -161,34 +165,20 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
       }
     }
   }
-  if (bwd && active && lane < K) {          // mixture-weight path, lane = component
-    float dlogit;
-    if (a.from_tuple) {
-      const float w = tile[lane];
+  if (bwd && active) {                      // mixture-weight path, lane = component
+    float gw = 0.f;
+    if (comp) {
       const float sc = -expf(rk[lane] - lse) * a.inv_norm;
-      dlogit = (w >= a.min_w && w <= 1.0f) ? sc / fminf(fmaxf(w, a.min_w), 1.0f) : 0.f;
-    } else {
-      float s1 = 0.f;
-      for (int j = 0; j < K; ++j) {
-        const float sj = expf(tile[j] - mx) / den;
-        const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
-        const float scj = -expf(rk[j] - lse) * a.inv_norm;
-        const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / fminf(fmaxf(wj, a.min_w), 1.0f) : 0.f;
-        s1 += gwj * wj;
-      }
-      float s2 = 0.f, gs_k = 0.f, s_k = 0.f;
-      for (int j = 0; j < K; ++j) {
-        const float sj = expf(tile[j] - mx) / den;
-        const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
-        const float scj = -expf(rk[j] - lse) * a.inv_norm;
-        const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / fminf(fmaxf(wj, a.min_w), 1.0f) : 0.f;
-        const float gsj = (sj >= a.min_w && sj <= 1.0f) ? (gwj - s1) / csum : 0.f;
-        s2 += gsj * sj;
-        if (j == lane) { gs_k = gsj; s_k = sj; }
-      }
-      dlogit = s_k * (gs_k - s2);
+      gw = (w_own >= a.min_w && w_own <= 1.0f) ? sc / fminf(fmaxf(w_own, a.min_w), 1.0f) : 0.f;
     }
-    dlg[lane] = dlogit;                     // separate slot: the logits stay readable
+    float dlogit = gw;
+    if (!a.from_tuple) {                    // through the renormalisation, the clamp, the softmax
+      const float s1 = wave_sum(gw * w_own);
+      const float gs = (comp && s_own >= a.min_w && s_own <= 1.0f) ? (gw - s1) / csum : 0.f;
+      const float s2 = wave_sum(gs * s_own);
+      dlogit = s_own * (gs - s2);
+    }
+    if (comp) dlg[lane] = dlogit;           // separate slot: the logits stay readable
   }
   __builtin_amdgcn_wave_barrier();
   out.lse = lse; out.uds = uds; out.bad = bad;
