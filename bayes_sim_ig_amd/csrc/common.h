@@ -64,6 +64,23 @@ __device__ inline float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// Same sum through the DPP row shifts / broadcasts of GFX9 (no LDS crossbar
+// round trips): inclusive scan inside the rows of 16, then row 0 -> 1, 2 -> 3,
+// rows 0-1 -> 2-3; lane 63 holds the total.  Deterministic, but a different
+// association than wave_sum.
+__device__ inline float wave_sum_dpp(float v) {
+#define BSIG_DPP_ADD(ctrl, row_mask)                                                        \
+  v += __builtin_bit_cast(                                                                  \
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+  BSIG_DPP_ADD(0x111, 0xf);   // row_shr:1
+  BSIG_DPP_ADD(0x112, 0xf);   // row_shr:2
+  BSIG_DPP_ADD(0x114, 0xf);   // row_shr:4
+  BSIG_DPP_ADD(0x118, 0xf);   // row_shr:8
+  BSIG_DPP_ADD(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+  BSIG_DPP_ADD(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef BSIG_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ inline float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

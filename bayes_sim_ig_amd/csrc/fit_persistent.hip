@@ -242,14 +242,12 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     }
     __syncthreads();
     BSIG_STAMP(11);
-    if (ks == 0 && tid_l < kNB) {            // biases of this block: column sums of d_out
+    float* bpart = X + kNB * DOP;          // [16][32] partial column sums (k-slice 0)
+    if (ks == 0) {                         // biases of this block: column sums of d_out
+      const int n = tid_l & 31, part = tid_l >> 5;
       float g = 0.f;
-      for (int b = 0; b < B; ++b) g += X[tid_l * DOP + b];
-      const float bm = biasl[32 + tid_l] + (g - biasl[32 + tid_l]) * ob1;
-      const float bv = biasl[64 + tid_l] * b2f + ob2 * g * g;
-      biasl[32 + tid_l] = bm;
-      biasl[64 + tid_l] = bv;
-      biasl[tid_l] = biasl[tid_l] - a0 * (bm / (sqrtf(bv) * a1 + p.adam_eps));
+      for (int b = part; b < B; b += kPT / 32) g += X[n * DOP + b];
+      bpart[part * 32 + n] = g;
     }
     {
       f32x16 acc;
@@ -275,6 +273,19 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
         float* wp = Wl + acc_row(i, h_l) * kPitch + kcol_l;
         // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences
         *wp = *wp - a0 * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * a1 + p.adam_eps));
+      }
+    }
+    if (ks == 0) {
+      __syncthreads();
+      if (tid_l < kNB) {
+        float g = 0.f;
+#pragma unroll
+        for (int q = 0; q < kPT / 32; ++q) g += bpart[q * 32 + tid_l];
+        const float bm = biasl[32 + tid_l] + (g - biasl[32 + tid_l]) * ob1;
+        const float bv = biasl[64 + tid_l] * b2f + ob2 * g * g;
+        biasl[32 + tid_l] = bm;
+        biasl[64 + tid_l] = bv;
+        biasl[tid_l] = biasl[tid_l] - a0 * (bm / (sqrtf(bv) * a1 + p.adam_eps));
       }
     }
     __syncthreads();
@@ -365,7 +376,7 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
       X[r * per_wave + col] = v;
       if (col >= K + DK && col < K + 2 * DK) eacc += expf(v);
     }
-    eacc = wave_sum(eacc);
+    eacc = wave_sum_dpp(eacc);
     if (lane == 0) red[w] = eacc;
     __syncthreads();
     if (tid == 0) {
@@ -389,7 +400,7 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
                             : 0.f;
                },
                ro);
-      uds_w = wave_sum(ro.uds);
+      uds_w = wave_sum_dpp(ro.uds);
       if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
       BSIG_STAMP(7);
       if (active) {
@@ -461,7 +472,7 @@ static bool persist_geom(const PersistShape& s, PersistGeom* g) {
   if (g->R > kPT / 64) return false;
   g->n_owner = ceil_div(s.batch, g->R);
   const int per_wave = g->Nh + s.out_dim + 3 * s.n_comp;
-  g->x_floats = (int)round_up(std::max(std::max(128 * kPbufPitch, kNB * (g->FR + 4)),
+  g->x_floats = (int)round_up(std::max(std::max(128 * kPbufPitch, kNB * (g->FR + 4) + (kPT / 32) * 32),
                                        (kPT / 64) * per_wave), 4);
   g->lds = ((size_t)g->FR * kPitch + (size_t)kNB * kPitch + g->x_floats + 64 + 96) * sizeof(float);
   // the forward reads feature rows up to 127 (results of rows >= batch are dropped)

@@ -94,9 +94,9 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
     float mx = tile[0];
     for (int j = 1; j < K; ++j) mx = fmaxf(mx, tile[j]);
     const float e_own = comp ? expf(tile[lane] - mx) : 0.f;
-    s_own = e_own / wave_sum(e_own);
+    s_own = e_own / wave_sum_dpp(e_own);
     const float c_own = comp ? fminf(fmaxf(s_own, a.min_w), 1.0f) : 0.f;
-    csum = wave_sum(c_own);
+    csum = wave_sum_dpp(c_own);
     w_own = c_own / csum;
   } else if (comp) {
     w_own = tile[lane];
@@ -173,9 +173,9 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
     }
     float dlogit = gw;
     if (!a.from_tuple) {                    // through the renormalisation, the clamp, the softmax
-      const float s1 = wave_sum(gw * w_own);
+      const float s1 = wave_sum_dpp(gw * w_own);
       const float gs = (comp && s_own >= a.min_w && s_own <= 1.0f) ? (gw - s1) / csum : 0.f;
-      const float s2 = wave_sum(gs * s_own);
+      const float s2 = wave_sum_dpp(gs * s_own);
       dlogit = s_own * (gs - s2);
     }
     if (comp) dlg[lane] = dlogit;           // separate slot: the logits stay readable
@@ -216,7 +216,7 @@ __device__ inline float granule_gather(unsigned long long* g, int G, uint32_t ta
     }
     __builtin_amdgcn_s_sleep(1);
   }
-  return (wave_sum(v[0]) + wave_sum(v[1])) + (wave_sum(v[2]) + wave_sum(v[3]));
+  return (wave_sum_dpp(v[0]) + wave_sum_dpp(v[1])) + (wave_sum_dpp(v[2]) + wave_sum_dpp(v[3]));
 }
 
 // wait until flags[0..G) >= epoch (G <= 256; one wavefront polls)
