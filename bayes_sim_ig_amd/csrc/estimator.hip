@@ -359,8 +359,9 @@ struct bsig_fit_plan {
   bsig_mdn_cfg cfg;
   Layout L;
   int64_t batch, max_test, n_updates, n_evals;
-  bool hoist;                  // RFF projection of every minibatch up front
-  int64_t feat_rows;           // n_updates*batch + n_evals*max_test
+  bool hoist;                  // RFF projection once per run_training call
+  bool feat_unique;            // ... of the distinct training rows (else of every gathered minibatch row)
+  int64_t feat_rows;           // n_updates*batch + max_test
   bsig_fit_buffers buf;
   bool bound;
   int64_t norm_batch;
@@ -404,6 +405,7 @@ static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st) {
   const bsig_fit_buffers& b = p->buf;
   PersistBuffers pb;
   pb.feats = m.feats; pb.ld_feats = p->cfg.rff_feats;
+  pb.feat_ids = p->feat_unique ? b.ids_table : nullptr;
   pb.y = b.y_train; pb.ldy = b.ldy_train; pb.ids = b.ids_table;
   pb.params = b.params; pb.exp_avg = b.exp_avg; pb.exp_avg_sq = b.exp_avg_sq;
   pb.w_off = p->L.head_w_off; pb.b_off = p->L.head_b_off;
@@ -422,7 +424,10 @@ static Inputs train_inputs(const bsig_fit_plan* p, const PlanMem& m) {
   Inputs in;
   in.dyn = b.state + ST_STEP; in.dyn_stride = p->batch;
   in.rff_coeff = b.rff_coeff; in.ld_coeff = b.ld_coeff; in.rff_offset = b.rff_offset;
-  if (p->hoist) { in.x = m.feats; in.ldx = p->cfg.rff_feats; in.is_feat = true; }
+  if (p->hoist) {
+    in.x = m.feats; in.ldx = p->cfg.rff_feats; in.is_feat = true;
+    if (p->feat_unique) in.rows = b.ids_table;   // feature cache: one row per training row
+  }
   else { in.x = b.x_train; in.ldx = b.ldx_train; in.rows = b.ids_table; }
   return in;
 }
@@ -433,7 +438,9 @@ static Inputs eval_inputs(const bsig_fit_plan* p, const PlanMem& m) {
   in.rff_coeff = b.rff_coeff; in.ld_coeff = b.ld_coeff; in.rff_offset = b.rff_offset;
   if (p->hoist) {
     in.x = m.feats; in.ldx = p->cfg.rff_feats; in.is_feat = true;
-    in.dyn = b.state + ST_EVAL; in.dyn_stride = b.n_test; in.dyn_base = p->n_updates * p->batch;
+    // the held-out rows are the same at every evaluation: projected once
+    in.dyn = b.state + ST_EVAL; in.dyn_stride = 0;
+    in.dyn_base = p->feat_unique ? b.n_train : p->n_updates * p->batch;
   } else {
     in.x = b.x_test; in.ldx = b.ldx_test;
   }
@@ -507,19 +514,17 @@ static int enqueue_hoisted_rff(bsig_fit_plan* p, hipStream_t st) {
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
   Inputs in;
-  in.x = b.x_train; in.ldx = b.ldx_train; in.rows = b.ids_table;
+  in.x = b.x_train; in.ldx = b.ldx_train;
   in.rff_coeff = b.rff_coeff; in.ld_coeff = b.ld_coeff; in.rff_offset = b.rff_offset;
-  BSIG_TRY(rff_project(&p->cfg, in, p->n_updates * p->batch, m.feats, m.big_ws,
-                       p->big_gemm_ws_bytes, st));
+  // feature cache: each distinct training row once (it is visited ~n_updates*batch/n_train
+  // times); when that does not fit the plan's buffer, every gathered minibatch row
+  const int64_t train_rows = p->feat_unique ? b.n_train : p->n_updates * p->batch;
+  if (!p->feat_unique) in.rows = b.ids_table;
+  BSIG_TRY(rff_project(&p->cfg, in, train_rows, m.feats, m.big_ws, p->big_gemm_ws_bytes, st));
   if (b.n_test > 0) {
-    const int n = (int)(p->n_evals * b.n_test);
-    hipLaunchKernelGGL(iota_mod_kernel, dim3(std::min(ceil_div(n, 256), 256)), dim3(256), 0, st,
-                       m.iota, n, (int)b.n_test);
-    BSIG_CHECK_LAUNCH("iota_mod");
-    in.x = b.x_test; in.ldx = b.ldx_test; in.rows = m.iota;
-    BSIG_TRY(rff_project(&p->cfg, in, n,
-                         m.feats + (size_t)p->n_updates * p->batch * p->cfg.rff_feats, m.big_ws,
-                         p->big_gemm_ws_bytes, st));
+    in.x = b.x_test; in.ldx = b.ldx_test; in.rows = nullptr;
+    BSIG_TRY(rff_project(&p->cfg, in, b.n_test, m.feats + (size_t)train_rows * p->cfg.rff_feats,
+                         m.big_ws, p->big_gemm_ws_bytes, st));
   }
   return BSIG_OK;
 }
@@ -656,7 +661,7 @@ extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t m
   carve(cfg, p->L, batch, nullptr, &s); p->train_ws_bytes = s.total_bytes;
   carve(cfg, p->L, std::max<int64_t>(max_test_rows, 1), nullptr, &s);
   p->test_ws_bytes = s.total_bytes;
-  p->feat_rows = n_updates * batch + p->n_evals * max_test_rows;
+  p->feat_rows = n_updates * batch + max_test_rows;
   const size_t feats = (size_t)p->feat_rows * (size_t)std::max(cfg->rff_feats, 0) * sizeof(float);
   const char* no_hoist = getenv("BSIG_NO_RFF_HOIST");
   p->hoist = cfg->rff_feats > 0 && n_updates > 0 && feats <= ((size_t)4 << 30) &&
@@ -675,9 +680,8 @@ extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t m
     const int64_t mf = cfg->rff_cos_only ? cfg->rff_feats : cfg->rff_feats / 2;
     p->big_gemm_ws_bytes = round_up<size_t>(
         std::max(bsig_gemm_workspace_bytes(n_updates * batch, mf, cfg->input_dim),
-                 bsig_gemm_workspace_bytes(std::max<int64_t>(p->n_evals * max_test_rows, 1), mf,
+                 bsig_gemm_workspace_bytes(std::max<int64_t>(max_test_rows, 1), mf,
                                            cfg->input_dim)) + 256, 256);
-    p->iota_bytes = round_up<size_t>((size_t)(p->n_evals * max_test_rows + 1) * sizeof(int32_t), 256);
   }
   *plan = p;
   return BSIG_OK;
@@ -713,6 +717,9 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
   if (!same) {
     drop_graphs(p);
     p->buf = *b;
+    const char* no_cache = getenv("BSIG_NO_FEAT_CACHE");
+    p->feat_unique = p->hoist && b->n_train <= p->n_updates * p->batch &&
+                     !(no_cache && no_cache[0] == '1');
     p->bound = true;
     p->use_graph = graph;
     p->split_adam = split;

@@ -50,7 +50,7 @@ struct PersistArgs {
   int B, FR, Fdim, Nh, NhP, D, K;
   int n_blocks, k_slices, G, n_owner, R;
   int n_updates, x_floats;
-  const float* feats; int64_t ld_feats;
+  const float* feats; int64_t ld_feats; const int32_t* feat_ids;
   const float* y; int64_t ldy; const int32_t* ids;
   float* params; float* m1; float* m2; int64_t w_off, b_off;
   int32_t* state; float* train_loss;
@@ -84,8 +84,9 @@ __device__ __forceinline__ bool run_aborted(int32_t* flagp, float* red, int tid)
 #define BSIG_PF_LOAD(u)                                                                   \
   {                                                                                       \
     const int idx = min((u) * kPT + tid, nvec - 1);                                       \
-    pf##u = *reinterpret_cast<const float4*>(src + (int64_t)(idx >> 6) * p.ld_feats +     \
-                                             (idx & 63) * 4);                             \
+    const int64_t r = pf_row0 + (idx >> 6);                                               \
+    const int64_t fr = p.feat_ids ? (int64_t)p.feat_ids[r] : r;                           \
+    pf##u = *reinterpret_cast<const float4*>(p.feats + fr * p.ld_feats + k0 + (idx & 63) * 4); \
   }
 #define BSIG_PF_STORE(u)                                                                  \
   {                                                                                       \
@@ -141,7 +142,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
   // feature tile of the first update (later ones are fetched during the waits)
   BSIG_PF_LIST(BSIG_PF_DECL)
   {
-    const float* src = p.feats + (int64_t)step0 * B * p.ld_feats + k0;
+    const int64_t pf_row0 = (int64_t)step0 * B;
     BSIG_PF_LIST(BSIG_PF_LOAD)
   }
   __syncthreads();
@@ -202,7 +203,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
 
     // ---- while the row owners work: next feature tile, Adam scalars -----------
     if (t + 1 < p.n_updates) {
-      const float* src = p.feats + (int64_t)(step + 1) * B * p.ld_feats + k0;
+      const int64_t pf_row0 = (int64_t)(step + 1) * B;
       BSIG_PF_LIST(BSIG_PF_LOAD)
     }
     b1t *= p.beta1; b2t *= p.beta2;      // beta^t as running products (double)
@@ -532,7 +533,7 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.D = s.out_dim; p.K = s.n_comp;
   p.n_blocks = g.n_blocks; p.k_slices = g.k_slices; p.G = g.G; p.n_owner = g.n_owner; p.R = g.R;
   p.n_updates = n; p.x_floats = g.x_floats;
-  p.feats = b.feats; p.ld_feats = b.ld_feats; p.y = b.y; p.ldy = b.ldy; p.ids = b.ids;
+  p.feats = b.feats; p.ld_feats = b.ld_feats; p.feat_ids = b.feat_ids; p.y = b.y; p.ldy = b.ldy; p.ids = b.ids;
   p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq; p.w_off = b.w_off; p.b_off = b.b_off;
   p.state = b.state; p.train_loss = b.train_loss;
   p.lr = hy.lr; p.beta1 = hy.beta1; p.beta2 = hy.beta2;

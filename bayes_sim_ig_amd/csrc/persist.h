@@ -11,7 +11,9 @@ struct PersistShape {
 };
 
 struct PersistBuffers {
-  const float* feats; int64_t ld_feats;   // row (step*batch + i) = features of minibatch row i
+  const float* feats; int64_t ld_feats;   // feature rows
+  const int32_t* feat_ids;                // minibatch row i of update `step` = feats[feat_ids[step*batch+i]]
+                                          // (null: feats[step*batch + i])
   const float* y; int64_t ldy;            // targets, gathered through ids
   const int32_t* ids;                     // [n_updates*batch] minibatch row ids
   float* params; float* exp_avg; float* exp_avg_sq;   // flat buffers
