@@ -770,28 +770,12 @@ extern "C" int bsig_fit_eval(bsig_fit_plan* p, bsig_stream_t stream) {
   return enqueue_eval(p, as_stream(stream));
 }
 
-extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t stream) {
-  BSIG_REQUIRE(p && p->bound, "fit_run: plan not bound");
-  BSIG_REQUIRE(n_updates >= 0 && n_updates <= p->n_updates,
-               "fit_run: n_updates %lld exceeds the plan's %lld", (long long)n_updates,
-               (long long)p->n_updates);
-  hipStream_t st = as_stream(stream);
-  if (p->use_graph) BSIG_TRY(ensure_graphs(p));
-  const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
-  if (p->persistent && !p->split_adam) {
-    // runs of updates between two held-out evaluations: one launch each
-    int64_t done = 0;
-    for (int64_t it = 0; it < n_updates; ++it) {
-      if (it % every == 0 || it + 1 == n_updates) {
-        BSIG_TRY(enqueue_persistent(p, (int)(it + 1 - done), st));
-        done = it + 1;
-        if (p->use_graph) BSIG_HIP(hipGraphLaunch(p->g_eval, st));
-        else BSIG_TRY(enqueue_eval(p, st));
-      }
-    }
-    return BSIG_OK;
-  }
-  for (int64_t it = 0; it < n_updates; ++it) {
+// n consecutive updates, no evaluation: one launch of the persistent kernel when
+// the plan is covered by it, else n replays of the update graph
+static int enqueue_updates(bsig_fit_plan* p, int64_t n, hipStream_t st) {
+  if (n <= 0) return BSIG_OK;
+  if (p->persistent && !p->split_adam) return enqueue_persistent(p, (int)n, st);
+  for (int64_t it = 0; it < n; ++it) {
     if (p->use_graph) {
       if (p->split_adam) {
         BSIG_HIP(hipGraphLaunch(p->g_grad, st));
@@ -803,7 +787,32 @@ extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t s
       BSIG_TRY(enqueue_grad(p, st, !p->split_adam));
       if (p->split_adam) BSIG_TRY(enqueue_apply(p, st));
     }
+  }
+  return BSIG_OK;
+}
+
+extern "C" int bsig_fit_updates(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t stream) {
+  BSIG_REQUIRE(p && p->bound, "fit_updates: plan not bound");
+  BSIG_REQUIRE(n_updates >= 0 && n_updates <= p->n_updates,
+               "fit_updates: n_updates %lld exceeds the plan's %lld", (long long)n_updates,
+               (long long)p->n_updates);
+  if (p->use_graph) BSIG_TRY(ensure_graphs(p));
+  return enqueue_updates(p, n_updates, as_stream(stream));
+}
+
+extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t stream) {
+  BSIG_REQUIRE(p && p->bound, "fit_run: plan not bound");
+  BSIG_REQUIRE(n_updates >= 0 && n_updates <= p->n_updates,
+               "fit_run: n_updates %lld exceeds the plan's %lld", (long long)n_updates,
+               (long long)p->n_updates);
+  hipStream_t st = as_stream(stream);
+  if (p->use_graph) BSIG_TRY(ensure_graphs(p));
+  const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
+  int64_t done = 0;
+  for (int64_t it = 0; it < n_updates; ++it) {
     if (it % every == 0 || it + 1 == n_updates) {
+      BSIG_TRY(enqueue_updates(p, it + 1 - done, st));   // the run of updates up to here
+      done = it + 1;
       if (p->use_graph) BSIG_HIP(hipGraphLaunch(p->g_eval, st));
       else BSIG_TRY(enqueue_eval(p, st));
     }

@@ -756,7 +756,7 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
     tiles = ceil_div<int64_t>(m, bm) * ceil_div<int64_t>(n, bn);
   }
   int64_t splits = 1;
-  if (tiles < target) {
+  if (tiles < target && tiles < 256) {   // fewer workgroups than CUs: split K
     splits = ceil_div<int64_t>(target, tiles);
     const int64_t max_by_k = k / (4 * BK) > 0 ? k / (4 * BK) : 1;   // >= PD K steps per block
     if (splits > max_by_k) splits = max_by_k;

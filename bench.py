@@ -204,42 +204,101 @@ def _event_time(fn, reps, warm=5):
     return start.elapsed_time(stop) * 1e3 / reps
 
 
-def time_dominant_kernel(pkg, cfg, bsim, device):
-    """HIP-event timing (torch events on the stream the fit launches on) of the
-    dominant kernel of this workload, launched through the C ABI with the
-    shapes the fit uses.
-      MDRFF: the RFF projection of one run_training call — ONE fp32-MFMA GEMM
-             over the n_updates*B gathered minibatch rows (csrc/estimator.hip
-             hoists it out of the update loop) with the fused cos/sin epilogue.
-      MDNN : the first trunk layer GEMM of one update (gathered minibatch)."""
+def time_update_kernel(pkg, cfg, bsim, device):
+    """MDRFF: HIP-event timing of the dominant kernel of the fit, the persistent
+    update kernel (csrc/fit_persistent.hip) — every launch of one run_training
+    call (runs of 1, 20, 20, 20, 20, 19 updates between the six held-out
+    evaluations), launched through the C ABI (bsig_fit_updates) on the plan the
+    timed fit just used, events on the stream it launches on."""
     lib = pkg._lib.load()
     L = pkg._lib
-    if cfg['model'] == 'MDRFF':
-        rff = bsim.model.rff
-        rows, i, mf = 100 * 100, rff.d, rff.m_feat
-        x = torch.randn(1000, L.round_up(i, 4), device=device)
-        ids = torch.randint(0, 800, (rows,), device=device, dtype=torch.int32)
+    m = bsim.model
+    plan = m._plan
+    st = L.stream()
+    stream = torch.cuda.current_stream()
+    n_updates, batch = 100, 100
+    every = max(n_updates // 5, 1)
+    runs, done = [], 0
+    for it in range(n_updates):
+        if it % every == 0 or it + 1 == n_updates:
+            runs.append(it + 1 - done)
+            done = it + 1
+    total_ms, launches = 0.0, 0
+    for rep in range(6):
+        L.check(lib.bsig_fit_begin(plan, 1234 + rep, batch, st))
+        evs = []
+        for n in runs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            L.check(lib.bsig_fit_updates(plan, n, st))
+            e1.record(stream)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        if rep == 0:
+            continue                                  # warm-up
+        total_ms += sum(a.elapsed_time(b) for a, b in evs)
+        launches += len(evs)
+    us = total_ms * 1e3 / launches
+    f_in, nh = m.input_dim if cfg['model'] != 'MDRFF' else m.rff.m_feat * 2, \
+        cfg['k'] * (1 + 2 * cfg['d'])
+    per_visit = 2.0 * 2.0 * f_in * nh                 # SURVEY 8(d) K6+K7, MDRFF heads: fwd + dW
+    flops = per_visit * batch * (float(n_updates) / len(runs))
+    ach = flops / (us * 1e-6) / 1e12
+    traffic, tsrc = pmc_traffic('linear_head_updates_kernel')
+    return {'bound': 'mfma',
+            'kernel': 'linear_head_updates_kernel: persistent update kernel, heads %dx%d on cached '
+                      'RFF features, minibatch %d, %s updates per launch (mean %.1f): forward '
+                      'product, NLL fwd/bwd, dW, Adam' % (nh, f_in, batch,
+                                                          '/'.join(str(r) for r in runs),
+                                                          float(n_updates) / len(runs)),
+            'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
+            'traffic': traffic, 'traffic_source': tsrc, 'avg_us': us,
+            'us_per_update': us * len(runs) / n_updates,
+            'algorithmic': '2*2*F*Nh = %.3e flop per row visit x %d rows x %.1f updates = %.3e flop '
+                           'per launch' % (per_visit, batch, float(n_updates) / len(runs), flops),
+            'note': 'latency-bound by design of the reference protocol (minibatch 100): each update '
+                    'is a chain of 4 cross-workgroup hand-offs (~1.5-3 us each) around ~6 us of '
+                    'fp32-MFMA work per CU; see DESIGN.md and scaled_batch_mode for the MFMA-bound regime'}
+
+
+def time_rff_kernel(pkg, cfg, bsim, device):
+    """Secondary: the RFF projection of one run_training call — ONE fp32-MFMA GEMM
+    over the distinct training rows of the chunk (feature cache) with the fused
+    cos/sin epilogue; also at the 10000-row shape of the scaled/gathered mode."""
+    lib = pkg._lib.load()
+    L = pkg._lib
+    rff = bsim.model.rff
+    out = {}
+    for tag, rows in (('chunk', 800), ('rows10k', 100 * 100)):
+        i, mf = rff.d, rff.m_feat
+        x = torch.randn(max(rows, 1000), L.round_up(i, 4), device=device)
         co = rff.coeff()
         feats = torch.empty(rows, 2 * mf, device=device)
         ws = torch.empty(int(lib.bsig_gemm_workspace_bytes(rows, mf, i)) // 4 + 1, device=device)
 
         def launch():
             L.check(lib.bsig_rff_project(
-                L.ptr(x), x.stride(0), L.ptr(ids), L.ptr(co), co.stride(0), None, L.ptr(feats),
+                L.ptr(x), x.stride(0), None, L.ptr(co), co.stride(0), None, L.ptr(feats),
                 feats.stride(0), rows, i, mf, float(rff.a), 0, L.ptr(ws), ws.numel() * 4,
                 L.stream()))
         us = _event_time(launch, 20)
         flops = 2.0 * rows * i * mf
         ach = flops / (us * 1e-6) / 1e12
-        traffic, tsrc = pmc_traffic('gemm_mfma_kernel<2, 2, 2, 2, false, false, 4, 4>')
-        return {'bound': 'mfma',
-                'kernel': 'gemm_mfma_kernel<2,2,2,2> RFF projection %dx%dx%d (all minibatch rows '
-                          'of one run_training call, gathered) + fused cos/sin epilogue'
-                          % (rows, mf, i),
-                'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
-                'avg_us': us, 'algorithmic': '2*rows*I*M = %.3e flop per launch; %.3e B '
-                '(4(I+2M) per row + coefficients)' % (flops, 4.0 * rows * (i + 2 * mf) + 4.0 * mf * i)}
+        out[tag] = {'shape': '%dx%dx%d' % (rows, mf, i), 'avg_us': us, 'achieved': ach,
+                    'frac': ach / PEAK_F32_TFLOPS}
+    traffic, tsrc = pmc_traffic('gemm_mfma_kernel<2, 2, 2, 2, false, false, 4, 4>')
+    return {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel RFF projection + fused cos/sin epilogue',
+            'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'per_chunk_launch': out['chunk'],
+            'large_launch': out['rows10k']}
+
+
+def time_dominant_kernel(pkg, cfg, bsim, device):
+    """MDRFF: the persistent update kernel (time_update_kernel).
+    MDNN : the first trunk layer GEMM of one update (gathered minibatch)."""
+    lib = pkg._lib.load()
+    L = pkg._lib
+    if cfg['model'] == 'MDRFF':
+        return time_update_kernel(pkg, cfg, bsim, device)
     m = bsim.model
     b, i, h0 = 100, m.input_dim, m._hidden[0]
     x = torch.randn(1000, L.round_up(i, 4), device=device)
@@ -413,6 +472,8 @@ def main():
         note('timed region done: %.3f s' % dt)
         out['roofline'] = time_dominant_kernel(pkg, cfg, bsim, device)
         out['roofline_summarizer'] = summarizer_roofline(pkg, cfg, bsim, min(n, 50000), device)
+        if cfg['model'] == 'MDRFF':
+            out['roofline_rff'] = time_rff_kernel(pkg, cfg, bsim, device)
         note('roofline done')
         if world == 1:
             out['nll_match'] = nll_check(pkg, cfg, theta, states, actions, device)

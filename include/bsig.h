@@ -261,6 +261,12 @@ int bsig_fit_begin(bsig_fit_plan* plan, uint64_t seed, int64_t norm_batch,
 /* n_updates SGD updates with a held-out evaluation every max(n_updates/5,1)
  * updates and after the last (mdnn.py:235-242). */
 int bsig_fit_run(bsig_fit_plan* plan, int64_t n_updates, bsig_stream_t stream);
+/* n_updates consecutive SGD updates (mdnn.py:219-233) without evaluation: ONE
+ * launch of the persistent update kernel when the plan is covered by it (linear
+ * heads on cached RFF features, diagonal covariance, single rank), else
+ * n_updates replays of the update graph.  bsig_fit_run = runs of these between
+ * the held-out evaluations. */
+int bsig_fit_updates(bsig_fit_plan* plan, int64_t n_updates, bsig_stream_t stream);
 /* Data-parallel pieces (BSIG_FIT_SPLIT_ADAM): gradient only (all-reduce
  * `grads` outside), then the flat Adam step. */
 int bsig_fit_grad(bsig_fit_plan* plan, bsig_stream_t stream);
