@@ -1,0 +1,172 @@
+"""The persistent update kernel (csrc/fit_persistent.hip) and the feature cache:
+parity with the oracle (teacher-forced chunks, full weight vectors), with the
+one-kernel-per-phase path it replaces, and across the launch schedule."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def B():
+    import bayes_sim_ig_amd as pkg
+    pkg._lib.require_gpu()
+    pkg.MDNN.VERBOSE = False
+    return pkg
+
+
+@pytest.fixture(autouse=True)
+def _guards():
+    import bayes_sim_ig_amd as pkg
+    old = pkg.MDNN.EPS_NOISE
+    yield
+    pkg.MDNN.EPS_NOISE = old
+    pkg.MDNN.USE_GRAPH = True
+    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_FEAT_CACHE'):
+        os.environ.pop(k, None)
+
+
+def _cfg(d, k, n_feat, sd=5, ad=2):
+    return dict(task='synthetic', model='MDRFF', summarizer='summary_start', t=11, sd=sd, ad=ad,
+                d=d, k=k, hidden=[], n_feat=n_feat, pairs=1000)
+
+
+def _chunk(B, cfg, n=1000, batch=100, n_updates=100, seed=3, eps=None, env=None):
+    """One teacher-forced chunk on a freshly built model -> (logs, flat weights, model)."""
+    import bench
+    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_FEAT_CACHE'):
+        os.environ.pop(k, None)
+    os.environ.update(env or {})
+    if eps is not None:
+        B.MDNN.EPS_NOISE = eps
+    theta, states, actions = bench.synth_pairs(cfg, n, seed, DEV)
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    n_train = n - int(n * 0.2)
+    ids = np.random.RandomState(5).randint(0, n_train, (n_updates, batch))
+    summ = bs._summarize(states, actions)
+    logs = bs.model.run_training(summ, theta, n_updates, batch, ids_table=ids)
+    return logs, bs.model._flat.clone(), bs, (theta, states, actions, ids)
+
+
+# (D, K, n_feat): two head blocks x two k-slices; the cfg2 head on 1024 features;
+# 11 head blocks x 16 k-slices (176 tile workgroups: two rows per owner workgroup)
+SHAPES = [(3, 5, 512), (13, 10, 1024), (40, 4, 4096)]
+
+
+@pytest.mark.parametrize('d,k,n_feat', SHAPES)
+def test_persistent_chunk_matches_oracle(B, d, k, n_feat):
+    """Teacher-forced chunk (EPS_NOISE=0, same start weights, same ids) against
+    the fp32 oracle: all 6+6 logged losses within 1e-4 relative (the north-star
+    bound), end weights within 2e-4 absolute of the oracle's."""
+    import bench
+    from oracle import summarize as osum
+    cfg = _cfg(d, k, n_feat)
+    torch.set_num_threads(8)
+    logs, flat, bs, (theta, states, actions, ids) = _chunk(B, cfg, eps=0.0)
+    ora = bench.build_oracle(cfg, bs.model.rff.d, 77, 0.0, freqs=bs.model.rff.freqs.cpu().numpy())
+    bs0 = bench.build_gpu_model(B, cfg, DEV, 77)
+    ora.load_state_dict({kk: v.cpu() for kk, v in bs0.model.state_dict().items()})
+    ora.rff.freqs = bs0.model.rff.freqs.cpu()
+    ref = ora.run_training(osum.SUMMARIZERS['summary_start'](states.cpu(), actions.cpu()),
+                           theta.cpu(), 100, 100, ids_table=ids)
+    for key in ('train_loss', 'test_loss'):
+        got, exp = np.array(logs[key]), np.array(ref[key])
+        assert got.shape == exp.shape == (6,)
+        assert np.all(np.abs(got - exp) <= 1e-4 * np.maximum(np.abs(exp), 1.0)), (key, got, exp)
+    sd = bs.model.state_dict()
+    for name, v in ora.state_dict().items():
+        assert torch.allclose(sd[name].cpu(), v, atol=2e-4, rtol=1e-3), name
+
+
+@pytest.mark.parametrize('eps', [0.0, 1e-5])
+def test_persistent_equals_phase_kernels(B, eps):
+    """Same chunk through the persistent kernel and through the per-phase
+    kernels it replaces (BSIG_NO_PERSISTENT=1): the jitter RNG streams are the
+    same, the arithmetic differs only in summation order."""
+    cfg = _cfg(4, 6, 512)
+    logs_p, flat_p, _, _ = _chunk(B, cfg, eps=eps)
+    logs_k, flat_k, _, _ = _chunk(B, cfg, eps=eps, env={'BSIG_NO_PERSISTENT': '1'})
+    for key in ('train_loss', 'test_loss'):
+        assert np.allclose(logs_p[key], logs_k[key], rtol=2e-5, atol=2e-5), (key, logs_p, logs_k)
+    assert torch.allclose(flat_p, flat_k, atol=5e-5, rtol=1e-3)
+    assert not torch.equal(flat_p, torch.zeros_like(flat_p))
+
+
+def test_feature_cache_is_bitwise_neutral(B):
+    """Projecting each distinct training row once (feature cache) or every
+    gathered minibatch row (BSIG_NO_FEAT_CACHE=1) feeds identical features to
+    identical kernels: logs and weights are bitwise equal."""
+    cfg = _cfg(3, 5, 512)
+    for env in ({}, {'BSIG_NO_PERSISTENT': '1'}):
+        a = _chunk(B, cfg, eps=1e-5, env=dict(env))
+        b = _chunk(B, cfg, eps=1e-5, env=dict(env, BSIG_NO_FEAT_CACHE='1'))
+        assert a[0] == b[0]
+        assert torch.equal(a[1], b[1])
+
+
+def test_persistent_graph_flag_and_rerun_are_bitwise(B):
+    """Evaluations replayed from a graph or launched directly, and a second
+    identical run: bitwise identical (fixed summation orders, no atomics)."""
+    cfg = _cfg(3, 5, 512)
+    out = []
+    for use_graph in (True, False, True):
+        B.MDNN.USE_GRAPH = use_graph
+        out.append(_chunk(B, cfg, eps=1e-5)[:2])
+    for logs, flat in out[1:]:
+        assert logs == out[0][0]
+        assert torch.equal(flat, out[0][1])
+
+
+@pytest.mark.parametrize('n,batch,n_updates', [(1000, 64, 37), (1000, 7, 11), (60, 100, 5), (1000, 104, 20)])
+def test_persistent_ragged_shapes_match_phase_kernels(B, n, batch, n_updates):
+    """Minibatches that are not a multiple of the MFMA tile, a chunk smaller
+    than one minibatch (ids repeat), odd update counts (runs of 1..n between
+    evaluations)."""
+    cfg = _cfg(3, 5, 512)
+    a = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=1e-5)
+    b = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=1e-5,
+               env={'BSIG_NO_PERSISTENT': '1'})
+    for key in ('train_loss', 'test_loss'):
+        assert len(a[0][key]) == len(b[0][key])
+        assert np.allclose(a[0][key], b[0][key], rtol=2e-5, atol=2e-5), (key, a[0], b[0])
+    assert torch.allclose(a[1], b[1], atol=5e-5, rtol=1e-3)
+
+
+def test_fit_updates_entry_point_splits_runs(B):
+    """bsig_fit_updates(5) + bsig_fit_updates(7) == bsig_fit_updates(12):
+    the launch schedule does not change the arithmetic."""
+    L = B._lib
+    lib = L.load()
+    cfg = _cfg(3, 5, 512)
+    _, _, bs, _ = _chunk(B, cfg, eps=1e-5)
+    m = bs.model
+    st = L.stream()
+    res = []
+    for runs in ((12,), (5, 7), (1, 1, 10)):
+        with torch.no_grad():
+            m._flat.copy_(torch.linspace(-0.05, 0.05, m._flat.numel(), device=DEV))
+        L.check(lib.bsig_fit_begin(m._plan, 99, 100, st))
+        for r in runs:
+            L.check(lib.bsig_fit_updates(m._plan, r, st))
+        torch.cuda.synchronize()
+        res.append(m._flat.clone())
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    assert torch.isfinite(res[0]).all()
+
+
+def test_nonfinite_features_raise_through_persistent_path(B):
+    """NaN in a training summary reaches the persistent kernel's finiteness
+    flag -> AssertionError (the reference asserts isfinite, mdnn.py:120-124)."""
+    import bench
+    cfg = _cfg(3, 5, 512)
+    theta, states, actions = bench.synth_pairs(cfg, 1000, 3, DEV)
+    states[5, 0, 0] = float('nan')
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    ids = np.random.RandomState(5).randint(0, 800, (100, 100))
+    ids[0, 0] = 5
+    with pytest.raises(AssertionError):
+        bs.model.run_training(bs._summarize(states, actions), theta, 100, 100, ids_table=ids)
