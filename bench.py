@@ -379,6 +379,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-scaled-batch', action='store_true')
+    ap.add_argument('--variants', action='store_true',
+                    help='also time the fit with the persistent kernel / feature cache / RFF hoist off')
     ap.add_argument('--watchdog', type=int, default=int(os.environ.get('BENCH_WATCHDOG', 1700)),
                     help='dump tracebacks and exit after this many seconds')
     ap.add_argument('--verbose', action='store_true')
@@ -481,22 +483,29 @@ def main():
             if not args.no_scaled_batch:
                 out['scaled_batch_mode'] = scaled_batch(pkg, cfg, theta, states, actions, device)
                 note('scaled batch done')
-            if cfg['model'] == 'MDRFF':
-                # transparency: the same fit with the RFF projection launched inside
-                # every update (one M=100 GEMM per step) instead of hoisted per call
-                os.environ['BSIG_NO_RFF_HOIST'] = '1'
-                try:
-                    b2 = build_gpu_model(pkg, cfg, device, 1234)
-                    np.random.seed(1234)
-                    b2.fit(theta, states, actions)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    b2.fit(theta, states, actions)
-                    torch.cuda.synchronize()
-                    out['rff_in_loop_pairs_per_s'] = n / (time.perf_counter() - t1)
-                finally:
-                    del os.environ['BSIG_NO_RFF_HOIST']
-                note('in-loop RFF variant done')
+            if cfg['model'] == 'MDRFF' and args.variants:
+                # transparency (opt-in, so that a profile of the default run shows the
+                # product path only): the same fit with pieces of the design switched off
+                out['variants_pairs_per_s'] = {}
+                for tag, env in (('phase_kernels_no_persistent', {'BSIG_NO_PERSISTENT': '1'}),
+                                 ('no_feature_cache', {'BSIG_NO_FEAT_CACHE': '1'}),
+                                 ('phase_kernels_no_feature_cache',
+                                  {'BSIG_NO_PERSISTENT': '1', 'BSIG_NO_FEAT_CACHE': '1'}),
+                                 ('rff_inside_every_update', {'BSIG_NO_RFF_HOIST': '1'})):
+                    os.environ.update(env)
+                    try:
+                        b2 = build_gpu_model(pkg, cfg, device, 1234)
+                        np.random.seed(1234)
+                        b2.fit(theta, states, actions)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        b2.fit(theta, states, actions)
+                        torch.cuda.synchronize()
+                        out['variants_pairs_per_s'][tag] = n / (time.perf_counter() - t1)
+                    finally:
+                        for k in env:
+                            del os.environ[k]
+                note('variants done')
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(cfg, theta[:12000], states[:12000],
                                                    actions[:12000])
