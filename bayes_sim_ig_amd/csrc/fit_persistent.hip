@@ -101,6 +101,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
   float* X = Wl + kNB * kPitch;              // scratch: forward k-halves | d_out^T
   float* red = X + p.x_floats;               // [64]
   float* biasl = red + 64;                   // [3][32] bias, exp_avg, exp_avg_sq (k-slice 0)
+  float* bpart = biasl + 96;                 // [16][32] partial column sums of d_out (k-slice 0)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int wg = blockIdx.x, ks = wg % p.k_slices, nb = wg / p.k_slices;
@@ -138,6 +139,20 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
   for (int idx = tid; idx < (p.FR - B) * kPitch; idx += kPT) Fl[B * kPitch + idx] = 0.f;
   const int DOP = p.FR + 4;
   const int nvec = B * (kPC / 4);
+  // The bias step of an update (k-slice 0) is finished off the critical path: by
+  // the otherwise idle lanes of wave 7 during the next forward product, before
+  // the bias is read again (or after the last update).
+  bool bias_pending = false;
+  auto bias_step = [&](int n) {
+    float g = 0.f;
+#pragma unroll
+    for (int q = 0; q < kPT / 32; ++q) g += bpart[q * 32 + n];
+    const float bm = biasl[32 + n] + (g - biasl[32 + n]) * ob1;
+    const float bv = biasl[64 + n] * b2f + ob2 * g * g;
+    biasl[32 + n] = bm;
+    biasl[64 + n] = bv;
+    biasl[n] = biasl[n] - a0 * (bm / (sqrtf(bv) * a1 + p.adam_eps));
+  };
 
   // feature tile of the first update (later ones are fetched during the waits)
   BSIG_PF_LIST(BSIG_PF_DECL)
@@ -183,6 +198,8 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
 #pragma unroll
         for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h_l)) * kPbufPitch + l31_l] = acc[i];
       }
+      if (bias_pending && w == kPT / 64 - 1 && lane < kNB) bias_step(lane);   // a0, a1 of that update
+      bias_pending = false;
       __syncthreads();
       if (kh == 0) {
         const float bias = ks == 0 ? biasl[l31_l] : 0.f;
@@ -243,7 +260,6 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     }
     __syncthreads();
     BSIG_STAMP(11);
-    float* bpart = X + kNB * DOP;          // [16][32] partial column sums (k-slice 0)
     if (ks == 0) {                         // biases of this block: column sums of d_out
       const int n = tid_l & 31, part = tid_l >> 5;
       float g = 0.f;
@@ -276,19 +292,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
         *wp = *wp - a0 * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * a1 + p.adam_eps));
       }
     }
-    if (ks == 0) {
-      __syncthreads();
-      if (tid_l < kNB) {
-        float g = 0.f;
-#pragma unroll
-        for (int q = 0; q < kPT / 32; ++q) g += bpart[q * 32 + tid_l];
-        const float bm = biasl[32 + tid_l] + (g - biasl[32 + tid_l]) * ob1;
-        const float bv = biasl[64 + tid_l] * b2f + ob2 * g * g;
-        biasl[32 + tid_l] = bm;
-        biasl[64 + tid_l] = bv;
-        biasl[tid_l] = biasl[tid_l] - a0 * (bm / (sqrtf(bv) * a1 + p.adam_eps));
-      }
-    }
+    bias_pending = ks == 0;
     __syncthreads();
     BSIG_STAMP(12);
   }
@@ -302,6 +306,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
       p.params[off] = Wl[acc_row(i, h) * kPitch + kcol]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
     }
   }
+  if (bias_pending && tid < kNB) bias_step(tid);
   if (ks == 0 && tid < kNB && n0 + tid < Nh) {
     p.params[p.b_off + n0 + tid] = biasl[tid];
     p.m1[p.b_off + n0 + tid] = biasl[32 + tid];
@@ -473,9 +478,9 @@ static bool persist_geom(const PersistShape& s, PersistGeom* g) {
   if (g->R > kPT / 64) return false;
   g->n_owner = ceil_div(s.batch, g->R);
   const int per_wave = g->Nh + s.out_dim + 3 * s.n_comp;
-  g->x_floats = (int)round_up(std::max(std::max(128 * kPbufPitch, kNB * (g->FR + 4) + (kPT / 32) * 32),
+  g->x_floats = (int)round_up(std::max(std::max(128 * kPbufPitch, kNB * (g->FR + 4)),
                                        (kPT / 64) * per_wave), 4);
-  g->lds = ((size_t)g->FR * kPitch + (size_t)kNB * kPitch + g->x_floats + 64 + 96) * sizeof(float);
+  g->lds = ((size_t)g->FR * kPitch + (size_t)kNB * kPitch + g->x_floats + 64 + 96 + (kPT / 32) * 32) * sizeof(float);
   // the forward reads feature rows up to 127 (results of rows >= batch are dropped)
   if ((size_t)128 * kPitch * sizeof(float) > g->lds || g->lds > (size_t)kLdsLimit) return false;
   g->slab_floats = (size_t)g->k_slices * s.batch * g->NhP;

@@ -44,3 +44,27 @@ for g in (owners[0], owners[-1]):
                     ('eps gather + row', 6, 7), ('dO/E store+publish', 7, 9)):
         print('    %-18s %6.2f us' % (n, (st[g, 1:8, b] - st[g, 1:8, a]).mean()))
     print('    %-18s %6.2f us' % ('idle until next', (st[g, 2:8, 0] - st[g, 1:7, 9]).mean()))
+
+# chip-level critical path of one update (wall_clock64 is one 100 MHz counter for the chip)
+print('chip-level timeline, mean over updates 2..6 of the launch (us after the first tile workgroup starts the update):')
+rows = [('last tile wg has its feature tile in LDS', tiles, 1, np.max),
+        ('last tile wg done with the forward MFMAs', tiles, 2, np.max),
+        ('last forward flag raised', tiles, 3, np.max),
+        ('first owner released', owners, 4, np.min),
+        ('last owner released', owners, 4, np.max),
+        ('last owner has its row (slab sum, exp published)', owners, 5, np.max),
+        ('last owner waits for eps', owners, 6, np.max),
+        ('last row finished', owners, 7, np.max),
+        ('last owner published d_out', owners, 9, np.max),
+        ('first tile wg released', tiles, 10, np.min),
+        ('last tile wg released', tiles, 10, np.max),
+        ('last d_out^T tile in LDS', tiles, 11, np.max),
+        ('first tile wg finished the update', tiles, 12, np.min),
+        ('last tile wg finished the update', tiles, 12, np.max)]
+acc = {r[0]: [] for r in rows}
+for u in range(2, 7):
+    t0 = min(st[g, u, 0] for g in tiles)
+    for label, grp, k, fn in rows:
+        acc[label].append(fn([st[g, u, k] for g in grp]) - t0)
+for label, _, _, _ in rows:
+    print('    %-52s %6.2f' % (label, np.mean(acc[label])))
