@@ -488,9 +488,20 @@ static bool persist_geom(const PersistShape& s, PersistGeom* g) {
   return true;
 }
 
+// Every workgroup of the launch must be resident at once (they wait for each
+// other): one per CU because of the LDS footprint, so the device needs that many
+// CUs and must grant the LDS.
+static bool device_can_host(const PersistGeom& g) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  return prop.multiProcessorCount >= g.G + g.n_owner &&
+         (size_t)prop.maxSharedMemoryPerMultiProcessor >= g.lds;
+}
+
 bool persist_supported(const PersistShape& s) {
   PersistGeom g;
-  return persist_geom(s, &g);
+  return persist_geom(s, &g) && device_can_host(g);
 }
 
 static size_t sync_bytes() { return kXwgMax * sizeof(unsigned) + 3 * kXwgMax * 8; }
