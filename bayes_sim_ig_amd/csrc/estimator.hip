@@ -154,8 +154,6 @@ struct Inputs {
 // Adam fused into the dW GEMMs (single rank)
 struct AdamFuse {
   float* m; float* v; const float* dyn; float beta1, beta2, eps;
-  // head bias gradients as partial column sums (fused head kernel); null: grads buffer
-  const float* head_bias_parts = nullptr; int n_head_bias_parts = 1; int64_t head_bias_stride = 0;
 };
 
 static void set_src_a(GemmParams& g, const float* x, int64_t ld, const Inputs* in, int delta) {
@@ -191,7 +189,7 @@ static int rff_project(const bsig_mdn_cfg* c, const Inputs& in, int64_t rows, fl
 // trunk (or RFF) + heads -> o ; leaves activations in s.h / s.feat
 static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* params,
                         const Inputs& in, int64_t B, const Scratch& s, float* o, int64_t ldo,
-                        hipStream_t st, int* n_sig = nullptr, int* head_slabs = nullptr) {
+                        hipStream_t st, int* n_sig = nullptr) {
   const float* feat = in.x; int64_t ldf = in.ldx; const Inputs* src = &in;
   if (c->rff_feats > 0 && !in.is_feat) {
     BSIG_TRY(rff_project(c, in, B, s.feat, s.gemm_ws, s.gemm_ws_bytes, st));
@@ -213,14 +211,6 @@ static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* par
   g.c = o; g.ldc = ldo;
   g.m = (int)B; g.n = (int)L.nh; g.k = (int)L.feat_dim;
   g.epilogue = BSIG_EPI_BIAS; g.bias = params + L.head_b_off;
-  if (head_slabs) {   // fused head: leave the split-K slabs in s.gemm_ws unreduced
-    *head_slabs = gemm_planned_splits(g.m, g.n, g.k, s.gemm_ws_bytes);
-    if (*head_slabs > 1) {
-      g.skip_reduce = true;
-      return gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st);
-    }
-    *head_slabs = 0;
-  }
   if (n_sig && c->head.eps_noise != 0.f) {   // sum(exp(pre_diag)) partials for the jitter scale
     g.expsum = s.head_ws;
     g.expsum_col0 = c->head.n_comp + c->head.out_dim * c->head.n_comp;
@@ -237,7 +227,7 @@ static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* par
 static int weight_grad(const float* dy, int64_t nout, const float* xin, int64_t ldin,
                        const Inputs* src, int delta, int64_t nin, int64_t B, float* params,
                        float* grads, int64_t w_off, int64_t b_off, const AdamFuse* fuse,
-                       const Scratch& s, hipStream_t st, bool is_head = false) {
+                       const Scratch& s, hipStream_t st) {
   GemmParams g;
   g.a = dy; g.lda = nout; g.a_kmajor = 1;
   set_src_b_kmajor(g, xin, ldin, src, delta);
@@ -248,10 +238,6 @@ static int weight_grad(const float* dy, int64_t nout, const float* xin, int64_t 
     g.adam_dyn = fuse->dyn; g.beta1 = fuse->beta1; g.beta2 = fuse->beta2; g.adam_eps = fuse->eps;
     g.bias_p = params + b_off; g.bias_m = fuse->m + b_off; g.bias_v = fuse->v + b_off;
     g.bias_g = grads + b_off;
-    if (is_head && fuse->head_bias_parts) {
-      g.bias_g = fuse->head_bias_parts; g.bias_g_parts = fuse->n_head_bias_parts;
-      g.bias_g_stride = fuse->head_bias_stride;
-    }
   } else {
     g.epilogue = BSIG_EPI_NONE;
     g.c = grads + w_off;
@@ -282,7 +268,7 @@ static int backward_pass(const bsig_mdn_cfg* c, const Layout& L, float* params,
   }
   // heads: dW = dO^T feat (bias gradient = column sums of dO, from the finish kernel)
   BSIG_TRY(weight_grad(s.d_o, L.nh, feat, ldf, fsrc, delta, L.feat_dim, B, params, grads,
-                       L.head_w_off, L.head_b_off, fuse, s, st, true));
+                       L.head_w_off, L.head_b_off, fuse, s, st));
   for (int l = L.n_layers - 1; l >= 0; --l) {
     const int64_t hw = c->hidden[l];
     const float* xin; int64_t ldin; const Inputs* xsrc = nullptr;
@@ -367,7 +353,6 @@ struct bsig_fit_plan {
   int64_t norm_batch;
   size_t train_ws_bytes, test_ws_bytes, feats_bytes, big_gemm_ws_bytes, iota_bytes;
   bool use_graph, split_adam;
-  bool fused_head;             // single-rank updates use the fused head kernel
   bool persistent;             // single-rank updates run in the persistent kernel (persist.h)
   size_t persist_bytes;
   hipStream_t cap_stream;
@@ -459,23 +444,13 @@ static int enqueue_grad(bsig_fit_plan* p, hipStream_t st, bool fuse_adam) {
   AdamFuse fuse{b.exp_avg, b.exp_avg_sq, reinterpret_cast<const float*>(b.state) + ST_ADAM0,
                 p->cfg.beta1, p->cfg.beta2, p->cfg.adam_eps};
   const uint64_t* rng = reinterpret_cast<const uint64_t*>(b.state + ST_RNG);
-  int n_sig = 0, slabs = 0;
-  const bool try_fused = fuse_adam && p->fused_head;
+  int n_sig = 0;
   BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, p->batch, m.tr, m.tr.o, p->L.nh, st,
-                        &n_sig, try_fused ? &slabs : nullptr));
-  if (slabs > 1) {   // split-K slabs -> NLL, backward, finish in one kernel
-    BSIG_TRY(mdn_head_fused_launch(&p->cfg.head, m.tr.gemm_ws, slabs, b.params + p->L.head_b_off,
-                                   b.y_train, b.ldy_train, b.ids_table, p->batch, p->norm_batch,
-                                   rng, b.train_loss, b.state + ST_STEP, m.tr.d_o, p->L.nh,
-                                   b.state + ST_NONFINITE, m.tr.head_ws, m.tr.head_ws_bytes, st,
-                                   &hd, &fuse.head_bias_parts, &fuse.n_head_bias_parts));
-    fuse.head_bias_stride = p->L.nh;
-  } else {
-    hd.n_sig_ready = n_sig;
-    BSIG_TRY(head_nll(&p->cfg, p->L, m.tr, b.y_train, b.ldy_train, b.ids_table, p->batch,
-                      p->norm_batch, nullptr, 0, 0, rng, b.train_loss, b.state + ST_STEP, true,
-                      b.grads + p->L.head_b_off, b.state + ST_NONFINITE, &hd, st));
-  }
+                        &n_sig));
+  hd.n_sig_ready = n_sig;
+  BSIG_TRY(head_nll(&p->cfg, p->L, m.tr, b.y_train, b.ldy_train, b.ids_table, p->batch,
+                    p->norm_batch, nullptr, 0, 0, rng, b.train_loss, b.state + ST_STEP, true,
+                    b.grads + p->L.head_b_off, b.state + ST_NONFINITE, &hd, st));
   return backward_pass(&p->cfg, p->L, b.params, in, -1, p->batch, m.tr, b.grads,
                        fuse_adam ? &fuse : nullptr, st);
 }
@@ -666,10 +641,6 @@ extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t m
   const char* no_hoist = getenv("BSIG_NO_RFF_HOIST");
   p->hoist = cfg->rff_feats > 0 && n_updates > 0 && feats <= ((size_t)4 << 30) &&
              !(no_hoist && no_hoist[0] == '1');
-  // experimental (slower than the three-kernel head today: see DESIGN.md)
-  const char* fused = getenv("BSIG_FUSED_HEAD");
-  p->fused_head = (fused && fused[0] == '1') && cfg->head.full_cov == 0 &&
-                  mdn_head_fused_ok(&cfg->head, batch);
   const char* no_persist = getenv("BSIG_NO_PERSISTENT");
   p->persistent = p->hoist && p->L.n_layers == 0 && cfg->head.full_cov == 0 &&
                   !(no_persist && no_persist[0] == '1') && persist_supported(persist_shape(p));
@@ -736,10 +707,6 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
   if (norm_batch != p->norm_batch) { drop_graphs(p); p->norm_batch = norm_batch; }
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(fit_begin_kernel, dim3(1), dim3(64), 0, st, p->buf.state, seed);
-  if (p->fused_head) {
-    PlanMem m; plan_mem(p, &m);
-    BSIG_TRY(mdn_head_sync_reset(&p->cfg.head, p->batch, m.tr.head_ws, m.tr.head_ws_bytes, st));
-  }
   BSIG_CHECK_LAUNCH("fit_begin");
   if (p->persistent) {
     PlanMem m; plan_mem(p, &m);

@@ -34,15 +34,11 @@ struct GemmParams {
   // bias_p[row] with gradient bias_g[row] (column sums computed earlier)
   float* bias_p = nullptr; float* bias_m = nullptr; float* bias_v = nullptr;
   const float* bias_g = nullptr;
-  int bias_g_parts = 1; int64_t bias_g_stride = 0;   // bias_g[row] = sum_q bias_g[q*stride + row]
-  // split-K only: leave the partial slabs unreduced (a consumer sums them)
-  bool skip_reduce = false;
 };
 
 // n_expsum (optional) receives the number of expsum partials written.
 int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st,
              int* n_expsum = nullptr);
-// split-K factor gemm_run will use for this problem and workspace
-int gemm_planned_splits(int64_t m, int64_t n, int64_t k, size_t workspace_bytes);
+
 
 }  // namespace bsig

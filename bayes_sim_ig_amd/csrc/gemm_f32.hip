@@ -88,8 +88,7 @@ __device__ inline void epilogue_store(const GemmParams& p, int row, int col, flo
       p.adam_v[e] = v1;
       p.c[e] = p.c[e] - p.adam_dyn[0] * (m1 / (sqrtf(v1) * p.adam_dyn[1] + p.adam_eps));
       if (col == 0 && p.bias_p) {
-        float g = 0.f;
-        for (int q = 0; q < p.bias_g_parts; ++q) g += p.bias_g[q * p.bias_g_stride + row];
+        const float g = p.bias_g[row];
         const float bm = p.bias_m[row] + (g - p.bias_m[row]) * (1.0f - p.beta1);
         const float bv = p.bias_v[row] * p.beta2 + (1.0f - p.beta2) * g * g;
         p.bias_m[row] = bm;
@@ -140,9 +139,7 @@ __device__ inline void tile_epilogue_vec(const GemmParams& p, const float* __res
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = ok[it] ? row0 + it * 8 + r8 : 0;
-        float gsum = 0.f;
-        for (int q = 0; q < p.bias_g_parts; ++q) gsum += p.bias_g[q * p.bias_g_stride + row];
-        bg[it] = gsum; bm0[it] = p.bias_m[row];
+        bg[it] = p.bias_g[row]; bm0[it] = p.bias_m[row];
         bv0[it] = p.bias_v[row]; bp0[it] = p.bias_p[row];
       }
     }
@@ -279,8 +276,7 @@ __device__ inline void tile_epilogue(const GemmParams& p, const float* __restric
       for (int it = 0; it < 16; ++it) {
         const int row = rbase + 2 * it;
         if (row < p.m) {
-          float g = 0.f;
-          for (int q = 0; q < p.bias_g_parts; ++q) g += p.bias_g[q * p.bias_g_stride + row];
+          const float g = p.bias_g[row];
           const float bm = p.bias_m[row] + (g - p.bias_m[row]) * (1.0f - p.beta1);
           const float bv = p.bias_v[row] * p.beta2 + (1.0f - p.beta2) * g * g;
           p.bias_m[row] = bm;
@@ -809,7 +805,7 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     rc = launch_tile<2, 2, 1, 1>(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   if (rc != BSIG_OK) return rc;
   BSIG_CHECK_LAUNCH("gemm_mfma");
-  if (p.splits > 1 && !p.skip_reduce) {
+  if (p.splits > 1) {
     const int64_t total = (int64_t)p.m * p.n;
     const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total, 256), 2048);
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
@@ -821,10 +817,6 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     *n_expsum = ceil_div(p.m, bm) * ceil_div(p.n, bn);
   }
   return BSIG_OK;
-}
-
-int gemm_planned_splits(int64_t m, int64_t n, int64_t k, size_t workspace_bytes) {
-  return plan_gemm(m, n, k, workspace_bytes).splits;
 }
 
 int gemm_f32(const float* a, int64_t lda, int a_kmajor, const int32_t* a_rows,

@@ -27,22 +27,6 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
                         float* colsum_out, int32_t* nonfinite, void* workspace,
                         size_t workspace_bytes, hipStream_t st, const HeadDyn* dyn);
 
-// Fused variant (diagonal covariance, fit engine, single rank): consumes the
-// unreduced split-K slabs of the head GEMM (pre = sum_z slabs[z] + bias), needs
-// dyn->y_dyn (the update counter: also the tag of its cross-workgroup sums) and
-// mdn_head_sync_reset on the same workspace when the fit call begins.  Returns
-// the per-workgroup column sums of d_out ([*n_colparts][Nh]) in the workspace.
-bool mdn_head_fused_ok(const bsig_head_dims* dims, int64_t batch);
-int mdn_head_sync_reset(const bsig_head_dims* dims, int64_t batch, void* workspace,
-                        size_t workspace_bytes, hipStream_t st);
-int mdn_head_fused_launch(const bsig_head_dims* dims, const float* slabs, int n_slabs,
-                          const float* bias, const float* y, int64_t ldy,
-                          const int32_t* y_rows, int64_t batch, int64_t norm_batch,
-                          const uint64_t* dyn_rng, float* loss, const int32_t* loss_slot,
-                          float* d_out, int64_t ld_dout, int32_t* nonfinite, void* workspace,
-                          size_t workspace_bytes, hipStream_t st, const HeadDyn* dyn,
-                          const float** colpart, int* n_colparts);
-
 int head_sig_capacity();   // max partial sums the head workspace can take
 
 }  // namespace bsig

@@ -9,9 +9,7 @@ constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr int kSigMax = 4096;       // capacity of the exp(pre) partial-sum array
 constexpr int kSigBlocks = 512;     // blocks of the stand-alone sigma0_sum kernel
 constexpr int kElemsPerLane = 8;    // wave kernel: register-cached elements per lane
-constexpr int kGranMax = 64;        // fused kernel: at most this many workgroups
 constexpr int kXwgMax = 256;        // persistent kernel: at most this many workgroups
-constexpr int kFusedThreads = 1024; // fused kernel: 16 wavefronts per workgroup
 
 struct HeadArgs {
   const float* seg_w; int64_t ld_w;    // logits (fused) or weights (tuple), K / row
@@ -31,13 +29,6 @@ struct HeadArgs {
   float* block_lse;                    // [gridDim.x]
   float* block_uds;                    // [gridDim.x]  sum u * dL/dsigma
   int32_t* nonfinite;
-  // fused variant only (fit engine, single rank): the raw head outputs arrive as
-  // split-K slabs, pre[row, col] = sum_z slabs[z][row][col] + bias[col]
-  const float* slabs; int n_slabs; const float* bias;
-  unsigned long long* gran;            // [3][kGranMax] {tag, value} cross-workgroup granules
-  float* colpart;                      // [gridDim.x][Nh] column sums of the block's d_out rows
-  float* loss; const int32_t* loss_slot;
-  FinishHook hook;
 };
 
 // ---- diagonal covariance, one wavefront per row ------------------------------

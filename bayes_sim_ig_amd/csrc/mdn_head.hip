@@ -364,145 +364,6 @@ __device__ inline void run_finish_hook(const FinishHook& hook) {
   reinterpret_cast<uint64_t*>(st + 8)[1] += 1;   // jitter RNG stream
 }
 
-// ---- fused variant: split-K reduce + NLL + backward + finish in one launch -----
-// Used by the single-rank fit engine for diagonal covariances when the head
-// GEMM ran split-K.  Grid = G <= 64 workgroups of 16 wavefronts, R rows each
-// (all co-resident: 256 CUs).  Phase A: all 1024 threads sum the slabs of the
-// workgroup's R rows into LDS (+ bias) and the workgroup publishes its
-// sum(exp(pre)); wave r < R then runs diag_row on row r.  The three batch-wide
-// sums (exp(pre) for the jitter scale, u*dL/dsigma for its gradient term, the
-// logsumexp for the loss) cross workgroups as 8-byte {tag, value} granules:
-// one relaxed agent-scope atomic store each, polled by lane g of every
-// consuming wave and summed in granule order (bitwise reproducible).  The tag
-// encodes (update, phase), granules are zeroed when a fit call begins, so a
-// stale value is never taken; the poll is bounded and raises the nonfinite
-// flag (bit 1) instead of hanging.
-__global__ __launch_bounds__(kFusedThreads) void mdn_fused_diag_kernel(HeadArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int D = a.D, K = a.K, Nh = a.Nh, R = a.R;
-  const int DK = D * K;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int per_wave = Nh + D + 3 * K;
-  float* red = smem;                         // [48] wave partials: exp | lse | uds
-  float* tile = smem + 64 + wid * per_wave;  // rows of waves 0..R-1
-  float* yv = tile + Nh;
-  float* rk = yv + D;
-  float* lpk = rk + K;
-  float* dlg = lpk + K;
-  const int G = gridDim.x;
-  const int step = a.y_dyn[0];
-  const uint32_t tag = (uint32_t)step * 4u + 4u;
-  unsigned long long* gran_exp = a.gran;
-  unsigned long long* gran_uds = a.gran + kGranMax;
-  unsigned long long* gran_lse = a.gran + 2 * kGranMax;
-  const int row = blockIdx.x * R + wid;
-  const bool owner = wid < R;
-  const bool active = owner && row < a.batch;
-  const float norm = (float)a.batch * (float)DK;
-
-  float yq = 0.f;
-  int64_t yrow = 0;
-  if (active) {
-    const int64_t yoff = (int64_t)step * a.y_dyn_stride;
-    yrow = a.y_rows ? (int64_t)a.y_rows[row + yoff] : row + yoff;
-    yq = a.y[yrow * a.ldy + min(lane, D - 1)];
-  }
-  // phase A: pre = sum of slabs (slab order) + bias
-  const int64_t total = (int64_t)a.batch * Nh;
-  const int64_t base = (int64_t)blockIdx.x * R * Nh;
-  const int nelem = (int)min((int64_t)R * Nh, total - base);
-  float eacc = 0.f;
-  for (int e = tid; e < nelem; e += kFusedThreads) {
-    const float* src = a.slabs + base + e;
-    float v = 0.f;
-    for (int z = 0; z < a.n_slabs; z += 16) {
-      float q[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) q[u] = src[(int64_t)min(z + u, a.n_slabs - 1) * total];
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (z + u < a.n_slabs) v += q[u];
-    }
-    const int r = e / Nh, col = e - r * Nh;
-    v += a.bias[col];
-    smem[64 + r * per_wave + col] = v;
-    if (col >= K + DK && col < K + 2 * DK) eacc += expf(v);
-  }
-  eacc = wave_sum(eacc);
-  if (lane == 0) red[wid] = eacc;
-  __syncthreads();
-  if (tid == 0) {
-    float sx = 0.f;
-    for (int w = 0; w < kFusedThreads / 64; ++w) sx += red[w];
-    granule_publish(gran_exp + blockIdx.x, tag + 1, sx);
-  }
-
-  RowOut ro;
-  ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
-#pragma unroll
-  for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
-  if (owner) {
-    if (active) {
-      if (lane < D) yv[lane] = yq;
-      for (int j = lane + 64; j < D; j += 64) yv[j] = a.y[yrow * a.ldy + j];
-    }
-    float eps = 0.f;
-    if (a.eps_noise != 0.f)
-      eps = a.eps_noise * (granule_gather(gran_exp, G, tag + 1, lane, a.nonfinite) / norm);
-    __builtin_amdgcn_wave_barrier();
-    diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, [&] { return eps; }, ro);
-    const float uds_w = wave_sum(ro.uds);
-    if (lane == 0) { red[16 + wid] = active ? ro.lse : 0.f; red[32 + wid] = uds_w; }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float sl = 0.f, su = 0.f;
-    for (int w = 0; w < R; ++w) { sl += red[16 + w]; su += red[32 + w]; }
-    granule_publish(gran_uds + blockIdx.x, tag + 2, su);
-    granule_publish(gran_lse + blockIdx.x, tag + 3, sl);
-  }
-  if (owner) {
-    // jitter-scale gradient term: d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
-    float c = 0.f;
-    if (a.eps_noise != 0.f)
-      c = a.eps_noise / norm * granule_gather(gran_uds, G, tag + 2, lane, a.nonfinite);
-    if (active) {
-      const int groups = 64 / K;
-      const int k = lane % K, d0 = lane / K;
-      if (c != 0.f && lane < groups * K) {
-#pragma unroll
-        for (int q = 0; q < kElemsPerLane; ++q) {
-          const int d = d0 + q * groups;
-          if (d < D) tile[K + DK + d * K + k] += c * ro.esg0[q];
-        }
-      }
-      for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
-      __builtin_amdgcn_wave_barrier();
-      float* o = a.d_out + (int64_t)row * a.ld_dout;
-      for (int j = lane; j < Nh; j += 64) o[j] = tile[j];
-    } else {
-      for (int j = lane; j < Nh; j += 64) tile[j] = 0.f;
-    }
-  }
-  __syncthreads();
-  // head bias gradients: column sums of the workgroup's rows
-  for (int col = tid; col < Nh; col += kFusedThreads) {
-    float t = 0.f;
-    for (int r = 0; r < R; ++r) t += smem[64 + r * per_wave + col];
-    a.colpart[(int64_t)blockIdx.x * Nh + col] = t;
-  }
-  if (blockIdx.x == 0 && wid == 0) {
-    const float s = granule_gather(gran_lse, G, tag + 3, lane, a.nonfinite);
-    if (lane == 0) {
-      const float l = -s / (float)a.batch;
-      if (a.loss) a.loss[a.loss_slot ? *a.loss_slot : 0] = l;
-      if (!isfinite(l) && a.nonfinite) atomicOr(a.nonfinite, 1);
-      if (a.hook.state) run_finish_hook(a.hook);
-    }
-  }
-  if (ro.bad && a.nonfinite) atomicOr(a.nonfinite, 1);
-}
-
 // Finishing kernel: loss = -(sum of block partials) / batch; jitter-scale
 // gradient term d pre += (EPS/(B*D*K)) * sum(u * dL/dsigma) * exp(pre) (the
 // non-detached mean of mdnn.py:115); column sums of the corrected d_out (the
@@ -677,77 +538,8 @@ static int head_geom(const bsig_head_dims* d, int64_t batch, HeadGeom* g) {
 }
 
 // workspace floats: [sig partials kSigMax][block_lse nblk][block_uds nblk][colsum slabs x Nh]
-static size_t head_ws_main_floats(const HeadGeom& g) {
-  return round_up<size_t>(kSigMax + 2 * (size_t)g.blocks + (size_t)kMaxSlabs * g.Nh, 4);
-}
-// ... followed by the fused kernel's granules: [3][kGranMax] x 8 bytes
 static size_t head_ws_floats(const HeadGeom& g) {
-  return head_ws_main_floats(g) + 3 * (size_t)kGranMax * 2;
-}
-
-// geometry of the fused kernel: R rows per workgroup so that G <= kGranMax
-static bool fused_geom(const HeadGeom& g, int64_t batch, int* rows_per_wg, int* wgs, size_t* lds) {
-  if (!g.wave_per_row) return false;
-  const int64_t R = ceil_div<int64_t>(batch, kGranMax);
-  if (R > kFusedThreads / 64) return false;
-  *rows_per_wg = (int)R;
-  *wgs = (int)ceil_div<int64_t>(batch, R);
-  *lds = (64 + (size_t)R * (g.Nh + g.D + 3 * g.K)) * sizeof(float);
-  return *lds <= 60 * 1024;
-}
-
-bool mdn_head_fused_ok(const bsig_head_dims* dims, int64_t batch) {
-  HeadGeom g;
-  int r, w; size_t lds;
-  if (batch < 1 || head_geom(dims, batch, &g) != BSIG_OK) return false;
-  return fused_geom(g, batch, &r, &w, &lds);
-}
-
-int mdn_head_sync_reset(const bsig_head_dims* dims, int64_t batch, void* workspace,
-                        size_t workspace_bytes, hipStream_t st) {
-  HeadGeom g;
-  BSIG_TRY(head_geom(dims, batch, &g));
-  BSIG_REQUIRE(workspace && workspace_bytes >= head_ws_floats(g) * sizeof(float),
-               "mdn head: workspace too small");
-  BSIG_HIP(hipMemsetAsync(reinterpret_cast<float*>(workspace) + head_ws_main_floats(g), 0,
-                          3 * (size_t)kGranMax * 8, st));
-  return BSIG_OK;
-}
-
-int mdn_head_fused_launch(const bsig_head_dims* dims, const float* slabs, int n_slabs,
-                          const float* bias, const float* y, int64_t ldy,
-                          const int32_t* y_rows, int64_t batch, int64_t norm_batch,
-                          const uint64_t* dyn_rng, float* loss, const int32_t* loss_slot,
-                          float* d_out, int64_t ld_dout, int32_t* nonfinite, void* workspace,
-                          size_t workspace_bytes, hipStream_t st, const HeadDyn* dyn,
-                          const float** colpart, int* n_colparts) {
-  HeadGeom g;
-  BSIG_TRY(head_geom(dims, batch, &g));
-  int R = 0, G = 0; size_t lds = 0;
-  BSIG_REQUIRE(fused_geom(g, batch, &R, &G, &lds), "mdn head: shape not covered by the fused kernel");
-  BSIG_REQUIRE(slabs && n_slabs >= 1 && bias && y && d_out && dyn && dyn->y_dyn && colpart &&
-                   n_colparts, "mdn head (fused): null argument");
-  BSIG_REQUIRE(workspace && workspace_bytes >= head_ws_floats(g) * sizeof(float),
-               "mdn head: workspace too small (%zu < %zu)", workspace_bytes,
-               head_ws_floats(g) * sizeof(float));
-  float* ws = reinterpret_cast<float*>(workspace);
-  HeadArgs a{};
-  a.y = y; a.ldy = ldy; a.y_rows = y_rows;
-  a.y_dyn = dyn->y_dyn; a.y_dyn_stride = dyn->y_dyn_stride;
-  a.batch = (int)batch; a.inv_norm = 1.0f / (float)norm_batch;
-  a.D = g.D; a.K = g.K; a.Ls = 0; a.Nh = g.Nh; a.R = R;
-  a.from_tuple = 0;
-  a.noise = nullptr; a.seed = 0; a.stream_id = 0; a.dyn_rng = dyn_rng;
-  a.eps_noise = dims->eps_noise; a.min_w = dims->min_weight; a.ll_limit = dims->ll_limit;
-  a.d_out = d_out; a.ld_dout = ld_dout; a.nonfinite = nonfinite;
-  a.slabs = slabs; a.n_slabs = n_slabs; a.bias = bias;
-  a.gran = reinterpret_cast<unsigned long long*>(ws + head_ws_main_floats(g));
-  a.colpart = ws + kSigMax + 2 * (size_t)g.blocks;     // the slab-sum area of the finish kernel
-  a.loss = loss; a.loss_slot = loss_slot; a.hook = dyn->hook;
-  hipLaunchKernelGGL(mdn_fused_diag_kernel, dim3(G), dim3(kFusedThreads), lds, st, a);
-  BSIG_CHECK_LAUNCH("mdn_fused");
-  *colpart = a.colpart; *n_colparts = G;
-  return BSIG_OK;
+  return kSigMax + 2 * (size_t)g.blocks + (size_t)kMaxSlabs * g.Nh;
 }
 
 int head_sig_capacity() { return kSigMax; }
