@@ -91,6 +91,8 @@ _PROTOS = {
     'bsig_fit_run': (C.c_int, [vp, i64, vp]),
     'bsig_fit_grad': (C.c_int, [vp, vp]),
     'bsig_fit_apply': (C.c_int, [vp, vp]),
+    'bsig_fit_flush': (C.c_int, [vp, vp]),
+    'bsig_fit_is_persistent': (C.c_int, [vp]),
     'bsig_fit_eval': (C.c_int, [vp, vp]),
     'bsig_fit_updates': (C.c_int, [vp, i64, vp]),
     'bsig_debug_persist_profile': (None, [vp]),

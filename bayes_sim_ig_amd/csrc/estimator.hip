@@ -353,7 +353,9 @@ struct bsig_fit_plan {
   int64_t norm_batch;
   size_t train_ws_bytes, test_ws_bytes, feats_bytes, big_gemm_ws_bytes, iota_bytes;
   bool use_graph, split_adam;
-  bool persistent;             // single-rank updates run in the persistent kernel (persist.h)
+  bool persistent;             // updates run in the persistent kernel (persist.h)
+  bool adam_pending;           // ... data-parallel: the Adam step on the reduced gradients is
+                               // taken by the next launch (or flushed before an evaluation)
   size_t persist_bytes;
   hipStream_t cap_stream;
   hipGraphExec_t g_step, g_grad, g_apply, g_eval;
@@ -384,7 +386,9 @@ static PersistShape persist_shape(const bsig_fit_plan* p) {
   return PersistShape{(int)p->batch, (int)p->L.feat_dim, p->cfg.head.out_dim, p->cfg.head.n_comp};
 }
 
-// n consecutive updates in the persistent kernel
+// n consecutive updates in the persistent kernel.  Data-parallel plans
+// (split_adam): ONE update whose gradients go to the flat gradient buffer, after
+// the pending Adam step of the previous one; n = 0 flushes that step.
 static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st) {
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
@@ -396,6 +400,10 @@ static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st) {
   pb.w_off = p->L.head_w_off; pb.b_off = p->L.head_b_off;
   pb.state = b.state; pb.train_loss = b.train_loss;
   pb.workspace = m.persist_ws; pb.workspace_bytes = p->persist_bytes;
+  if (p->split_adam) {
+    pb.grads = b.grads; pb.adam_pending = p->adam_pending ? 1 : 0;
+    p->adam_pending = false;
+  }
   PersistHyper hy;
   hy.lr = p->cfg.lr; hy.beta1 = p->cfg.beta1; hy.beta2 = p->cfg.beta2;
   hy.adam_eps = p->cfg.adam_eps; hy.eps_noise = p->cfg.head.eps_noise;
@@ -527,8 +535,12 @@ static int capture(bsig_fit_plan* p, hipGraphExec_t* out, F&& body) {
 static int ensure_graphs(bsig_fit_plan* p) {
   if (!p->use_graph || p->g_eval) return BSIG_OK;
   if (p->split_adam) {
-    BSIG_TRY(capture(p, &p->g_grad, [&](hipStream_t s) { return enqueue_grad(p, s, false); }));
-    BSIG_TRY(capture(p, &p->g_apply, [&](hipStream_t s) { return enqueue_apply(p, s); }));
+    if (!p->persistent) {
+      BSIG_TRY(capture(p, &p->g_grad, [&](hipStream_t s) { return enqueue_grad(p, s, false); }));
+      BSIG_TRY(capture(p, &p->g_apply, [&](hipStream_t s) { return enqueue_apply(p, s); }));
+    }
+  } else if (p->persistent) {
+    // updates are single launches of the persistent kernel: no update graph
   } else {
     BSIG_TRY(capture(p, &p->g_step, [&](hipStream_t s) { return enqueue_grad(p, s, true); }));
   }
@@ -708,6 +720,7 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(fit_begin_kernel, dim3(1), dim3(64), 0, st, p->buf.state, seed);
   BSIG_CHECK_LAUNCH("fit_begin");
+  p->adam_pending = false;
   if (p->persistent) {
     PlanMem m; plan_mem(p, &m);
     BSIG_TRY(persist_reset(persist_shape(p), m.persist_ws, p->persist_bytes, st));
@@ -721,18 +734,32 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
 
 extern "C" int bsig_fit_grad(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_grad: plan not bound with SPLIT_ADAM");
+  if (p->persistent) return enqueue_persistent(p, 1, as_stream(stream));
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_grad, as_stream(stream))); return BSIG_OK; }
   return enqueue_grad(p, as_stream(stream), false);
 }
 
 extern "C" int bsig_fit_apply(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_apply: plan not bound with SPLIT_ADAM");
+  // persistent kernel: the step is taken by the next bsig_fit_grad launch while it
+  // loads its tiles (bsig_fit_eval / bsig_fit_flush take it at once)
+  if (p->persistent) { p->adam_pending = true; return BSIG_OK; }
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_apply, as_stream(stream))); return BSIG_OK; }
   return enqueue_apply(p, as_stream(stream));
 }
 
+extern "C" int bsig_fit_is_persistent(const bsig_fit_plan* p) { return p && p->persistent ? 1 : 0; }
+
+extern "C" int bsig_fit_flush(bsig_fit_plan* p, bsig_stream_t stream) {
+  BSIG_REQUIRE(p && p->bound, "fit_flush: plan not bound");
+  if (p->persistent && p->split_adam && p->adam_pending)
+    return enqueue_persistent(p, 0, as_stream(stream));
+  return BSIG_OK;
+}
+
 extern "C" int bsig_fit_eval(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound, "fit_eval: plan not bound");
+  BSIG_TRY(bsig_fit_flush(p, stream));
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_eval, as_stream(stream))); return BSIG_OK; }
   return enqueue_eval(p, as_stream(stream));
 }
@@ -742,6 +769,13 @@ extern "C" int bsig_fit_eval(bsig_fit_plan* p, bsig_stream_t stream) {
 static int enqueue_updates(bsig_fit_plan* p, int64_t n, hipStream_t st) {
   if (n <= 0) return BSIG_OK;
   if (p->persistent && !p->split_adam) return enqueue_persistent(p, (int)n, st);
+  if (p->persistent) {   // data-parallel plan driven without an exchange (one rank)
+    for (int64_t it = 0; it < n; ++it) {
+      BSIG_TRY(enqueue_persistent(p, 1, st));
+      p->adam_pending = true;
+    }
+    return BSIG_OK;
+  }
   for (int64_t it = 0; it < n; ++it) {
     if (p->use_graph) {
       if (p->split_adam) {
@@ -780,8 +814,7 @@ extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t s
     if (it % every == 0 || it + 1 == n_updates) {
       BSIG_TRY(enqueue_updates(p, it + 1 - done, st));   // the run of updates up to here
       done = it + 1;
-      if (p->use_graph) BSIG_HIP(hipGraphLaunch(p->g_eval, st));
-      else BSIG_TRY(enqueue_eval(p, st));
+      BSIG_TRY(bsig_fit_eval(p, stream));
     }
   }
   return BSIG_OK;

@@ -57,6 +57,11 @@ struct PersistArgs {
   double lr, beta1, beta2;
   float adam_eps, eps_noise, min_w, ll_limit, inv_norm;
   float* slabs; float* d_out; float* e_out; unsigned* flag_fwd; unsigned long long* gran;
+  // data-parallel ranks (one update per launch, the caller all-reduces `grads`
+  // between launches): dW / bias gradients go to `grads` instead of Adam, and the
+  // Adam step of the PREVIOUS update (on the reduced gradients) is taken while the
+  // tile is loaded (adam_pending)
+  float* grads; int adam_pending;
   long long* prof;   // diagnostics: [G][kProfUpdates][16] wall-clock stamps, or null
 };
 
@@ -68,6 +73,25 @@ constexpr int kProfUpdates = 8;
   } while (0)
 
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// One Adam step of a weight element / a bias element.  Written with explicit
+// fused operations so that every call site (the resident run, a data-parallel
+// rank's pending step) rounds identically whatever the surrounding code.
+struct AdamK { float ob1, b2f, ob2, eps; };
+__device__ __forceinline__ float adam_weight(float g, float& m, float& v, float w, float a0,
+                                             float a1, const AdamK& k) {
+  m = __builtin_fmaf(g - m, k.ob1, m);
+  v = __builtin_fmaf(k.ob2 * g, g, v * k.b2f);
+  // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences
+  const float r = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_sqrtf(v), a1, k.eps));
+  return __builtin_fmaf(-a0, m * r, w);
+}
+__device__ __forceinline__ float adam_bias(float g, float& m, float& v, float w, float a0,
+                                           float a1, const AdamK& k) {
+  m = __builtin_fmaf(g - m, k.ob1, m);
+  v = __builtin_fmaf(k.ob2 * g, g, v * k.b2f);
+  return __builtin_fmaf(-a0, m / __builtin_fmaf(sqrtf(v), a1, k.eps), w);
+}
 
 // workgroup-uniform test of the time-out bit (set by any bounded poll on the chip)
 __device__ __forceinline__ bool run_aborted(int32_t* flagp, float* red, int tid) {
@@ -88,6 +112,7 @@ __device__ __forceinline__ bool run_aborted(int32_t* flagp, float* red, int tid)
     const int64_t fr = p.feat_ids ? (int64_t)p.feat_ids[r] : r;                           \
     pf##u = *reinterpret_cast<const float4*>(p.feats + fr * p.ld_feats + k0 + (idx & 63) * 4); \
   }
+#define BSIG_PF_ZERO(u) pf##u = make_float4(0.f, 0.f, 0.f, 0.f);
 #define BSIG_PF_STORE(u)                                                                  \
   {                                                                                       \
     const int idx = (u) * kPT + tid;                                                      \
@@ -95,6 +120,7 @@ __device__ __forceinline__ bool run_aborted(int32_t* flagp, float* red, int tid)
   }
 
 // ---- tile workgroups: forward partial products, dW, Adam ----------------------
+template <bool DP>
 __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem) {
   float* Fl = smem;                          // [FR][kPitch] minibatch features (this k-slice)
   float* Wl = Fl + p.FR * kPitch;            // [32][kPitch] weight tile (authoritative copy)
@@ -112,13 +138,18 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
   double b1t = reinterpret_cast<const double*>(p.state + 12)[0];
   double b2t = reinterpret_cast<const double*>(p.state + 12)[1];
   float a0 = 0.f, a1 = 0.f;
-  const float ob1 = 1.0f - (float)p.beta1, b2f = (float)p.beta2, ob2 = 1.0f - (float)p.beta2;
+  const AdamK ak{1.0f - (float)p.beta1, (float)p.beta2, 1.0f - (float)p.beta2, p.adam_eps};
 
   // resident Adam moments in the dW accumulator layout: element i of lane
   // (h, l31) of wave w  <->  W[n0 + acc_row(i, h)][k0 + 32w + l31]; W itself
   // lives in LDS (it is the B operand of the forward product)
   float Mr[16], Vr[16];
   const int kcol = 32 * w + l31;
+  constexpr bool dp = DP;
+  const bool pend = DP && p.adam_pending != 0;
+  // data-parallel: Adam scalars of the update whose reduced gradients are pending
+  const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
+  const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int n = n0 + acc_row(i, h);
@@ -127,14 +158,25 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     if (n < Nh) {
       const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
       wv = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+      if (pend) {
+        // (a data-parallel launch changes the tile only here: written back at once,
+        // the stores drain under the forward product)
+        wv = adam_weight(p.grads[off], Mr[i], Vr[i], wv, pa0, pa1, ak);
+        p.params[off] = wv; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+      }
     }
     Wl[acc_row(i, h) * kPitch + kcol] = wv;
   }
   if (ks == 0 && tid < kNB) {
     const int n = n0 + tid;
-    biasl[tid] = n < Nh ? p.params[p.b_off + n] : 0.f;
-    biasl[32 + tid] = n < Nh ? p.m1[p.b_off + n] : 0.f;
-    biasl[64 + tid] = n < Nh ? p.m2[p.b_off + n] : 0.f;
+    float bw = n < Nh ? p.params[p.b_off + n] : 0.f;
+    float bm = n < Nh ? p.m1[p.b_off + n] : 0.f;
+    float bv = n < Nh ? p.m2[p.b_off + n] : 0.f;
+    if (pend && n < Nh) {
+      bw = adam_bias(p.grads[p.b_off + n], bm, bv, bw, pa0, pa1, ak);
+      p.params[p.b_off + n] = bw; p.m1[p.b_off + n] = bm; p.m2[p.b_off + n] = bv;
+    }
+    biasl[tid] = bw; biasl[32 + tid] = bm; biasl[64 + tid] = bv;
   }
   for (int idx = tid; idx < (p.FR - B) * kPitch; idx += kPT) Fl[B * kPitch + idx] = 0.f;
   const int DOP = p.FR + 4;
@@ -147,18 +189,19 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     float g = 0.f;
 #pragma unroll
     for (int q = 0; q < kPT / 32; ++q) g += bpart[q * 32 + n];
-    const float bm = biasl[32 + n] + (g - biasl[32 + n]) * ob1;
-    const float bv = biasl[64 + n] * b2f + ob2 * g * g;
+    float bm = biasl[32 + n], bv = biasl[64 + n];
+    biasl[n] = adam_bias(g, bm, bv, biasl[n], a0, a1, ak);
     biasl[32 + n] = bm;
     biasl[64 + n] = bv;
-    biasl[n] = biasl[n] - a0 * (bm / (sqrtf(bv) * a1 + p.adam_eps));
   };
 
   // feature tile of the first update (later ones are fetched during the waits)
   BSIG_PF_LIST(BSIG_PF_DECL)
-  {
+  if (p.n_updates > 0) {
     const int64_t pf_row0 = (int64_t)step0 * B;
     BSIG_PF_LIST(BSIG_PF_LOAD)
+  } else {
+    BSIG_PF_LIST(BSIG_PF_ZERO)
   }
   __syncthreads();
 
@@ -281,33 +324,46 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, f2, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, f3, acc, 0, 0, 0);
       }
+      if (dp) {
+        // this rank's share of the gradient: summed over the ranks by the caller
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float g = acc[i];
-        const float m = Mr[i] + (g - Mr[i]) * ob1;
-        const float v = Vr[i] * b2f + ob2 * g * g;
-        Mr[i] = m; Vr[i] = v;
-        float* wp = Wl + acc_row(i, h_l) * kPitch + kcol_l;
-        // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences
-        *wp = *wp - a0 * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * a1 + p.adam_eps));
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + acc_row(i, h_l);
+          if (n < Nh) p.grads[p.w_off + (int64_t)n * p.Fdim + k0 + kcol_l] = acc[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float* wp = Wl + acc_row(i, h_l) * kPitch + kcol_l;
+          *wp = adam_weight(acc[i], Mr[i], Vr[i], *wp, a0, a1, ak);
+        }
       }
     }
-    bias_pending = ks == 0;
+    bias_pending = ks == 0 && !dp;
     __syncthreads();
+    if (dp && ks == 0 && tid_l < kNB && n0 + tid_l < Nh) {
+      float g = 0.f;
+#pragma unroll
+      for (int q = 0; q < kPT / 32; ++q) g += bpart[q * 32 + tid_l];
+      p.grads[p.b_off + n0 + tid_l] = g;
+    }
     BSIG_STAMP(12);
   }
 
   // ---- write the tile back, advance the engine state -------------------------
+  const bool dirty = !dp;
+  if (dirty) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int n = n0 + acc_row(i, h);
-    if (n < Nh) {
-      const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
-      p.params[off] = Wl[acc_row(i, h) * kPitch + kcol]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + acc_row(i, h);
+      if (n < Nh) {
+        const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
+        p.params[off] = Wl[acc_row(i, h) * kPitch + kcol]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+      }
     }
   }
   if (bias_pending && tid < kNB) bias_step(tid);
-  if (ks == 0 && tid < kNB && n0 + tid < Nh) {
+  if (dirty && ks == 0 && tid < kNB && n0 + tid < Nh) {
     p.params[p.b_off + n0 + tid] = biasl[tid];
     p.m1[p.b_off + n0 + tid] = biasl[32 + tid];
     p.m2[p.b_off + n0 + tid] = biasl[64 + tid];
@@ -446,9 +502,11 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
   }
 }
 
+// DP: data-parallel rank (gradients out, pending Adam step in; see PersistArgs)
+template <bool DP>
 __global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x < p.G) tile_workgroup(p, smem);
+  if ((int)blockIdx.x < p.G) tile_workgroup<DP>(p, smem);
   else owner_workgroup(p, smem);
 }
 
@@ -481,8 +539,10 @@ static bool persist_geom(const PersistShape& s, PersistGeom* g) {
   g->x_floats = (int)round_up(std::max(std::max(128 * kPbufPitch, kNB * (g->FR + 4)),
                                        (kPT / 64) * per_wave), 4);
   g->lds = ((size_t)g->FR * kPitch + (size_t)kNB * kPitch + g->x_floats + 64 + 96 + (kPT / 32) * 32) * sizeof(float);
-  // the forward reads feature rows up to 127 (results of rows >= batch are dropped)
-  if ((size_t)128 * kPitch * sizeof(float) > g->lds || g->lds > (size_t)kLdsLimit) return false;
+  // the forward reads feature rows up to 127 (results of rows >= batch are dropped):
+  // small minibatches get an allocation that covers those reads
+  g->lds = std::max(g->lds, (size_t)128 * kPitch * sizeof(float));
+  if (g->lds > (size_t)kLdsLimit) return false;
   g->slab_floats = (size_t)g->k_slices * s.batch * g->NhP;
   g->dout_floats = (size_t)s.batch * g->NhP;
   return true;
@@ -537,10 +597,14 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
                "persistent updates: workspace too small");
   BSIG_REQUIRE(b.ld_feats % 4 == 0 && aligned(b.feats, 16) && b.ld_feats >= s.feat_dim,
                "persistent updates: features must be 16-byte aligned rows");
-  if (n <= 0) return BSIG_OK;
+  BSIG_REQUIRE(!(b.adam_pending && !b.grads), "persistent updates: pending Adam step without gradients");
+  BSIG_REQUIRE(!(b.grads && n > 1), "persistent updates: data-parallel launches take one update");
+  if (n <= 0 && !b.adam_pending) return BSIG_OK;
   static bool attr_set = false;
   if (!attr_set) {
-    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_head_updates_kernel),
+    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_head_updates_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_head_updates_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
     attr_set = true;
   }
@@ -548,7 +612,8 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.B = s.batch; p.FR = g.FR; p.Fdim = s.feat_dim; p.Nh = g.Nh; p.NhP = g.NhP;
   p.D = s.out_dim; p.K = s.n_comp;
   p.n_blocks = g.n_blocks; p.k_slices = g.k_slices; p.G = g.G; p.n_owner = g.n_owner; p.R = g.R;
-  p.n_updates = n; p.x_floats = g.x_floats;
+  p.n_updates = std::max(n, 0); p.x_floats = g.x_floats;
+  p.grads = b.grads; p.adam_pending = b.adam_pending;
   p.feats = b.feats; p.ld_feats = b.ld_feats; p.feat_ids = b.feat_ids; p.y = b.y; p.ldy = b.ldy; p.ids = b.ids;
   p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq; p.w_off = b.w_off; p.b_off = b.b_off;
   p.state = b.state; p.train_loss = b.train_loss;
@@ -563,7 +628,13 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.flag_fwd = reinterpret_cast<unsigned*>(sync);
   p.gran = reinterpret_cast<unsigned long long*>(sync + kXwgMax * sizeof(unsigned));
   p.prof = g_prof;
-  hipLaunchKernelGGL(linear_head_updates_kernel, dim3(g.G + g.n_owner), dim3(kPT), g.lds, st, p);
+  // (a pending-Adam-only launch needs the tile workgroups only)
+  if (b.grads)
+    hipLaunchKernelGGL(linear_head_updates_kernel<true>, dim3(n > 0 ? g.G + g.n_owner : g.G),
+                       dim3(kPT), g.lds, st, p);
+  else
+    hipLaunchKernelGGL(linear_head_updates_kernel<false>, dim3(g.G + g.n_owner), dim3(kPT), g.lds,
+                       st, p);
   BSIG_CHECK_LAUNCH("linear_head_updates");
   return BSIG_OK;
 }

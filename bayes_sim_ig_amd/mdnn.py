@@ -457,6 +457,7 @@ class MDNN(nn.Module):
                 allreduce=lambda: self._dp.allreduce_sum(self._flat_grad),
                 apply=lambda: _lib.check(lib.bsig_fit_apply(self._plan, st)),
                 evaluate=lambda: _lib.check(lib.bsig_fit_eval(self._plan, st)))
+            _lib.check(lib.bsig_fit_flush(self._plan, st))
         # single read-back per call: 6+6 losses and the isfinite flag
         tl = train_loss[:n_updates]
         te = test_loss[:len(eval_its)]

@@ -224,15 +224,27 @@ def time_update_kernel(pkg, cfg, bsim, device):
             runs.append(it + 1 - done)
             done = it + 1
     total_ms, launches = 0.0, 0
+    dp = m._dp is not None
+    if dp:
+        # data-parallel rank: one launch per update (gradients out; the Adam step on
+        # the reduced gradients is taken by the next launch); the all-reduce between
+        # the launches is not part of the kernel's time
+        runs = [1] * n_updates
     for rep in range(6):
-        L.check(lib.bsig_fit_begin(plan, 1234 + rep, batch, st))
+        L.check(lib.bsig_fit_begin(plan, 1234 + rep, batch * (m._dp.world if dp else 1), st))
         evs = []
         for n in runs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            L.check(lib.bsig_fit_updates(plan, n, st))
+            if dp:
+                L.check(lib.bsig_fit_grad(plan, st))
+                L.check(lib.bsig_fit_apply(plan, st))
+            else:
+                L.check(lib.bsig_fit_updates(plan, n, st))
             e1.record(stream)
             evs.append((e0, e1))
+        if dp:
+            L.check(lib.bsig_fit_flush(plan, st))
         torch.cuda.synchronize()
         if rep == 0:
             continue                                  # warm-up
@@ -244,13 +256,16 @@ def time_update_kernel(pkg, cfg, bsim, device):
     per_visit = 2.0 * 2.0 * f_in * nh                 # SURVEY 8(d) K6+K7, MDRFF heads: fwd + dW
     flops = per_visit * batch * (float(n_updates) / len(runs))
     ach = flops / (us * 1e-6) / 1e12
-    traffic, tsrc = pmc_traffic('linear_head_updates_kernel')
+    traffic, tsrc = pmc_traffic('linear_head_updates_kernel') if not dp else (None, None)
     return {'bound': 'mfma',
             'kernel': 'linear_head_updates_kernel: persistent update kernel, heads %dx%d on cached '
                       'RFF features, minibatch %d, %s updates per launch (mean %.1f): forward '
-                      'product, NLL fwd/bwd, dW, Adam' % (nh, f_in, batch,
-                                                          '/'.join(str(r) for r in runs),
-                                                          float(n_updates) / len(runs)),
+                      'product, NLL fwd/bwd, dW, Adam%s'
+                      % (nh, f_in, batch, '/'.join(str(r) for r in runs) if not dp else '1',
+                         float(n_updates) / len(runs),
+                         ' (data-parallel rank: gradients written for the all-reduce, Adam step of '
+                         'the previous update taken from the reduced gradients while the weight '
+                         'tiles are loaded)' if dp else ''),
             'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
             'traffic': traffic, 'traffic_source': tsrc, 'avg_us': us,
             'us_per_update': us * len(runs) / n_updates,
@@ -405,6 +420,8 @@ def main():
     pkg._lib.require_gpu()
     pkg.MDNN.VERBOSE = False
     pkg.MDNN.USE_GRAPH = not args.no_graph
+    if os.environ.get('BENCH_SHARE_GPU') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
     dist = None
@@ -413,8 +430,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device(device))
+        # BENCH_BACKEND=gloo BENCH_SHARE_GPU=1: several ranks on ONE GPU (a functional
+        # check of the multi-rank path on a 1-GPU box; RCCL refuses two ranks per device)
+        backend = os.environ.get('BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = dict(CONFIGS[args.config])
     n = args.pairs or cfg['pairs']
@@ -466,7 +489,9 @@ def main():
                                100, ' per rank (global %d, grad all-reduce)' % (100 * world)
                                if world > 1 else ''),
                 'pairs_per_gpu': n, 'parallelism': 'dp%d' % world,
-                'gradient_exchange': 'rccl all-reduce' if dist is not None else 'none',
+                'gradient_exchange': ('rccl all-reduce' if os.environ.get('BENCH_BACKEND', 'nccl') == 'nccl'
+                                      else os.environ['BENCH_BACKEND'] + ' all-reduce (functional check)')
+                if dist is not None else 'none',
                 'hip_graph': not args.no_graph},
             'sgd_visits_per_sec': value * 10.0,
             'heldout_nll_last_step_mean': final_test,
@@ -510,10 +535,15 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(cfg, theta[:12000], states[:12000],
                                                    actions[:12000])
                 out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner
+        # through C stdio, which would otherwise be flushed after it at exit
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -267,10 +267,19 @@ int bsig_fit_run(bsig_fit_plan* plan, int64_t n_updates, bsig_stream_t stream);
  * n_updates replays of the update graph.  bsig_fit_run = runs of these between
  * the held-out evaluations. */
 int bsig_fit_updates(bsig_fit_plan* plan, int64_t n_updates, bsig_stream_t stream);
-/* Data-parallel pieces (BSIG_FIT_SPLIT_ADAM): gradient only (all-reduce
- * `grads` outside), then the flat Adam step. */
+/* Data-parallel pieces (BSIG_FIT_SPLIT_ADAM; mdnn.py:229-233 with the exchange
+ * the reference does not have between loss.backward() and optimizer.step()):
+ * bsig_fit_grad = forward + NLL + backward of one minibatch into `grads`
+ * (all-reduce `grads` outside), bsig_fit_apply = the Adam step on `grads`.
+ * Plans covered by the persistent update kernel run an update as ONE launch:
+ * bsig_fit_apply then only marks the step as pending and the next bsig_fit_grad
+ * takes it while it loads its weight tiles; bsig_fit_eval takes a pending step
+ * first, bsig_fit_flush takes it at once (call it before reading `params`). */
 int bsig_fit_grad(bsig_fit_plan* plan, bsig_stream_t stream);
 int bsig_fit_apply(bsig_fit_plan* plan, bsig_stream_t stream);
+int bsig_fit_flush(bsig_fit_plan* plan, bsig_stream_t stream);
+/* 1 when the plan's updates run in the persistent update kernel (diagnostics / tests). */
+int bsig_fit_is_persistent(const bsig_fit_plan* plan);
 int bsig_fit_eval(bsig_fit_plan* plan, bsig_stream_t stream);
 
 /* Diagnostics: device buffer of [256][8][16] int64 wall-clock stamps filled by the

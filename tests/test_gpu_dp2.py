@@ -26,42 +26,47 @@ def _data(rank):
     return x, y, ids
 
 
-def _model(pkg):
+def _model(pkg, n_feat):
     torch.manual_seed(3)
     np.random.seed(3)
     pkg.MDNN.VERBOSE = False
     pkg.MDNN.EPS_NOISE = 0.0
     return pkg.MDRFF(input_dim=I, output_dim=D, output_lows=np.zeros(D), output_highs=np.ones(D),
                      n_gaussians=K, lr=2e-3, activation=torch.nn.Tanh, full_covariance=False,
-                     n_feat=64, sigma=3.0, device='cuda:0')
+                     n_feat=n_feat, sigma=3.0, device='cuda:0')
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, n_feat):
     import sys
     sys.path.insert(0, ROOT)
     import bayes_sim_ig_amd as pkg
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    m = _model(pkg).enable_data_parallel()
+    m = _model(pkg, n_feat).enable_data_parallel()
     x, y, ids = _data(rank)
     logs = m.run_training(x.cuda(), y.cuda(), NU, B, test_frac=0.2, ids_table=ids)
     if rank == 0:
-        torch.save({'logs': logs, 'flat': m._flat.cpu()}, out)
+        torch.save({'logs': logs, 'flat': m._flat.cpu(),
+                    'persistent': int(pkg._lib.load().bsig_fit_is_persistent(m._plan))}, out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_fit_equals_union_minibatch(tmp_path):
+# 64 features: per-phase kernels; 512: every update one launch of the persistent
+# kernel per rank (gradients out, Adam step of the reduced gradients in)
+@pytest.mark.parametrize('n_feat', [64, 512])
+def test_two_rank_fit_equals_union_minibatch(tmp_path, n_feat):
     import bayes_sim_ig_amd as pkg
     out = str(tmp_path / 'dp2.pt')
-    mp.spawn(_worker, args=(2, 29600 + os.getpid() % 1000, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, 29600 + os.getpid() % 1000, out, n_feat), nprocs=2, join=True)
     res = torch.load(out)
+    assert res['persistent'] == (1 if n_feat == 512 else 0)
     (x0, y0, i0), (x1, y1, i1) = _data(0), _data(1)
     # single process: [train0; train1; test0; test1], minibatch = both ranks' rows
     x = torch.cat([x0[:N_TRAIN], x1[:N_TRAIN], x0[N_TRAIN:], x1[N_TRAIN:]])
     y = torch.cat([y0[:N_TRAIN], y1[:N_TRAIN], y0[N_TRAIN:], y1[N_TRAIN:]])
     ids = np.concatenate([i0, i1 + N_TRAIN], axis=1)
-    m = _model(pkg)
+    m = _model(pkg, n_feat)
     logs = m.run_training(x.cuda(), y.cuda(), NU, 2 * B, test_frac=0.2, ids_table=ids)
     pkg.MDNN.EPS_NOISE = 1e-5
     np.testing.assert_allclose(res['logs']['train_loss'], logs['train_loss'], rtol=2e-5, atol=1e-6)

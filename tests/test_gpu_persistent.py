@@ -130,6 +130,9 @@ def test_persistent_ragged_shapes_match_phase_kernels(B, n, batch, n_updates):
     a = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=1e-5)
     b = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=1e-5,
                env={'BSIG_NO_PERSISTENT': '1'})
+    lib = B._lib.load()
+    assert lib.bsig_fit_is_persistent(a[2].model._plan) == 1
+    assert lib.bsig_fit_is_persistent(b[2].model._plan) == 0
     for key in ('train_loss', 'test_loss'):
         assert len(a[0][key]) == len(b[0][key])
         assert np.allclose(a[0][key], b[0][key], rtol=2e-5, atol=2e-5), (key, a[0], b[0])
@@ -170,3 +173,36 @@ def test_nonfinite_features_raise_through_persistent_path(B):
     ids[0, 0] = 5
     with pytest.raises(AssertionError):
         bs.model.run_training(bs._summarize(states, actions), theta, 100, 100, ids_table=ids)
+
+
+@pytest.mark.parametrize('eps', [0.0, 1e-5])
+def test_data_parallel_rank_in_persistent_kernel_is_bitwise(B, eps):
+    """A data-parallel rank runs each update as ONE launch of the persistent
+    kernel (gradients out -> all-reduce -> the Adam step taken by the next launch
+    while it loads its tiles).  On a 1-rank group that is the same arithmetic as
+    the resident single-rank run: weights and losses bitwise equal."""
+    import torch.distributed as dist
+    cfg = _cfg(4, 6, 512)
+    logs_p, flat_p, bs_p, _ = _chunk(B, cfg, eps=eps)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29578')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        import bench
+        B.MDNN.EPS_NOISE = eps
+        theta, states, actions = bench.synth_pairs(cfg, 1000, 3, DEV)
+        bs = bench.build_gpu_model(B, cfg, DEV, 77)
+        bs.model.enable_data_parallel()
+        ids = np.random.RandomState(5).randint(0, 800, (100, 100))
+        logs_d = bs.model.run_training(bs._summarize(states, actions), theta, 100, 100,
+                                       ids_table=ids)
+        flat_d = bs.model._flat.clone()
+        lib = B._lib.load()
+        assert lib.bsig_fit_is_persistent(bs.model._plan) == 1
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert logs_d == logs_p
+    assert torch.equal(flat_d, flat_p)
