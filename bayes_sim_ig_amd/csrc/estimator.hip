@@ -29,6 +29,7 @@
 #include "gemm.h"
 #include "head.h"
 #include "persist.h"
+#include "persist_mdnn.h"
 
 #include <algorithm>
 #include <cmath>
@@ -354,6 +355,7 @@ struct bsig_fit_plan {
   size_t train_ws_bytes, test_ws_bytes, feats_bytes, big_gemm_ws_bytes, iota_bytes;
   bool use_graph, split_adam;
   bool persistent;             // updates run in the persistent kernel (persist.h)
+  bool persistent_mdnn;        // single-rank MDNN [128, 128] updates: fit_persistent_mdnn.hip
   bool adam_pending;           // ... data-parallel: the Adam step on the reduced gradients is
                                // taken by the next launch (or flushed before an evaluation)
   size_t persist_bytes;
@@ -410,6 +412,34 @@ static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st) {
   hy.min_weight = p->cfg.head.min_weight; hy.ll_limit = p->cfg.head.ll_limit;
   hy.norm_batch = p->norm_batch;
   return persist_run(persist_shape(p), pb, hy, n, st);
+}
+
+static PersistMdnnShape persist_mdnn_shape(const bsig_fit_plan* p) {
+  const bsig_mdn_cfg& c = p->cfg;
+  return PersistMdnnShape{(int)p->batch, c.input_dim, c.n_hidden > 0 ? c.hidden[0] : 0,
+                          c.n_hidden > 1 ? c.hidden[1] : 0, c.activation, c.head.out_dim,
+                          c.head.n_comp, c.head.full_cov};
+}
+
+// n consecutive updates of the two-layer MDNN in its persistent kernel
+static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st) {
+  PlanMem m; plan_mem(p, &m);
+  const bsig_fit_buffers& b = p->buf;
+  PersistMdnnBuffers pb;
+  pb.x = b.x_train; pb.ldx = b.ldx_train; pb.ids = b.ids_table;
+  pb.y = b.y_train; pb.ldy = b.ldy_train;
+  pb.params = b.params; pb.exp_avg = b.exp_avg; pb.exp_avg_sq = b.exp_avg_sq;
+  pb.w1_off = p->L.w_off[0]; pb.b1_off = p->L.b_off[0];
+  pb.w2_off = p->L.w_off[1]; pb.b2_off = p->L.b_off[1];
+  pb.wh_off = p->L.head_w_off; pb.bh_off = p->L.head_b_off;
+  pb.state = b.state; pb.train_loss = b.train_loss;
+  pb.workspace = m.persist_ws; pb.workspace_bytes = p->persist_bytes;
+  PersistHyper hy;
+  hy.lr = p->cfg.lr; hy.beta1 = p->cfg.beta1; hy.beta2 = p->cfg.beta2;
+  hy.adam_eps = p->cfg.adam_eps; hy.eps_noise = p->cfg.head.eps_noise;
+  hy.min_weight = p->cfg.head.min_weight; hy.ll_limit = p->cfg.head.ll_limit;
+  hy.norm_batch = p->norm_batch;
+  return persist_mdnn_run(persist_mdnn_shape(p), pb, hy, n, st);
 }
 
 static Inputs train_inputs(const bsig_fit_plan* p, const PlanMem& m) {
@@ -539,8 +569,8 @@ static int ensure_graphs(bsig_fit_plan* p) {
       BSIG_TRY(capture(p, &p->g_grad, [&](hipStream_t s) { return enqueue_grad(p, s, false); }));
       BSIG_TRY(capture(p, &p->g_apply, [&](hipStream_t s) { return enqueue_apply(p, s); }));
     }
-  } else if (p->persistent) {
-    // updates are single launches of the persistent kernel: no update graph
+  } else if (p->persistent || p->persistent_mdnn) {
+    // updates are single launches of a persistent kernel: no update graph
   } else {
     BSIG_TRY(capture(p, &p->g_step, [&](hipStream_t s) { return enqueue_grad(p, s, true); }));
   }
@@ -658,6 +688,11 @@ extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t m
                   !(no_persist && no_persist[0] == '1') && persist_supported(persist_shape(p));
   if (p->persistent)
     p->persist_bytes = round_up<size_t>(persist_workspace_bytes(persist_shape(p)), 256);
+  p->persistent_mdnn = cfg->rff_feats == 0 && p->L.n_layers == 2 && n_updates > 0 &&
+                       !(no_persist && no_persist[0] == '1') &&
+                       persist_mdnn_supported(persist_mdnn_shape(p));
+  if (p->persistent_mdnn)
+    p->persist_bytes = round_up<size_t>(persist_mdnn_workspace_bytes(persist_mdnn_shape(p)), 256);
   if (p->hoist) {
     p->feats_bytes = round_up<size_t>(feats, 256);
     const int64_t mf = cfg->rff_cos_only ? cfg->rff_feats : cfg->rff_feats / 2;
@@ -725,6 +760,10 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
     PlanMem m; plan_mem(p, &m);
     BSIG_TRY(persist_reset(persist_shape(p), m.persist_ws, p->persist_bytes, st));
   }
+  if (p->persistent_mdnn) {
+    PlanMem m; plan_mem(p, &m);
+    BSIG_TRY(persist_mdnn_reset(persist_mdnn_shape(p), m.persist_ws, p->persist_bytes, st));
+  }
   // fresh optimizer state for every run_training call (mdnn.py:203)
   BSIG_HIP(hipMemsetAsync(p->buf.exp_avg, 0, (size_t)p->L.total * sizeof(float), st));
   BSIG_HIP(hipMemsetAsync(p->buf.exp_avg_sq, 0, (size_t)p->L.total * sizeof(float), st));
@@ -748,7 +787,11 @@ extern "C" int bsig_fit_apply(bsig_fit_plan* p, bsig_stream_t stream) {
   return enqueue_apply(p, as_stream(stream));
 }
 
-extern "C" int bsig_fit_is_persistent(const bsig_fit_plan* p) { return p && p->persistent ? 1 : 0; }
+extern "C" int bsig_fit_is_persistent(const bsig_fit_plan* p) {
+  if (!p) return 0;
+  if (p->persistent) return 1;
+  return p->persistent_mdnn && !p->split_adam ? 2 : 0;
+}
 
 extern "C" int bsig_fit_flush(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound, "fit_flush: plan not bound");
@@ -769,6 +812,7 @@ extern "C" int bsig_fit_eval(bsig_fit_plan* p, bsig_stream_t stream) {
 static int enqueue_updates(bsig_fit_plan* p, int64_t n, hipStream_t st) {
   if (n <= 0) return BSIG_OK;
   if (p->persistent && !p->split_adam) return enqueue_persistent(p, (int)n, st);
+  if (p->persistent_mdnn && !p->split_adam) return enqueue_persistent_mdnn(p, (int)n, st);
   if (p->persistent) {   // data-parallel plan driven without an exchange (one rank)
     for (int64_t it = 0; it < n; ++it) {
       BSIG_TRY(enqueue_persistent(p, 1, st));

@@ -34,6 +34,7 @@
 #include <algorithm>
 
 #include "head_device.h"
+#include "persist_device.h"
 
 namespace bsig {
 
@@ -71,35 +72,6 @@ constexpr int kProfUpdates = 8;
     if (p.prof && threadIdx.x == 0 && t < kProfUpdates)                                    \
       p.prof[((int64_t)wg * kProfUpdates + t) * 16 + (k)] = wall_clock64();        \
   } while (0)
-
-__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
-
-// One Adam step of a weight element / a bias element.  Written with explicit
-// fused operations so that every call site (the resident run, a data-parallel
-// rank's pending step) rounds identically whatever the surrounding code.
-struct AdamK { float ob1, b2f, ob2, eps; };
-__device__ __forceinline__ float adam_weight(float g, float& m, float& v, float w, float a0,
-                                             float a1, const AdamK& k) {
-  m = __builtin_fmaf(g - m, k.ob1, m);
-  v = __builtin_fmaf(k.ob2 * g, g, v * k.b2f);
-  // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences
-  const float r = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_sqrtf(v), a1, k.eps));
-  return __builtin_fmaf(-a0, m * r, w);
-}
-__device__ __forceinline__ float adam_bias(float g, float& m, float& v, float w, float a0,
-                                           float a1, const AdamK& k) {
-  m = __builtin_fmaf(g - m, k.ob1, m);
-  v = __builtin_fmaf(k.ob2 * g, g, v * k.b2f);
-  return __builtin_fmaf(-a0, m / __builtin_fmaf(sqrtf(v), a1, k.eps), w);
-}
-
-// workgroup-uniform test of the time-out bit (set by any bounded poll on the chip)
-__device__ __forceinline__ bool run_aborted(int32_t* flagp, float* red, int tid) {
-  if (tid == 0)
-    red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
-  __syncthreads();
-  return red[63] != 0.f;
-}
 
 // one [<=104, 256] feature tile = 13 float4 per thread, kept in named registers
 // between the prefetch and the LDS write (an indexed array lands in scratch)

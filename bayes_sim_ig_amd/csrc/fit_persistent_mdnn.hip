@@ -1,0 +1,831 @@
+// Persistent update kernel for the MDNN estimator with the reference's default
+// trunk (hidden_layers [128, 128], tanh, diagonal covariance): a run of
+// consecutive SGD updates (MDNN.run_training's inner loop, mdnn.py:219-233:
+// forward :89-125, NLL :127-178, backward, Adam :203/:229) in ONE launch.
+//
+// As separate kernels an update is ~15 launches of 9-18 us each (two trunk GEMMs
+// with split-K reduces, head GEMM, NLL, finish, three dX GEMMs, three dW+Adam
+// GEMMs, bias column sums).  Here three kinds of workgroups (512 threads, one per
+// CU) keep the model resident and hand each other activations through
+// write-through stores and flags (see fit_persistent.hip for the mechanism):
+//
+//  * tile workgroups (4 x ceil(I/256)): own the 32 x 256 tile W1[32nb.., 256ks..]
+//    of the first layer (weights in LDS, both Adam moments in registers, MFMA
+//    accumulator layout).  Per update: gather their [B, 256] slice of the
+//    minibatch summaries into LDS, partial product X_slice W1_tile^T (fp32 MFMA
+//    32x32x2) -> split-K slab; later dW1_tile = dz1^T X_slice and Adam.
+//  * row-owner workgroups (ceil(B/8)): own 8 minibatch rows.  Sum the k-slices
+//    (+b1, tanh) -> h1; h2 = tanh(h1 W2^T + b2); head outputs; the row-wise
+//    mixture NLL forward/backward (diag_row, one wavefront per row); dz2 = (d_out
+//    Wh) * (1 - h2^2); dz1 = (dz2 W2) * (1 - h1^2).  The four small products run
+//    on the MFMA units (fp32 16x16x4) with W2 in registers (both operand layouts)
+//    and the head matrix in LDS (XOR-swizzled rows, conflict-free for both
+//    directions), refreshed once per update.
+//  * small-weight workgroups (4 + ceil(Nh/32)): own 32 rows of W2 or of the head
+//    matrix with their Adam moments in registers: dW = d^T h over the minibatch
+//    (MFMA 32x32x2), Adam, rows written through for the owners' next refresh.
+//
+// Per update: tiles -> (slabs) -> owners -> (dz1 | h1, h2, dz2, d_out) -> tiles |
+// small-weight workgroups -> (W2, Wh) -> owners of the next update.  Every sum
+// across workgroups is taken in a fixed order: runs are bitwise reproducible.
+#include "persist_mdnn.h"
+
+#include <algorithm>
+
+#include "persist.h"
+#include "persist_device.h"
+
+namespace bsig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMT = 512;            // threads per workgroup (8 wavefronts)
+constexpr int kMC = 256;            // first-layer input columns per tile workgroup
+constexpr int kMPitch = kMC + 4;    // LDS row pitch of the summary / weight tiles
+constexpr int kMNB = 32;            // weight rows per tile / small-weight workgroup
+constexpr int kMH = 128;            // hidden width (both layers)
+constexpr int kMHP = kMH + 4;       // LDS pitch of a 128-wide activation row
+constexpr int kMR = 8;              // minibatch rows per owner workgroup
+constexpr int kMPbuf = 33;
+constexpr int kMLdsLimit = 160 * 1024;
+
+struct MdnnArgs {
+  int B, FR, I, Nh, Nh16, NhP, D, K;
+  int k_slices, G1, n_owner, n_small;
+  int n_updates, x_floats;
+  const float* x; int64_t ldx; const int32_t* ids;
+  const float* y; int64_t ldy;
+  float* params; float* m1; float* m2;
+  int64_t w1_off, b1_off, w2_off, b2_off, wh_off, bh_off;
+  int32_t* state; float* train_loss;
+  double lr, beta1, beta2;
+  float adam_eps, eps_noise, min_w, ll_limit, inv_norm;
+  // exchange area (written through, read around the L2)
+  float* slabs;   // [k_slices][B][128] first-layer partial products
+  float* dz1;     // [B][128]   owners -> tiles
+  float* h1;      // [B][128]   owners -> small-weight workgroups (W2 blocks)
+  float* h2;      // [B][128]   ... (head blocks)
+  float* dz2;     // [B][128]   ... (W2 blocks)
+  float* d_out;   // [B][NhP]   ... (head blocks)
+  unsigned* flag_fwd; unsigned* flag_own; unsigned* flag_small; unsigned long long* gran;
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// one [<=104, 256] summary tile = 13 float4 per thread in named registers
+#define BSIG_MPF_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#define BSIG_MPF_DECL(u) float4 pf##u;
+#define BSIG_MPF_LOAD(u)                                                                    \
+  {                                                                                         \
+    const int idx = min((u) * kMT + tid, nvec - 1);                                         \
+    const int64_t fr = (int64_t)p.ids[pf_row0 + (idx >> 6)];                                \
+    const int64_t col = min((int64_t)k0 + (idx & 63) * 4, p.ldx - 4);                       \
+    pf##u = *reinterpret_cast<const float4*>(p.x + fr * p.ldx + col);                       \
+  }
+// columns >= I (row padding, the tail of the last k-slice) enter as zeros
+#define BSIG_MPF_STORE(u)                                                                   \
+  {                                                                                         \
+    const int idx = (u) * kMT + tid;                                                        \
+    if (idx < nvec) {                                                                       \
+      const int col = k0 + (idx & 63) * 4;                                                  \
+      float4 v = pf##u;                                                                     \
+      v.x = col + 0 < p.I ? v.x : 0.f; v.y = col + 1 < p.I ? v.y : 0.f;                     \
+      v.z = col + 2 < p.I ? v.z : 0.f; v.w = col + 3 < p.I ? v.w : 0.f;                     \
+      *reinterpret_cast<float4*>(Fl + (idx >> 6) * kMPitch + (idx & 63) * 4) = v;           \
+    }                                                                                       \
+  }
+
+// ---- tile workgroups: first-layer partial products, dW1, Adam -------------------
+__device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* smem) {
+  float* Fl = smem;                          // [FR][kMPitch] minibatch summaries (this k-slice)
+  float* Wl = Fl + p.FR * kMPitch;           // [32][kMPitch] weight tile (authoritative copy)
+  float* X = Wl + kMNB * kMPitch;            // scratch: forward k-halves | dz1^T
+  float* red = X + p.x_floats;               // [64]
+  float* biasl = red + 64;                   // [3][32] b1, exp_avg, exp_avg_sq (k-slice 0)
+  float* bpart = biasl + 96;                 // [16][32] partial column sums of dz1 (k-slice 0)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wg = blockIdx.x, ks = wg % p.k_slices, nb = wg / p.k_slices;
+  const int n0 = nb * kMNB, k0 = ks * kMC;
+  const int B = p.B;
+  int32_t* flagp = p.state + 2;
+  const int step0 = p.state[0];
+  double b1t = reinterpret_cast<const double*>(p.state + 12)[0];
+  double b2t = reinterpret_cast<const double*>(p.state + 12)[1];
+  float a0 = 0.f, a1 = 0.f;
+  const AdamK ak{1.0f - (float)p.beta1, (float)p.beta2, 1.0f - (float)p.beta2, p.adam_eps};
+
+  float Mr[16], Vr[16];
+  const int kcol = 32 * w + l31;
+  const bool col_ok = k0 + kcol < p.I;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + acc_row(i, h);
+    float wv = 0.f;
+    Mr[i] = 0.f; Vr[i] = 0.f;
+    if (col_ok) {
+      const int64_t off = p.w1_off + (int64_t)n * p.I + k0 + kcol;
+      wv = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+    }
+    Wl[acc_row(i, h) * kMPitch + kcol] = wv;
+  }
+  if (ks == 0 && tid < kMNB) {
+    biasl[tid] = p.params[p.b1_off + n0 + tid];
+    biasl[32 + tid] = p.m1[p.b1_off + n0 + tid];
+    biasl[64 + tid] = p.m2[p.b1_off + n0 + tid];
+  }
+  for (int idx = tid; idx < (p.FR - B) * kMPitch; idx += kMT) Fl[B * kMPitch + idx] = 0.f;
+  const int DOP = p.FR + 4;
+  const int nvec = B * (kMC / 4);
+  bool bias_pending = false;
+  auto bias_step = [&](int n) {
+    float g = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMT / 32; ++q) g += bpart[q * 32 + n];
+    float bm = biasl[32 + n], bv = biasl[64 + n];
+    biasl[n] = adam_bias(g, bm, bv, biasl[n], a0, a1, ak);
+    biasl[32 + n] = bm;
+    biasl[64 + n] = bv;
+  };
+
+  BSIG_MPF_LIST(BSIG_MPF_DECL)
+  {
+    const int64_t pf_row0 = (int64_t)step0 * B;
+    BSIG_MPF_LIST(BSIG_MPF_LOAD)
+  }
+  __syncthreads();
+
+  for (int t = 0; t < p.n_updates; ++t) {
+    int tid_l = tid, l31_l = l31, h_l = h, kcol_l = kcol;
+    asm volatile("" : "+v"(tid_l), "+v"(l31_l), "+v"(h_l), "+v"(kcol_l));
+    const int step = step0 + t;
+    const unsigned epoch = (unsigned)step + 1u;
+    if (run_aborted(flagp, red, tid_l)) break;
+    // ---- 1. summary tile -> LDS ------------------------------------------------
+    BSIG_MPF_LIST(BSIG_MPF_STORE)
+    __syncthreads();
+
+    // ---- 2. partial forward: P[b, n] = sum_{k in slice} X[b, k] W1[n, k] ---------
+    {
+      const int mt = w & 3, kh = w >> 2;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = Fl + (mt * 32 + l31_l) * kMPitch + kh * 128 + 4 * h_l;
+      const float* bp = Wl + l31_l * kMPitch + kh * 128 + 4 * h_l;
+#pragma unroll 4
+      for (int kk = 0; kk < 128; kk += 8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      }
+      if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h_l)) * kMPbuf + l31_l] = acc[i];
+      }
+      if (bias_pending && w == kMT / 64 - 1 && lane < kMNB) bias_step(lane);
+      bias_pending = false;
+      __syncthreads();
+      if (kh == 0) {
+        const float bias = ks == 0 ? biasl[l31_l] : 0.f;
+        float* dst = p.slabs + (int64_t)ks * B * kMH + n0 + l31_l;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mt * 32 + acc_row(i, h_l);
+          const float v = acc[i] + X[row * kMPbuf + l31_l] + bias;
+          if (row < B) xwg_store(dst + (int64_t)row * kMH, v);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid_l == 0)
+        __hip_atomic_store(p.flag_fwd + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- while the owners work: next summary tile, Adam scalars ------------------
+    if (t + 1 < p.n_updates) {
+      const int64_t pf_row0 = (int64_t)(step + 1) * B;
+      BSIG_MPF_LIST(BSIG_MPF_LOAD)
+    }
+    b1t *= p.beta1; b2t *= p.beta2;
+    a0 = (float)(p.lr / (1.0 - b1t));
+    a1 = (float)(1.0 / sqrt(1.0 - b2t));
+
+    // ---- 3. dW1 = dz1^T X on this tile, Adam ---------------------------------------
+    if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
+    __syncthreads();
+    for (int base = 0; base < p.FR * kMNB; base += kMT * 8) {
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kMT + tid_l;
+        const int b = idx >> 5;
+        q[u] = (idx < p.FR * kMNB && b < B) ? xwg_load(p.dz1 + (int64_t)b * kMH + n0 + (idx & 31)) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kMT + tid_l;
+        if (idx < p.FR * kMNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u];
+      }
+    }
+    __syncthreads();
+    if (ks == 0) {                         // b1 of this block: column sums of dz1
+      const int n = tid_l & 31, part = tid_l >> 5;
+      float g = 0.f;
+      for (int b = part; b < B; b += kMT / 32) g += X[n * DOP + b];
+      bpart[part * 32 + n] = g;
+    }
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = X + l31_l * DOP + 4 * h_l;
+      const float* bp = Fl + (4 * h_l) * kMPitch + kcol_l;
+      for (int bb = 0; bb < p.FR; bb += 8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + bb);
+        const float f0 = bp[(bb + 0) * kMPitch], f1 = bp[(bb + 1) * kMPitch];
+        const float f2 = bp[(bb + 2) * kMPitch], f3 = bp[(bb + 3) * kMPitch];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, f0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, f1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, f2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, f3, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float* wp = Wl + acc_row(i, h_l) * kMPitch + kcol_l;
+        *wp = adam_weight(acc[i], Mr[i], Vr[i], *wp, a0, a1, ak);
+      }
+    }
+    bias_pending = ks == 0;
+    __syncthreads();
+  }
+
+  // ---- write the tile back, advance the engine state ---------------------------
+  if (col_ok) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + acc_row(i, h);
+      const int64_t off = p.w1_off + (int64_t)n * p.I + k0 + kcol;
+      p.params[off] = Wl[acc_row(i, h) * kMPitch + kcol]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+    }
+  }
+  if (bias_pending && tid < kMNB) bias_step(tid);
+  if (ks == 0 && tid < kMNB) {
+    p.params[p.b1_off + n0 + tid] = biasl[tid];
+    p.m1[p.b1_off + n0 + tid] = biasl[32 + tid];
+    p.m2[p.b1_off + n0 + tid] = biasl[64 + tid];
+  }
+  if (wg == 0 && tid == 0 && p.n_updates > 0) {
+    int32_t* st = p.state;
+    reinterpret_cast<double*>(st + 12)[0] = b1t;
+    reinterpret_cast<double*>(st + 12)[1] = b2t;
+    reinterpret_cast<float*>(st)[4] = a0;
+    reinterpret_cast<float*>(st)[5] = a1;
+    reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)p.n_updates;
+    st[0] = step0 + p.n_updates;
+  }
+}
+
+// ---- small-weight workgroups: 32 rows of W2 or of the head matrix ----------------
+__device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* smem) {
+  float* Hs = smem;                          // [FR][kMHP] input activations of the layer
+  float* X = Hs + p.FR * kMHP;               // [32][FR + 4] output gradients, transposed
+  float* red = X + kMNB * (p.FR + 4);        // [64]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int sb = blockIdx.x - p.G1 - p.n_owner;
+  const bool is_w2 = sb < kMH / kMNB;
+  const int n0 = (is_w2 ? sb : sb - kMH / kMNB) * kMNB;
+  const int nrows = is_w2 ? kMH : p.Nh;
+  const int64_t w_off = is_w2 ? p.w2_off : p.wh_off, b_off = is_w2 ? p.b2_off : p.bh_off;
+  const float* dsrc = is_w2 ? p.dz2 : p.d_out;
+  const int dpitch = is_w2 ? kMH : p.NhP;
+  const float* hsrc = is_w2 ? p.h1 : p.h2;
+  const int B = p.B, DOP = p.FR + 4;
+  int32_t* flagp = p.state + 2;
+  const int step0 = p.state[0];
+  double b1t = reinterpret_cast<const double*>(p.state + 12)[0];
+  double b2t = reinterpret_cast<const double*>(p.state + 12)[1];
+  const AdamK ak{1.0f - (float)p.beta1, (float)p.beta2, 1.0f - (float)p.beta2, p.adam_eps};
+
+  // waves 0-3: element i of lane (h, l31) of wave w <-> W[n0 + acc_row(i, h)][32w + l31]
+  float Wr[16], Mr[16], Vr[16];
+  const int kcol = 32 * (w & 3) + l31;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + acc_row(i, h);
+    Wr[i] = 0.f; Mr[i] = 0.f; Vr[i] = 0.f;
+    if (w < 4 && n < nrows) {
+      const int64_t off = w_off + (int64_t)n * kMH + kcol;
+      Wr[i] = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+    }
+  }
+  // wave 4, lanes 0-31: the 32 biases
+  const bool bias_lane = w == 4 && lane < kMNB && n0 + lane < nrows;
+  float bw = 0.f, bm = 0.f, bv = 0.f;
+  if (bias_lane) {
+    bw = p.params[b_off + n0 + lane]; bm = p.m1[b_off + n0 + lane]; bv = p.m2[b_off + n0 + lane];
+  }
+  for (int idx = tid; idx < (p.FR - B) * kMHP; idx += kMT) Hs[B * kMHP + idx] = 0.f;
+  __syncthreads();
+
+  for (int t = 0; t < p.n_updates; ++t) {
+    const int step = step0 + t;
+    const unsigned epoch = (unsigned)step + 1u;
+    if (run_aborted(flagp, red, tid)) break;
+    b1t *= p.beta1; b2t *= p.beta2;
+    const float a0 = (float)(p.lr / (1.0 - b1t));
+    const float a1 = (float)(1.0 / sqrt(1.0 - b2t));
+    if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
+    __syncthreads();
+    // activations [B, 128] (8-byte loads) and this block's gradient columns [B, 32]
+    for (int base = 0; base < B * (kMH / 2); base += kMT * 8) {
+      float2 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = min(base + u * kMT + tid, B * (kMH / 2) - 1);
+        q[u] = xwg_load2(hsrc + (int64_t)(idx >> 6) * kMH + (idx & 63) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kMT + tid;
+        if (idx < B * (kMH / 2))
+          *reinterpret_cast<float2*>(Hs + (idx >> 6) * kMHP + (idx & 63) * 2) = q[u];
+      }
+    }
+    for (int base = 0; base < p.FR * kMNB; base += kMT * 8) {
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kMT + tid;
+        const int b = idx >> 5, n = n0 + (idx & 31);
+        q[u] = (idx < p.FR * kMNB && b < B && n < nrows) ? xwg_load(dsrc + (int64_t)b * dpitch + n) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kMT + tid;
+        if (idx < p.FR * kMNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u];
+      }
+    }
+    __syncthreads();
+    if (w < 4) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = X + l31 * DOP + 4 * h;
+      const float* bp = Hs + (4 * h) * kMHP + kcol;
+      for (int bb = 0; bb < p.FR; bb += 8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + bb);
+        const float f0 = bp[(bb + 0) * kMHP], f1 = bp[(bb + 1) * kMHP];
+        const float f2 = bp[(bb + 2) * kMHP], f3 = bp[(bb + 3) * kMHP];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, f0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, f1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, f2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, f3, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + acc_row(i, h);
+        Wr[i] = adam_weight(acc[i], Mr[i], Vr[i], Wr[i], a0, a1, ak);
+        if (n < nrows) xwg_store(p.params + w_off + (int64_t)n * kMH + kcol, Wr[i]);
+      }
+    } else if (bias_lane) {
+      float g = 0.f;
+      for (int b = 0; b < B; ++b) g += X[lane * DOP + b];
+      bw = adam_bias(g, bm, bv, bw, a0, a1, ak);
+      xwg_store(p.params + b_off + n0 + lane, bw);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(p.flag_small + sb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + acc_row(i, h);
+    if (w < 4 && n < nrows) {
+      const int64_t off = w_off + (int64_t)n * kMH + kcol;
+      p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+    }
+  }
+  if (bias_lane) { p.m1[b_off + n0 + lane] = bm; p.m2[b_off + n0 + lane] = bv; }
+}
+
+// ---- row-owner workgroups: layers 2.., NLL forward / backward ---------------------
+__device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
+  const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
+  const int po = Nh16 + 4;                   // pitch of a head-output row
+  const int per_wave = D + 3 * K;
+  float* Whs = smem;                         // [Nh16][128], element (n, i) at n*128 + (i ^ 4(n & 15))
+  float* H1s = Whs + Nh16 * kMH;             // [8][kMHP]
+  float* H2s = H1s + kMR * kMHP;             // [8][kMHP]  h2, later dz2 in place
+  float* Os = H2s + kMR * kMHP;              // [8][po]    head outputs, later d_out in place
+  float* b2s = Os + kMR * po;                // [128]
+  float* bhs = b2s + kMH;                    // [Nh16]
+  float* wsc = bhs + Nh16;                   // [8][D + 3K] per-row scratch of diag_row
+  float* red = wsc + kMR * per_wave;         // [64]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c16 = lane & 15, g = lane >> 4, rowA = c16 & (kMR - 1);
+  const int o = blockIdx.x - p.G1;
+  const int r0 = o * kMR;
+  int32_t* flagp = p.state + 2;
+  const int step0 = p.state[0];
+  const uint64_t rng_seed = reinterpret_cast<const uint64_t*>(p.state + 8)[0];
+  const uint64_t rng_ctr0 = reinterpret_cast<const uint64_t*>(p.state + 8)[1];
+  HeadArgs a{};
+  a.D = D; a.K = K; a.Nh = Nh; a.batch = B; a.from_tuple = 0;
+  a.min_w = p.min_w; a.ll_limit = p.ll_limit; a.inv_norm = p.inv_norm;
+  a.eps_noise = p.eps_noise; a.seed = rng_seed; a.d_out = p.d_out;
+  const float norm = (float)B * (float)DK;
+  const int row = r0 + w;                    // wave w <-> minibatch row r0 + w in the row-wise phases
+  const bool active = row < B;
+  float* tile = Os + w * po;
+  float* yv = wsc + w * per_wave;
+  float* rk = yv + D;
+  float* lpk = rk + K;
+  float* dlg = lpk + K;
+  const float* W2 = p.params + p.w2_off;
+  const float* Wh = p.params + p.wh_off;
+  const int64_t zs = (int64_t)B * kMH;
+  // W2 as the B operand of both products, one column block of 16 per wave:
+  // w2f[4t + j] = W2[16w + c16][16t + 4g + j], w2b[4t + j] = W2[16t + 4g + j][16w + c16]
+  float w2f[32], w2b[32];
+
+  for (int t = 0; t < p.n_updates; ++t) {
+    const int step = step0 + t;
+    const unsigned epoch = (unsigned)step + 1u;
+    const uint32_t tag = epoch * 4u;
+    if (run_aborted(flagp, red, tid)) break;
+    // ---- weights of this update (written by the small-weight workgroups) ---------
+    if (w == 0) flags_wait(p.flag_small, p.n_small, epoch - 1u, lane, flagp);
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const float* src = W2 + (int64_t)(16 * w + c16) * kMH + 16 * tt + 4 * g;
+      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 2);
+      w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        w2b[4 * tt + j] = xwg_load(W2 + (int64_t)(16 * tt + 4 * g + j) * kMH + 16 * w + c16);
+    for (int base = 0; base < Nh16 * (kMH / 2); base += kMT * 8) {
+      float2 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kMT + tid;
+        const int n = idx >> 6;
+        q[u] = n < Nh ? xwg_load2(Wh + (int64_t)n * kMH + (idx & 63) * 2) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * kMT + tid;
+        const int n = idx >> 6, c2 = (idx & 63) * 2;
+        if (n < Nh16) *reinterpret_cast<float2*>(Whs + n * kMH + (c2 ^ (4 * (n & 15)))) = q[u];
+      }
+    }
+    if (tid < kMH) b2s[tid] = xwg_load(p.params + p.b2_off + tid);
+    for (int j = tid; j < Nh16; j += kMT) bhs[j] = j < Nh ? xwg_load(p.params + p.bh_off + j) : 0.f;
+    if (active) {      // target row
+      const int64_t yrow = p.ids[(int64_t)step * B + row];
+      for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
+    }
+    // ---- h1 = tanh(sum of the k-slices) (b1 rides on slice 0) -----------------------
+    if (w == 0) flags_wait(p.flag_fwd, p.G1, epoch, lane, flagp);
+    __syncthreads();
+    {
+      const int r = tid >> 6, c2 = (tid & 63) * 2;      // 8 rows x 64 column pairs
+      const bool ok = r0 + r < B;
+      const float* src = p.slabs + (int64_t)min(r0 + r, B - 1) * kMH + c2;
+      float vx = 0.f, vy = 0.f;
+      for (int z = 0; z < p.k_slices; z += 16) {
+        float2 q[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) q[u] = xwg_load2(src + (int64_t)min(z + u, p.k_slices - 1) * zs);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (z + u < p.k_slices) { vx += q[u].x; vy += q[u].y; }
+      }
+      vx = ok ? tanhf(vx) : 0.f; vy = ok ? tanhf(vy) : 0.f;
+      H1s[r * kMHP + c2] = vx; H1s[r * kMHP + c2 + 1] = vy;
+      if (ok) { xwg_store(p.h1 + (int64_t)(r0 + r) * kMH + c2, vx); xwg_store(p.h1 + (int64_t)(r0 + r) * kMH + c2 + 1, vy); }
+    }
+    __syncthreads();
+    // ---- h2 = tanh(h1 W2^T + b2): wave w -> columns 16w .. 16w+15 -------------------
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* ap = H1s + rowA * kMHP + 4 * g;
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+        acc = mfma16(a4.x, w2f[4 * tt + 0], acc);
+        acc = mfma16(a4.y, w2f[4 * tt + 1], acc);
+        acc = mfma16(a4.z, w2f[4 * tt + 2], acc);
+        acc = mfma16(a4.w, w2f[4 * tt + 3], acc);
+      }
+      if (g < 2) {
+        const int n = 16 * w + c16;
+        const float bias = b2s[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * g + r;
+          const float v = tanhf(acc[r] + bias);
+          H2s[rr * kMHP + n] = v;
+          if (r0 + rr < B) xwg_store(p.h2 + (int64_t)(r0 + rr) * kMH + n, v);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- head outputs = h2 Wh^T + bh: column blocks w, w+8, w+16 -----------------------
+    float eacc = 0.f;
+    for (int cb = w; cb * 16 < Nh16; cb += 8) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int n = 16 * cb + c16;
+      const float* ap = H2s + rowA * kMHP + 4 * g;
+      const float* bp = Whs + n * kMH;
+      const int sw = 4 * c16;                      // = 4 * (n & 15)
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + ((16 * tt + 4 * g) ^ sw));
+        acc = mfma16(a4.x, b4.x, acc);
+        acc = mfma16(a4.y, b4.y, acc);
+        acc = mfma16(a4.z, b4.z, acc);
+        acc = mfma16(a4.w, b4.w, acc);
+      }
+      if (g < 2) {
+        const float bias = bhs[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * g + r;
+          const float v = acc[r] + bias;
+          Os[rr * po + n] = v;
+          if (r0 + rr < B && n >= K + DK && n < K + 2 * DK) eacc += expf(v);
+        }
+      }
+    }
+    eacc = wave_sum_dpp(eacc);
+    if (lane == 0) red[w] = eacc;
+    __syncthreads();
+    if (tid == 0) {
+      float sx = 0.f;
+      for (int q = 0; q < kMT / 64; ++q) sx += red[q];
+      granule_publish(p.gran + o, tag + 1, sx);
+    }
+    // ---- row-wise NLL forward / backward (one wavefront per row) -----------------------
+    RowOut ro;
+    ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
+#pragma unroll
+    for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
+    a.stream_id = rng_ctr0 + (uint64_t)t;
+    diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg,
+             [&] {
+               return p.eps_noise != 0.f
+                          ? p.eps_noise * (granule_gather(p.gran, p.n_owner, tag + 1, lane, flagp) / norm)
+                          : 0.f;
+             },
+             ro);
+    {
+      const float uds_w = wave_sum_dpp(ro.uds);
+      if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float sl = 0.f, su = 0.f;
+      for (int q = 0; q < kMR; ++q) { sl += red[16 + q]; su += red[32 + q]; }
+      granule_publish(p.gran + kXwgMax + o, tag + 2, su);
+      granule_publish(p.gran + 2 * kXwgMax + o, tag + 3, sl);
+    }
+    // the jitter-scale gradient term d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
+    // needs the sum over the whole minibatch
+    {
+      float c = 0.f;
+      if (p.eps_noise != 0.f)
+        c = p.eps_noise / norm * granule_gather(p.gran + kXwgMax, p.n_owner, tag + 2, lane, flagp);
+      if (active) {
+        const int groups = 64 / K, TPR = groups * K;
+        const int k = lane % K, d0 = lane / K;
+        if (c != 0.f && lane < TPR) {
+#pragma unroll
+          for (int q = 0; q < kElemsPerLane; ++q) {
+            const int d = d0 + q * groups;
+            if (d < D) tile[K + DK + d * K + k] += c * ro.esg0[q];
+          }
+        }
+        for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
+        __builtin_amdgcn_wave_barrier();
+        float* dst = p.d_out + (int64_t)row * p.NhP;
+        for (int j = lane; j < Nh; j += 64) xwg_store(dst + j, tile[j]);
+      }
+    }
+    if (ro.bad) atomicOr(flagp, 1);
+    __syncthreads();
+    // ---- dz2 = (d_out Wh) * (1 - h2^2): wave w -> columns 16w .. 16w+15 ----------------
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int i = 16 * w + c16;
+      const float* ap = Os + rowA * po + 4 * g;
+      for (int tt = 0; tt * 16 < Nh16; ++tt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+        const float* bp = Whs + (16 * tt + 4 * g) * kMH;
+        // rows 16tt + 4g + j: (row & 15) = 4g + j
+        const float f0 = bp[0 * kMH + (i ^ (4 * (4 * g + 0)))];
+        const float f1 = bp[1 * kMH + (i ^ (4 * (4 * g + 1)))];
+        const float f2 = bp[2 * kMH + (i ^ (4 * (4 * g + 2)))];
+        const float f3 = bp[3 * kMH + (i ^ (4 * (4 * g + 3)))];
+        acc = mfma16(a4.x, f0, acc);
+        acc = mfma16(a4.y, f1, acc);
+        acc = mfma16(a4.z, f2, acc);
+        acc = mfma16(a4.w, f3, acc);
+      }
+      if (g < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * g + r;
+          const float hv = H2s[rr * kMHP + i];
+          const float v = acc[r] * (1.0f - hv * hv);
+          H2s[rr * kMHP + i] = v;            // same lane read h2 just above
+          if (r0 + rr < B) xwg_store(p.dz2 + (int64_t)(r0 + rr) * kMH + i, v);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- dz1 = (dz2 W2) * (1 - h1^2) -------------------------------------------------------
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int i = 16 * w + c16;
+      const float* ap = H2s + rowA * kMHP + 4 * g;
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+        acc = mfma16(a4.x, w2b[4 * tt + 0], acc);
+        acc = mfma16(a4.y, w2b[4 * tt + 1], acc);
+        acc = mfma16(a4.z, w2b[4 * tt + 2], acc);
+        acc = mfma16(a4.w, w2b[4 * tt + 3], acc);
+      }
+      if (g < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * g + r;
+          const float hv = H1s[rr * kMHP + i];
+          if (r0 + rr < B) xwg_store(p.dz1 + (int64_t)(r0 + rr) * kMH + i, acc[r] * (1.0f - hv * hv));
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(p.flag_own + o, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (o == 0 && w == 0) {
+      const float s = granule_gather(p.gran + 2 * kXwgMax, p.n_owner, tag + 3, lane, flagp);
+      if (lane == 0) {
+        const float l = -s / (float)B;
+        p.train_loss[step] = l;
+        if (!isfinite(l)) atomicOr(flagp, 1);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kMT) void mdnn_updates_kernel(MdnnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wg = blockIdx.x;
+  if (wg < p.G1) mdnn_tile_workgroup(p, smem);
+  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup(p, smem);
+  else mdnn_small_workgroup(p, smem);
+}
+
+// ---------------------------------------------------------------- host side
+struct MdnnGeom {
+  int FR, Nh, Nh16, NhP, k_slices, G1, n_owner, n_small, x_floats;
+  size_t lds;
+  size_t slab_floats, act_floats, dout_floats;
+};
+
+static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
+  if (s.batch < 1 || s.input_dim < 4 || s.h1 != kMH || s.h2 != kMH ||
+      s.activation != BSIG_ACT_TANH || s.full_cov != 0 || s.out_dim < 1 || s.n_comp < 1 ||
+      s.n_comp > 64)
+    return false;
+  const int groups = 64 / s.n_comp;
+  if (ceil_div(s.out_dim, groups) > kElemsPerLane) return false;
+  g->FR = (int)round_up(s.batch, 8);
+  if (g->FR > 104) return false;               // 13 float4 of the summary tile per thread
+  g->Nh = s.n_comp + 2 * s.out_dim * s.n_comp;
+  g->Nh16 = (int)round_up(g->Nh, 16);
+  g->NhP = (int)round_up(g->Nh, kMNB);
+  g->k_slices = ceil_div(s.input_dim, kMC);
+  g->G1 = (kMH / kMNB) * g->k_slices;
+  g->n_owner = ceil_div(s.batch, kMR);
+  g->n_small = kMH / kMNB + g->NhP / kMNB;
+  if (g->G1 > kXwgMax || g->G1 + g->n_owner + g->n_small > kXwgMax) return false;
+  g->x_floats = (int)round_up(std::max(128 * kMPbuf, kMNB * (g->FR + 4)), 4);
+  const size_t tile_lds = ((size_t)g->FR * kMPitch + (size_t)kMNB * kMPitch + g->x_floats + 64 + 96 +
+                           (kMT / 32) * 32) * sizeof(float);
+  const size_t owner_lds = ((size_t)g->Nh16 * kMH + 2 * kMR * kMHP + (size_t)kMR * (g->Nh16 + 4) + kMH +
+                            g->Nh16 + (size_t)kMR * (s.out_dim + 3 * s.n_comp) + 64) * sizeof(float);
+  const size_t small_lds = ((size_t)g->FR * kMHP + (size_t)kMNB * (g->FR + 4) + 64) * sizeof(float);
+  // the forward of the tile workgroups reads summary rows up to 127
+  g->lds = std::max(std::max(tile_lds, (size_t)128 * kMPitch * sizeof(float)),
+                    std::max(owner_lds, small_lds));
+  if (g->lds > (size_t)kMLdsLimit) return false;
+  g->slab_floats = (size_t)g->k_slices * s.batch * kMH;
+  g->act_floats = (size_t)s.batch * kMH;
+  g->dout_floats = (size_t)s.batch * g->NhP;
+  return true;
+}
+
+static bool mdnn_device_can_host(const MdnnGeom& g) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  return prop.multiProcessorCount >= g.G1 + g.n_owner + g.n_small &&
+         (size_t)prop.maxSharedMemoryPerMultiProcessor >= g.lds;
+}
+
+bool persist_mdnn_supported(const PersistMdnnShape& s) {
+  MdnnGeom g;
+  return mdnn_geom(s, &g) && mdnn_device_can_host(g);
+}
+
+static size_t mdnn_data_bytes(const MdnnGeom& g) {
+  return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats) * sizeof(float), 256);
+}
+static size_t mdnn_sync_bytes() { return 3 * kXwgMax * sizeof(unsigned) + 3 * kXwgMax * 8; }
+
+size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
+  MdnnGeom g;
+  if (!mdnn_geom(s, &g)) return 0;
+  return mdnn_data_bytes(g) + mdnn_sync_bytes();
+}
+
+int persist_mdnn_reset(const PersistMdnnShape& s, void* workspace, size_t workspace_bytes,
+                       hipStream_t st) {
+  MdnnGeom g;
+  BSIG_REQUIRE(mdnn_geom(s, &g), "persistent MDNN updates: shape not covered");
+  BSIG_REQUIRE(workspace && workspace_bytes >= persist_mdnn_workspace_bytes(s),
+               "persistent MDNN updates: workspace too small");
+  char* base = reinterpret_cast<char*>(workspace);
+  const size_t slab_bytes = g.slab_floats * sizeof(float);
+  // activations / gradients (padding columns of d_out stay zero), flags and granules
+  BSIG_HIP(hipMemsetAsync(base + slab_bytes, 0, persist_mdnn_workspace_bytes(s) - slab_bytes, st));
+  return BSIG_OK;
+}
+
+int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
+                     const PersistHyper& hy, int n, hipStream_t st) {
+  MdnnGeom g;
+  BSIG_REQUIRE(mdnn_geom(s, &g), "persistent MDNN updates: shape not covered");
+  BSIG_REQUIRE(b.x && b.y && b.ids && b.params && b.exp_avg && b.exp_avg_sq && b.state &&
+                   b.train_loss && b.workspace, "persistent MDNN updates: null buffer");
+  BSIG_REQUIRE(b.workspace_bytes >= persist_mdnn_workspace_bytes(s),
+               "persistent MDNN updates: workspace too small");
+  BSIG_REQUIRE(b.ldx % 4 == 0 && b.ldx >= s.input_dim && aligned(b.x, 16),
+               "persistent MDNN updates: summaries must be 16-byte aligned rows");
+  BSIG_REQUIRE(b.w2_off % 2 == 0 && b.wh_off % 2 == 0 && aligned(b.params, 16),
+               "persistent MDNN updates: weight blocks must be 8-byte aligned");
+  if (n <= 0) return BSIG_OK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mdnn_updates_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit));
+    attr_set = true;
+  }
+  MdnnArgs p{};
+  p.B = s.batch; p.FR = g.FR; p.I = s.input_dim; p.Nh = g.Nh; p.Nh16 = g.Nh16; p.NhP = g.NhP;
+  p.D = s.out_dim; p.K = s.n_comp;
+  p.k_slices = g.k_slices; p.G1 = g.G1; p.n_owner = g.n_owner; p.n_small = g.n_small;
+  p.n_updates = n; p.x_floats = g.x_floats;
+  p.x = b.x; p.ldx = b.ldx; p.ids = b.ids; p.y = b.y; p.ldy = b.ldy;
+  p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq;
+  p.w1_off = b.w1_off; p.b1_off = b.b1_off; p.w2_off = b.w2_off; p.b2_off = b.b2_off;
+  p.wh_off = b.wh_off; p.bh_off = b.bh_off;
+  p.state = b.state; p.train_loss = b.train_loss;
+  p.lr = hy.lr; p.beta1 = hy.beta1; p.beta2 = hy.beta2;
+  p.adam_eps = hy.adam_eps; p.eps_noise = hy.eps_noise; p.min_w = hy.min_weight;
+  p.ll_limit = hy.ll_limit; p.inv_norm = 1.0f / (float)hy.norm_batch;
+  char* base = reinterpret_cast<char*>(b.workspace);
+  p.slabs = reinterpret_cast<float*>(base);
+  p.dz1 = p.slabs + g.slab_floats;
+  p.h1 = p.dz1 + g.act_floats;
+  p.h2 = p.h1 + g.act_floats;
+  p.dz2 = p.h2 + g.act_floats;
+  p.d_out = p.dz2 + g.act_floats;
+  char* sync = base + mdnn_data_bytes(g);
+  p.flag_fwd = reinterpret_cast<unsigned*>(sync);
+  p.flag_own = p.flag_fwd + kXwgMax;
+  p.flag_small = p.flag_own + kXwgMax;
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 3 * kXwgMax * sizeof(unsigned));
+  hipLaunchKernelGGL(mdnn_updates_kernel, dim3(g.G1 + g.n_owner + g.n_small), dim3(kMT), g.lds, st, p);
+  BSIG_CHECK_LAUNCH("mdnn_updates");
+  return BSIG_OK;
+}
+
+}  // namespace bsig

@@ -1,0 +1,36 @@
+// Persistent update kernel of the fit engine for the MDNN estimator with the
+// reference's default trunk (two hidden layers of 128 tanh units, diagonal
+// covariance; fit_persistent_mdnn.hip): a run of consecutive Adam updates
+// (mdnn.py:219-233) in ONE launch.
+#pragma once
+#include "common.h"
+
+namespace bsig {
+
+struct PersistMdnnShape {
+  int batch, input_dim, h1, h2, activation, out_dim, n_comp, full_cov;
+};
+
+struct PersistMdnnBuffers {
+  const float* x; int64_t ldx;            // summary rows (training split of the chunk)
+  const int32_t* ids;                     // [n_updates*batch] minibatch row ids (rows of x and y)
+  const float* y; int64_t ldy;            // normalised targets
+  float* params; float* exp_avg; float* exp_avg_sq;   // flat buffers
+  int64_t w1_off, b1_off, w2_off, b2_off, wh_off, bh_off;
+  int32_t* state;                         // the fit engine's 16-word state block
+  float* train_loss;                      // [n_updates]
+  void* workspace; size_t workspace_bytes;
+};
+
+struct PersistHyper;   // persist.h
+
+bool persist_mdnn_supported(const PersistMdnnShape& s);
+size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s);
+int persist_mdnn_reset(const PersistMdnnShape& s, void* workspace, size_t workspace_bytes,
+                       hipStream_t st);
+// n consecutive updates starting at the state block's step counter; advances the
+// counter, the jitter RNG stream and the Adam bias-correction powers
+int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
+                     const PersistHyper& h, int n, hipStream_t st);
+
+}  // namespace bsig

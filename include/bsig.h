@@ -278,7 +278,9 @@ int bsig_fit_updates(bsig_fit_plan* plan, int64_t n_updates, bsig_stream_t strea
 int bsig_fit_grad(bsig_fit_plan* plan, bsig_stream_t stream);
 int bsig_fit_apply(bsig_fit_plan* plan, bsig_stream_t stream);
 int bsig_fit_flush(bsig_fit_plan* plan, bsig_stream_t stream);
-/* 1 when the plan's updates run in the persistent update kernel (diagnostics / tests). */
+/* 1: the plan's updates run in the persistent kernel for linear heads on cached
+ * features (MDRFF), 2: in the one for the two-layer MDNN trunk (as bound), 0: as
+ * per-phase kernels (diagnostics / tests). */
 int bsig_fit_is_persistent(const bsig_fit_plan* plan);
 int bsig_fit_eval(bsig_fit_plan* plan, bsig_stream_t stream);
 

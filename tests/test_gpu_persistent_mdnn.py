@@ -1,0 +1,151 @@
+"""The persistent update kernel of the two-layer MDNN (csrc/fit_persistent_mdnn.hip):
+parity with the oracle (teacher-forced chunks, all logged losses and the full
+weight vector), with the per-phase kernels it replaces, across the launch
+schedule, and the finiteness flag."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def B():
+    import bayes_sim_ig_amd as pkg
+    pkg._lib.require_gpu()
+    pkg.MDNN.VERBOSE = False
+    return pkg
+
+
+@pytest.fixture(autouse=True)
+def _guards():
+    import bayes_sim_ig_amd as pkg
+    old = pkg.MDNN.EPS_NOISE
+    yield
+    pkg.MDNN.EPS_NOISE = old
+    pkg.MDNN.USE_GRAPH = True
+    os.environ.pop('BSIG_NO_PERSISTENT', None)
+
+
+def _cfg(d, k, summarizer='summary_start', t=11, sd=5, ad=2, hidden=(128, 128)):
+    return dict(task='synthetic', model='MDNN', summarizer=summarizer, t=t, sd=sd, ad=ad,
+                d=d, k=k, hidden=list(hidden), n_feat=0, pairs=1000)
+
+
+def _chunk(B, cfg, n=1000, batch=100, n_updates=100, seed=3, eps=None, env=None):
+    """One teacher-forced chunk on a freshly built model -> (logs, flat weights, BayesSim, data)."""
+    import bench
+    os.environ.pop('BSIG_NO_PERSISTENT', None)
+    os.environ.update(env or {})
+    if eps is not None:
+        B.MDNN.EPS_NOISE = eps
+    theta, states, actions = bench.synth_pairs(cfg, n, seed, DEV)
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    n_train = n - int(n * 0.2)
+    ids = np.random.RandomState(5).randint(0, n_train, (n_updates, batch))
+    summ = bs._summarize(states, actions)
+    logs = bs.model.run_training(summ, theta, n_updates, batch, ids_table=ids)
+    return logs, bs.model._flat.clone(), bs, (theta, states, actions, ids)
+
+
+# (D, K, summarizer, sd, ad, T): I = 70 (one k-slice, ragged tail); the Pendulum
+# head (K=10, D=2) on I = 40; cross-correlation summaries I = 722 (3 k-slices, I % 4 = 2);
+# a ShadowHand-sized head (Nh = 260) on I = 1170
+SHAPES = [(3, 5, 'summary_start', 5, 2, 11), (2, 10, 'summary_start', 3, 1, 21),
+          (17, 5, 'summary_corrdiff', 10, 8, 12), (32, 4, 'summary_start', 97, 20, 11)]
+
+
+@pytest.mark.parametrize('d,k,summarizer,sd,ad,t', SHAPES)
+def test_persistent_mdnn_chunk_matches_oracle(B, d, k, summarizer, sd, ad, t):
+    """Teacher-forced chunk (EPS_NOISE=0, same start weights, same ids) against the
+    fp32 oracle: all 6+6 logged losses within 1e-4 relative (the north-star
+    bound), end weights within 2e-4 absolute of the oracle's."""
+    import bench
+    from oracle import summarize as osum
+    cfg = _cfg(d, k, summarizer, t, sd, ad)
+    torch.set_num_threads(8)
+    logs, flat, bs, (theta, states, actions, ids) = _chunk(B, cfg, eps=0.0)
+    assert B._lib.load().bsig_fit_is_persistent(bs.model._plan) == 2
+    ora = bench.build_oracle(cfg, bs.model.input_dim, 77, 0.0)
+    bs0 = bench.build_gpu_model(B, cfg, DEV, 77)
+    ora.load_state_dict({kk: v.cpu() for kk, v in bs0.model.state_dict().items()})
+    ref = ora.run_training(osum.SUMMARIZERS[summarizer](states.cpu(), actions.cpu()),
+                           theta.cpu(), 100, 100, ids_table=ids)
+    for key in ('train_loss', 'test_loss'):
+        got, exp = np.array(logs[key]), np.array(ref[key])
+        assert got.shape == exp.shape == (6,)
+        assert np.all(np.abs(got - exp) <= 1e-4 * np.maximum(np.abs(exp), 1.0)), (key, got, exp)
+    # (an element whose gradient hovers around zero takes Adam steps of +-lr whose sign
+    # is decided by rounding: the per-phase kernels show the same isolated outliers)
+    sd_ = bs.model.state_dict()
+    for name, v in ora.state_dict().items():
+        diff = (sd_[name].cpu() - v).abs()
+        assert int((diff > 2e-4 + 1e-3 * v.abs()).sum()) <= 3 and float(diff.max()) < 2e-3, name
+
+
+@pytest.mark.parametrize('eps', [0.0, 1e-5])
+def test_persistent_mdnn_equals_phase_kernels(B, eps):
+    """Same chunk through the persistent kernel and through the per-phase kernels
+    it replaces (BSIG_NO_PERSISTENT=1): same jitter RNG streams, the arithmetic
+    differs only in summation order."""
+    cfg = _cfg(4, 6, 'summary_corrdiff', 12, 7, 3)
+    logs_p, flat_p, bs_p, _ = _chunk(B, cfg, eps=eps)
+    logs_k, flat_k, bs_k, _ = _chunk(B, cfg, eps=eps, env={'BSIG_NO_PERSISTENT': '1'})
+    lib = B._lib.load()
+    assert lib.bsig_fit_is_persistent(bs_p.model._plan) == 2
+    assert lib.bsig_fit_is_persistent(bs_k.model._plan) == 0
+    for key in ('train_loss', 'test_loss'):
+        assert np.allclose(logs_p[key], logs_k[key], rtol=3e-5, atol=3e-5), (key, logs_p, logs_k)
+    assert torch.allclose(flat_p, flat_k, atol=1e-4, rtol=1e-3)
+    assert not torch.equal(flat_p, torch.zeros_like(flat_p))
+
+
+def test_persistent_mdnn_reruns_are_bitwise(B):
+    """Every cross-workgroup sum is taken in a fixed order: two runs (jitter on)
+    give identical bits."""
+    cfg = _cfg(3, 5, 'summary_start', 11, 40, 6)
+    a = _chunk(B, cfg, eps=1e-5)
+    b = _chunk(B, cfg, eps=1e-5)
+    assert a[0] == b[0]
+    assert torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize('n,batch,n_updates', [(1000, 64, 37), (1000, 7, 11), (60, 100, 5), (1000, 104, 20)])
+def test_persistent_mdnn_ragged_shapes_match_phase_kernels(B, n, batch, n_updates):
+    """Minibatches that are not a multiple of the owners' 8 rows or of the MFMA
+    tile, a chunk smaller than one minibatch, odd update counts."""
+    cfg = _cfg(3, 5, 'summary_start', 11, 9, 2)
+    a = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=1e-5)
+    b = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=1e-5,
+               env={'BSIG_NO_PERSISTENT': '1'})
+    lib = B._lib.load()
+    assert lib.bsig_fit_is_persistent(a[2].model._plan) == 2
+    assert lib.bsig_fit_is_persistent(b[2].model._plan) == 0
+    for key in ('train_loss', 'test_loss'):
+        assert len(a[0][key]) == len(b[0][key])
+        assert np.allclose(a[0][key], b[0][key], rtol=3e-5, atol=3e-5), (key, a[0], b[0])
+    assert torch.allclose(a[1], b[1], atol=1e-4, rtol=1e-3)
+
+
+def test_other_trunks_keep_the_phase_kernels(B):
+    """Only the reference's default trunk [128, 128] is covered."""
+    cfg = _cfg(3, 5, hidden=(64, 64))
+    _, _, bs, _ = _chunk(B, cfg, n_updates=5, eps=0.0)
+    assert B._lib.load().bsig_fit_is_persistent(bs.model._plan) == 0
+
+
+def test_nonfinite_summary_raises_through_persistent_mdnn(B):
+    """NaN in a training summary reaches the kernel's finiteness flag ->
+    AssertionError (the reference asserts isfinite, mdnn.py:120-124)."""
+    import bench
+    cfg = _cfg(3, 5)
+    theta, states, actions = bench.synth_pairs(cfg, 1000, 3, DEV)
+    states[5, 0, 0] = float('nan')
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    ids = np.random.RandomState(5).randint(0, 800, (100, 100))
+    ids[0, 0] = 5
+    with pytest.raises(AssertionError):
+        bs.model.run_training(bs._summarize(states, actions), theta, 100, 100, ids_table=ids)
