@@ -558,6 +558,7 @@ int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes
 
 static long long* g_prof = nullptr;
 void persist_set_profile_buffer(void* buf) { g_prof = reinterpret_cast<long long*>(buf); }
+void* persist_profile_buffer() { return g_prof; }
 
 int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyper& hy, int n,
                 hipStream_t st) {

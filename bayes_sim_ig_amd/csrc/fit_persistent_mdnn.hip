@@ -14,7 +14,7 @@
 //    accumulator layout).  Per update: gather their [B, 256] slice of the
 //    minibatch summaries into LDS, partial product X_slice W1_tile^T (fp32 MFMA
 //    32x32x2) -> split-K slab; later dW1_tile = dz1^T X_slice and Adam.
-//  * row-owner workgroups (ceil(B/8)): own 8 minibatch rows.  Sum the k-slices
+//  * row-owner workgroups (ceil(B/4)): own 4 minibatch rows.  Sum the k-slices
 //    (+b1, tanh) -> h1; h2 = tanh(h1 W2^T + b2); head outputs; the row-wise
 //    mixture NLL forward/backward (diag_row, one wavefront per row); dz2 = (d_out
 //    Wh) * (1 - h2^2); dz1 = (dz2 W2) * (1 - h1^2).  The four small products run
@@ -46,7 +46,7 @@ constexpr int kMPitch = kMC + 4;    // LDS row pitch of the summary / weight til
 constexpr int kMNB = 32;            // weight rows per tile / small-weight workgroup
 constexpr int kMH = 128;            // hidden width (both layers)
 constexpr int kMHP = kMH + 4;       // LDS pitch of a 128-wide activation row
-constexpr int kMR = 8;              // minibatch rows per owner workgroup
+constexpr int kMR = 4;              // minibatch rows per owner workgroup (power of two <= 8)
 constexpr int kMPbuf = 33;
 constexpr int kMLdsLimit = 160 * 1024;
 
@@ -68,8 +68,22 @@ struct MdnnArgs {
   float* h2;      // [B][128]   ... (head blocks)
   float* dz2;     // [B][128]   ... (W2 blocks)
   float* d_out;   // [B][NhP]   ... (head blocks)
-  unsigned* flag_fwd; unsigned* flag_own; unsigned* flag_small; unsigned long long* gran;
+  // W2 again, in the order the owners' MFMA operands want it (one coalesced 8-byte load
+  // per lane and instruction): written by the W2 small-weight workgroups next to `params`
+  float* w2f_pack;   // [8 waves][8 tt][2][64 lanes][2]: W2[16w + c16][16tt + 4g + 2half + e]
+  float* w2b_pack;   // [8 waves][8 tt][2][64 lanes][2]: W2[16tt + 4g + 2half + e][16w + c16]
+  unsigned* flag_fwd; unsigned* flag_own; unsigned* flag_small; unsigned* flag_pack;
+  unsigned launch_tag;   // flag_pack value of THIS launch (the packs are rebuilt per launch)
+  unsigned long long* gran;
+  long long* prof;   // diagnostics: [256][kMProfUpdates][16] wall-clock stamps, or null
 };
+
+constexpr int kMProfUpdates = 8;
+#define BSIG_MSTAMP(k)                                                              \
+  do {                                                                              \
+    if (p.prof && threadIdx.x == 0 && t < kMProfUpdates)                            \
+      p.prof[((int64_t)blockIdx.x * kMProfUpdates + t) * 16 + (k)] = wall_clock64(); \
+  } while (0)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -164,9 +178,11 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     const int step = step0 + t;
     const unsigned epoch = (unsigned)step + 1u;
     if (run_aborted(flagp, red, tid_l)) break;
+    BSIG_MSTAMP(0);
     // ---- 1. summary tile -> LDS ------------------------------------------------
     BSIG_MPF_LIST(BSIG_MPF_STORE)
     __syncthreads();
+    BSIG_MSTAMP(1);
 
     // ---- 2. partial forward: P[b, n] = sum_{k in slice} X[b, k] W1[n, k] ---------
     {
@@ -185,6 +201,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
       }
+      BSIG_MSTAMP(2);
       if (kh == 1) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h_l)) * kMPbuf + l31_l] = acc[i];
@@ -206,6 +223,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
       __syncthreads();
       if (tid_l == 0)
         __hip_atomic_store(p.flag_fwd + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      BSIG_MSTAMP(3);
     }
 
     // ---- while the owners work: next summary tile, Adam scalars ------------------
@@ -220,6 +238,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     // ---- 3. dW1 = dz1^T X on this tile, Adam ---------------------------------------
     if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
     __syncthreads();
+    BSIG_MSTAMP(10);
     for (int base = 0; base < p.FR * kMNB; base += kMT * 8) {
       float q[8];
 #pragma unroll
@@ -235,6 +254,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
       }
     }
     __syncthreads();
+    BSIG_MSTAMP(11);
     if (ks == 0) {                         // b1 of this block: column sums of dz1
       const int n = tid_l & 31, part = tid_l >> 5;
       float g = 0.f;
@@ -264,6 +284,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     }
     bias_pending = ks == 0;
     __syncthreads();
+    BSIG_MSTAMP(12);
   }
 
   // ---- write the tile back, advance the engine state ---------------------------
@@ -326,6 +347,23 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
       Wr[i] = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
     }
   }
+  // the owners' operand-order copies of W2 (see MdnnArgs)
+  auto publish_w2 = [&](int i, int h, int kcol) {
+    const int n = n0 + acc_row(i, h);
+    const int lf = ((kcol >> 2) & 3) * 16 + (n & 15), lb = ((n >> 2) & 3) * 16 + (kcol & 15);
+    xwg_store(p.w2f_pack + ((((n >> 4) * 8 + (kcol >> 4)) * 2 + ((kcol >> 1) & 1)) * 64 + lf) * 2 + (kcol & 1), Wr[i]);
+    xwg_store(p.w2b_pack + ((((kcol >> 4) * 8 + (n >> 4)) * 2 + ((n >> 1) & 1)) * 64 + lb) * 2 + (n & 1), Wr[i]);
+  };
+  if (is_w2) {
+    if (w < 4) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) publish_w2(i, h, kcol);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(p.flag_pack + sb, p.launch_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // wave 4, lanes 0-31: the 32 biases
   const bool bias_lane = w == 4 && lane < kMNB && n0 + lane < nrows;
   float bw = 0.f, bm = 0.f, bv = 0.f;
@@ -342,8 +380,10 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
     b1t *= p.beta1; b2t *= p.beta2;
     const float a0 = (float)(p.lr / (1.0 - b1t));
     const float a1 = (float)(1.0 / sqrt(1.0 - b2t));
+    BSIG_MSTAMP(0);
     if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
     __syncthreads();
+    BSIG_MSTAMP(4);
     // activations [B, 128] (8-byte loads) and this block's gradient columns [B, 32]
     for (int base = 0; base < B * (kMH / 2); base += kMT * 8) {
       float2 q[8];
@@ -374,7 +414,11 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
       }
     }
     __syncthreads();
+    BSIG_MSTAMP(5);
     if (w < 4) {
+      // (laundered: the 48 store addresses below are recomputed per update, not kept live)
+      int h_l = h, kcol_l = kcol;
+      asm volatile("" : "+v"(h_l), "+v"(kcol_l));
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -391,9 +435,10 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int n = n0 + acc_row(i, h);
+        const int n = n0 + acc_row(i, h_l);
         Wr[i] = adam_weight(acc[i], Mr[i], Vr[i], Wr[i], a0, a1, ak);
-        if (n < nrows) xwg_store(p.params + w_off + (int64_t)n * kMH + kcol, Wr[i]);
+        if (n < nrows) xwg_store(p.params + w_off + (int64_t)n * kMH + kcol_l, Wr[i]);
+        if (is_w2) publish_w2(i, h_l, kcol_l);
       }
     } else if (bias_lane) {
       float g = 0.f;
@@ -405,6 +450,7 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
     __syncthreads();
     if (tid == 0)
       __hip_atomic_store(p.flag_small + sb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    BSIG_MSTAMP(6);
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -423,15 +469,15 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   const int po = Nh16 + 4;                   // pitch of a head-output row
   const int per_wave = D + 3 * K;
   float* Whs = smem;                         // [Nh16][128], element (n, i) at n*128 + (i ^ 4(n & 15))
-  float* H1s = Whs + Nh16 * kMH;             // [8][kMHP]
-  float* H2s = H1s + kMR * kMHP;             // [8][kMHP]  h2, later dz2 in place
-  float* Os = H2s + kMR * kMHP;              // [8][po]    head outputs, later d_out in place
+  float* H1s = Whs + Nh16 * kMH;             // [kMR][kMHP]
+  float* H2s = H1s + kMR * kMHP;             // [kMR][kMHP]  h2, later dz2 in place
+  float* Os = H2s + kMR * kMHP;              // [kMR][po]    head outputs, later d_out in place
   float* b2s = Os + kMR * po;                // [128]
   float* bhs = b2s + kMH;                    // [Nh16]
-  float* wsc = bhs + Nh16;                   // [8][D + 3K] per-row scratch of diag_row
+  float* wsc = bhs + Nh16;                   // [kMR][D + 3K] per-row scratch of diag_row
   float* red = wsc + kMR * per_wave;         // [64]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int c16 = lane & 15, g = lane >> 4, rowA = c16 & (kMR - 1);
+  const int tid_0 = threadIdx.x, w_0 = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
+  const int c16_0 = tid_0 & 15, g_0 = (tid_0 & 63) >> 4;
   const int o = blockIdx.x - p.G1;
   const int r0 = o * kMR;
   int32_t* flagp = p.state + 2;
@@ -443,39 +489,39 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   a.min_w = p.min_w; a.ll_limit = p.ll_limit; a.inv_norm = p.inv_norm;
   a.eps_noise = p.eps_noise; a.seed = rng_seed; a.d_out = p.d_out;
   const float norm = (float)B * (float)DK;
-  const int row = r0 + w;                    // wave w <-> minibatch row r0 + w in the row-wise phases
-  const bool active = row < B;
-  float* tile = Os + w * po;
-  float* yv = wsc + w * per_wave;
-  float* rk = yv + D;
-  float* lpk = rk + K;
-  float* dlg = lpk + K;
-  const float* W2 = p.params + p.w2_off;
+  // (wave w <-> minibatch row r0 + w in the row-wise phases)
   const float* Wh = p.params + p.wh_off;
   const int64_t zs = (int64_t)B * kMH;
-  // W2 as the B operand of both products, one column block of 16 per wave:
-  // w2f[4t + j] = W2[16w + c16][16t + 4g + j], w2b[4t + j] = W2[16t + 4g + j][16w + c16]
-  float w2f[32], w2b[32];
+  // W2 is the B operand of two products, one column block of 16 per wave, straight
+  // from registers: w2f[4t + j] = W2[16w + c16][16t + 4g + j] (forward, fetched under the
+  // k-slice sum), w2b[4t + j] = W2[16t + 4g + j][16w + c16] (backward, fetched under the
+  // wait for the other owners' rows)
 
+  if (w_0 == 0) flags_wait(p.flag_pack, kMH / kMNB, p.launch_tag, tid_0 & 63, flagp);
+  __syncthreads();
   for (int t = 0; t < p.n_updates; ++t) {
+    // lane-derived indices are laundered once per update so that the address
+    // arithmetic built on them is recomputed, not kept live across the update loop
+    int c16 = c16_0, g = g_0, w = w_0, tid = tid_0;
+    asm volatile("" : "+v"(c16), "+v"(g), "+v"(tid));
+    asm volatile("" : "+s"(w));
+    const int lane = tid & 63, rowA = c16 & (kMR - 1);
+    const int row = r0 + w;
+    const bool active = w < kMR && row < B;
+    float* tile = Os + (w & (kMR - 1)) * po;
+    float* yv = wsc + (w & (kMR - 1)) * per_wave;
+    float* rk = yv + D;
+    float* lpk = rk + K;
+    float* dlg = lpk + K;
     const int step = step0 + t;
     const unsigned epoch = (unsigned)step + 1u;
     const uint32_t tag = epoch * 4u;
     if (run_aborted(flagp, red, tid)) break;
+    BSIG_MSTAMP(0);
     // ---- weights of this update (written by the small-weight workgroups) ---------
     if (w == 0) flags_wait(p.flag_small, p.n_small, epoch - 1u, lane, flagp);
     __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < 8; ++tt) {
-      const float* src = W2 + (int64_t)(16 * w + c16) * kMH + 16 * tt + 4 * g;
-      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 2);
-      w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y;
-    }
-#pragma unroll
-    for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        w2b[4 * tt + j] = xwg_load(W2 + (int64_t)(16 * tt + 4 * g + j) * kMH + 16 * w + c16);
+    BSIG_MSTAMP(4);
     for (int base = 0; base < Nh16 * (kMH / 2); base += kMT * 8) {
       float2 q[8];
 #pragma unroll
@@ -498,26 +544,53 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
     }
     // ---- h1 = tanh(sum of the k-slices) (b1 rides on slice 0) -----------------------
+    BSIG_MSTAMP(5);
     if (w == 0) flags_wait(p.flag_fwd, p.G1, epoch, lane, flagp);
     __syncthreads();
+    BSIG_MSTAMP(6);
+    float w2f[32];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const float* src = p.w2f_pack + (((w * 8 + tt) * 2) * 64 + lane) * 2;
+      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);
+      w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y;
+    }
     {
-      const int r = tid >> 6, c2 = (tid & 63) * 2;      // 8 rows x 64 column pairs
+      // (row, column pair) items; kSub threads share an item's k-slices, their partial
+      // sums are combined in a fixed order through LDS
+      constexpr int kItems = kMR * 64, kSub = kMT / kItems;
+      const int item = tid & (kItems - 1), sub = tid / kItems;
+      const int r = item >> 6, c2 = (item & 63) * 2;
       const bool ok = r0 + r < B;
       const float* src = p.slabs + (int64_t)min(r0 + r, B - 1) * kMH + c2;
+      const int per = ceil_div(p.k_slices, kSub);
+      const int z_lo = sub * per, z_hi = min(z_lo + per, p.k_slices);
       float vx = 0.f, vy = 0.f;
-      for (int z = 0; z < p.k_slices; z += 16) {
-        float2 q[16];
+      for (int z = z_lo; z < z_hi; z += 24) {
+        float2 q[24];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) q[u] = xwg_load2(src + (int64_t)min(z + u, p.k_slices - 1) * zs);
+        for (int u = 0; u < 24; ++u) q[u] = xwg_load2(src + (int64_t)min(z + u, z_hi - 1) * zs);
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (z + u < p.k_slices) { vx += q[u].x; vy += q[u].y; }
+        for (int u = 0; u < 24; ++u)
+          if (z + u < z_hi) { vx += q[u].x; vy += q[u].y; }
       }
-      vx = ok ? tanhf(vx) : 0.f; vy = ok ? tanhf(vy) : 0.f;
-      H1s[r * kMHP + c2] = vx; H1s[r * kMHP + c2 + 1] = vy;
-      if (ok) { xwg_store(p.h1 + (int64_t)(r0 + r) * kMH + c2, vx); xwg_store(p.h1 + (int64_t)(r0 + r) * kMH + c2 + 1, vy); }
+      if (kSub > 1) {
+        float* part = H2s;                   // free until h2 is written
+        if (sub > 0) { part[((sub - 1) * kItems + item) * 2] = vx; part[((sub - 1) * kItems + item) * 2 + 1] = vy; }
+        __syncthreads();
+        if (sub == 0) {
+#pragma unroll
+          for (int q = 1; q < kSub; ++q) { vx += part[((q - 1) * kItems + item) * 2]; vy += part[((q - 1) * kItems + item) * 2 + 1]; }
+        }
+      }
+      if (sub == 0) {
+        vx = ok ? tanhf(vx) : 0.f; vy = ok ? tanhf(vy) : 0.f;
+        H1s[r * kMHP + c2] = vx; H1s[r * kMHP + c2 + 1] = vy;
+        if (ok) { xwg_store(p.h1 + (int64_t)(r0 + r) * kMH + c2, vx); xwg_store(p.h1 + (int64_t)(r0 + r) * kMH + c2 + 1, vy); }
+      }
     }
     __syncthreads();
+    BSIG_MSTAMP(7);
     // ---- h2 = tanh(h1 W2^T + b2): wave w -> columns 16w .. 16w+15 -------------------
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -530,7 +603,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         acc = mfma16(a4.z, w2f[4 * tt + 2], acc);
         acc = mfma16(a4.w, w2f[4 * tt + 3], acc);
       }
-      if (g < 2) {
+      if (4 * g < kMR) {
         const int n = 16 * w + c16;
         const float bias = b2s[n];
 #pragma unroll
@@ -543,6 +616,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       }
     }
     __syncthreads();
+    BSIG_MSTAMP(8);
     // ---- head outputs = h2 Wh^T + bh: column blocks w, w+8, w+16 -----------------------
     float eacc = 0.f;
     for (int cb = w; cb * 16 < Nh16; cb += 8) {
@@ -560,7 +634,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         acc = mfma16(a4.z, b4.z, acc);
         acc = mfma16(a4.w, b4.w, acc);
       }
-      if (g < 2) {
+      if (4 * g < kMR) {
         const float bias = bhs[n];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -579,6 +653,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       for (int q = 0; q < kMT / 64; ++q) sx += red[q];
       granule_publish(p.gran + o, tag + 1, sx);
     }
+    BSIG_MSTAMP(9);
     // ---- row-wise NLL forward / backward (one wavefront per row) -----------------------
     RowOut ro;
     ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
@@ -602,6 +677,14 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       for (int q = 0; q < kMR; ++q) { sl += red[16 + q]; su += red[32 + q]; }
       granule_publish(p.gran + kXwgMax + o, tag + 2, su);
       granule_publish(p.gran + 2 * kXwgMax + o, tag + 3, sl);
+    }
+    BSIG_MSTAMP(13);
+    float w2b[32];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const float* src = p.w2b_pack + (((w * 8 + tt) * 2) * 64 + lane) * 2;
+      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);
+      w2b[4 * tt + 0] = lo.x; w2b[4 * tt + 1] = lo.y; w2b[4 * tt + 2] = hi.x; w2b[4 * tt + 3] = hi.y;
     }
     // the jitter-scale gradient term d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
     // needs the sum over the whole minibatch
@@ -627,6 +710,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     }
     if (ro.bad) atomicOr(flagp, 1);
     __syncthreads();
+    BSIG_MSTAMP(14);
     // ---- dz2 = (d_out Wh) * (1 - h2^2): wave w -> columns 16w .. 16w+15 ----------------
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -645,7 +729,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         acc = mfma16(a4.z, f2, acc);
         acc = mfma16(a4.w, f3, acc);
       }
-      if (g < 2) {
+      if (4 * g < kMR) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rr = 4 * g + r;
@@ -670,7 +754,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         acc = mfma16(a4.z, w2b[4 * tt + 2], acc);
         acc = mfma16(a4.w, w2b[4 * tt + 3], acc);
       }
-      if (g < 2) {
+      if (4 * g < kMR) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rr = 4 * g + r;
@@ -683,6 +767,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     __syncthreads();
     if (tid == 0)
       __hip_atomic_store(p.flag_own + o, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    BSIG_MSTAMP(15);
     if (o == 0 && w == 0) {
       const float s = granule_gather(p.gran + 2 * kXwgMax, p.n_owner, tag + 3, lane, flagp);
       if (lane == 0) {
@@ -755,10 +840,12 @@ bool persist_mdnn_supported(const PersistMdnnShape& s) {
   return mdnn_geom(s, &g) && mdnn_device_can_host(g);
 }
 
+constexpr size_t kPackFloats = (size_t)kMH * kMH;
 static size_t mdnn_data_bytes(const MdnnGeom& g) {
-  return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats) * sizeof(float), 256);
+  return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats + 2 * kPackFloats) *
+                              sizeof(float), 256);
 }
-static size_t mdnn_sync_bytes() { return 3 * kXwgMax * sizeof(unsigned) + 3 * kXwgMax * 8; }
+static size_t mdnn_sync_bytes() { return 4 * kXwgMax * sizeof(unsigned) + 3 * kXwgMax * 8; }
 
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
   MdnnGeom g;
@@ -818,11 +905,17 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.h2 = p.h1 + g.act_floats;
   p.dz2 = p.h2 + g.act_floats;
   p.d_out = p.dz2 + g.act_floats;
+  p.w2f_pack = p.d_out + g.dout_floats;
+  p.w2b_pack = p.w2f_pack + kPackFloats;
   char* sync = base + mdnn_data_bytes(g);
   p.flag_fwd = reinterpret_cast<unsigned*>(sync);
   p.flag_own = p.flag_fwd + kXwgMax;
   p.flag_small = p.flag_own + kXwgMax;
-  p.gran = reinterpret_cast<unsigned long long*>(sync + 3 * kXwgMax * sizeof(unsigned));
+  p.flag_pack = p.flag_small + kXwgMax;
+  static unsigned launch_tag = 0;
+  p.launch_tag = ++launch_tag;
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 4 * kXwgMax * sizeof(unsigned));
+  p.prof = reinterpret_cast<long long*>(persist_profile_buffer());
   hipLaunchKernelGGL(mdnn_updates_kernel, dim3(g.G1 + g.n_owner + g.n_small), dim3(kMT), g.lds, st, p);
   BSIG_CHECK_LAUNCH("mdnn_updates");
   return BSIG_OK;

@@ -46,5 +46,6 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
 // diagnostics: [256][8][16] int64 wall-clock stamps of the first 8 updates of every
 // following launch (null: off)
 void persist_set_profile_buffer(void* buf);
+void* persist_profile_buffer();
 
 }  // namespace bsig

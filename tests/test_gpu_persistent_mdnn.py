@@ -115,7 +115,7 @@ def test_persistent_mdnn_reruns_are_bitwise(B):
 
 @pytest.mark.parametrize('n,batch,n_updates', [(1000, 64, 37), (1000, 7, 11), (60, 100, 5), (1000, 104, 20)])
 def test_persistent_mdnn_ragged_shapes_match_phase_kernels(B, n, batch, n_updates):
-    """Minibatches that are not a multiple of the owners' 8 rows or of the MFMA
+    """Minibatches that are not a multiple of the owners' 4 rows or of the MFMA
     tile, a chunk smaller than one minibatch, odd update counts."""
     cfg = _cfg(3, 5, 'summary_start', 11, 9, 2)
     a = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=1e-5)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the persistent MDNN update kernel (fit_persistent_mdnn.hip)
+from its wall-clock stamps (bsig_debug_persist_profile): one chunk of a bench config."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                     # noqa: E402
+import bayes_sim_ig_amd as B     # noqa: E402
+
+B.MDNN.VERBOSE = False
+dev = 'cuda:0'
+lib = B._lib.require_gpu()
+lib.bsig_debug_persist_profile.restype = None
+lib.bsig_debug_persist_profile.argtypes = [C.c_void_p]
+name = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
+cfg = dict(bench.CONFIGS[name])
+theta, states, actions = bench.synth_pairs(cfg, 1000, 3, dev)
+bs = bench.build_gpu_model(B, cfg, dev, 77)
+summ = bs._summarize(states, actions)
+bs.model.run_training(summ, theta, 100, 100)          # warm-up (plan, graphs)
+assert lib.bsig_fit_is_persistent(bs.model._plan) == 2
+buf = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
+lib.bsig_debug_persist_profile(buf.data_ptr())
+bs.model.run_training(summ, theta, 100, 100)
+torch.cuda.synchronize()
+lib.bsig_debug_persist_profile(None)
+st = buf.cpu().numpy().reshape(256, 8, 16).astype(np.float64) / 100.0   # 100 MHz -> us
+live = [g for g in range(256) if st[g, 1, 0] > 0]
+tiles = [g for g in live if st[g, 1, 12] > 0]
+owners = [g for g in live if st[g, 1, 15] > 0]
+small = [g for g in live if g not in tiles and g not in owners]
+print('%s: %d tile + %d owner + %d small-weight workgroups; mean over updates 2..6 of the last launch'
+      % (name, len(tiles), len(owners), len(small)))
+rows = [('last tile wg has its summary tile in LDS', tiles, 1, np.max),
+        ('last tile wg done with the forward MFMAs', tiles, 2, np.max),
+        ('last forward flag raised', tiles, 3, np.max),
+        ('owners: first / last start of the update', owners, 0, np.min),
+        ('owners: last start of the update', owners, 0, np.max),
+        ('owners: last has the small weights flags', owners, 4, np.max),
+        ('owners: last has Wh in LDS', owners, 5, np.max),
+        ('owners: first released by the forward flags', owners, 6, np.min),
+        ('owners: last released by the forward flags', owners, 6, np.max),
+        ('owners: last h1 (k-slice sum, tanh)', owners, 7, np.max),
+        ('owners: last h2', owners, 8, np.max),
+        ('owners: last head outputs', owners, 9, np.max),
+        ('owners: last rows finished (NLL fwd/bwd)', owners, 13, np.max),
+        ('owners: last d_out corrected + published', owners, 14, np.max),
+        ('owners: last flag (dz2, dz1 out)', owners, 15, np.max),
+        ('tiles: first released', tiles, 10, np.min),
+        ('tiles: last released', tiles, 10, np.max),
+        ('tiles: last dz1^T in LDS', tiles, 11, np.max),
+        ('tiles: first finished the update', tiles, 12, np.min),
+        ('tiles: last finished the update', tiles, 12, np.max),
+        ('small: first released', small, 4, np.min),
+        ('small: last inputs in LDS', small, 5, np.max),
+        ('small: last weights published', small, 6, np.max)]
+acc = {r[0]: [] for r in rows}
+per = []
+for u in range(2, 7):
+    t0 = min(st[g, u, 0] for g in tiles)
+    per.append(min(st[g, u + 1, 0] for g in tiles) - t0)
+    for label, grp, k, fn in rows:
+        acc[label].append(fn([st[g, u, k] for g in grp]) - t0)
+print('update period %.2f us' % np.mean(per))
+for label, _, _, _ in rows:
+    print('    %-52s %6.2f' % (label, np.mean(acc[label])))
