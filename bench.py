@@ -177,16 +177,18 @@ def pmc_traffic(kernel_substr):
     import glob
     out = {}
     for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
-        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_%s.txt' % ctr)))
-        if not files:
-            return None, None
-        for line in open(files[-1]):
-            if kernel_substr in line and ctr in line:
-                out[ctr] = float(line.split(ctr)[1].split()[1])
+        # latest round first; a round commits one file per profiled config
+        for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_%s.txt' % ctr)),
+                           reverse=True):
+            for line in open(path):
+                if kernel_substr in line and ctr in line:
+                    out[ctr] = float(line.split(ctr)[1].split()[1])
+                    out['src_' + ctr] = os.path.basename(path)
+                    break
+            if ctr in out:
                 break
         else:
             return None, None
-        out['src_' + ctr] = os.path.basename(files[-1])
     return (2.0 * out['FETCH_SIZE'] + out['WRITE_SIZE']) * 1024.0, \
         '%s, %s' % (out['src_FETCH_SIZE'], out['src_WRITE_SIZE'])
 
@@ -251,8 +253,10 @@ def time_update_kernel(pkg, cfg, bsim, device):
         total_ms += sum(a.elapsed_time(b) for a, b in evs)
         launches += len(evs)
     us = total_ms * 1e3 / launches
-    f_in, nh = m.input_dim if cfg['model'] != 'MDRFF' else m.rff.m_feat * 2, \
-        cfg['k'] * (1 + 2 * cfg['d'])
+    nh = cfg['k'] * (1 + 2 * cfg['d'])
+    if cfg['model'] != 'MDRFF':
+        return mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh)
+    f_in = m.rff.m_feat * 2
     per_visit = 2.0 * 2.0 * f_in * nh                 # SURVEY 8(d) K6+K7, MDRFF heads: fwd + dW
     flops = per_visit * batch * (float(n_updates) / len(runs))
     ach = flops / (us * 1e-6) / 1e12
@@ -274,6 +278,31 @@ def time_update_kernel(pkg, cfg, bsim, device):
             'note': 'latency-bound by design of the reference protocol (minibatch 100): each update '
                     'is a chain of 4 cross-workgroup hand-offs (~1.5-3 us each) around ~6 us of '
                     'fp32-MFMA work per CU; see DESIGN.md and scaled_batch_mode for the MFMA-bound regime'}
+
+
+def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh):
+    """MDNN [128, 128]: the persistent update kernel (csrc/fit_persistent_mdnn.hip).
+    Algorithmic work per row visit (SURVEY.md 8(d) K5 + K6/K7): first layer forward + dW1
+    (no dX of the input), second layer and heads forward + dW + dX."""
+    i, h = m.input_dim, 128
+    per_visit = 2.0 * (2.0 * i * h) + 3.0 * (2.0 * h * h) + 3.0 * (2.0 * h * nh)
+    flops = per_visit * batch * (float(n_updates) / len(runs))
+    ach = flops / (us * 1e-6) / 1e12
+    traffic, tsrc = pmc_traffic('mdnn_updates_kernel')
+    return {'bound': 'mfma',
+            'kernel': 'mdnn_updates_kernel: persistent update kernel of the two-layer MDNN, '
+                      'trunk %d-128-128, heads %d, minibatch %d, %s updates per launch (mean %.1f): '
+                      'forward, NLL fwd/bwd, backward, Adam'
+                      % (i, nh, batch, '/'.join(str(r) for r in runs), float(n_updates) / len(runs)),
+            'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
+            'traffic': traffic, 'traffic_source': tsrc, 'avg_us': us,
+            'us_per_update': us * len(runs) / n_updates,
+            'algorithmic': '2*(2*I*128) + 3*(2*128*128) + 3*(2*128*Nh) = %.3e flop per row visit x %d '
+                           'rows x %.1f updates = %.3e flop per launch'
+                           % (per_visit, batch, float(n_updates) / len(runs), flops),
+            'note': 'latency-bound by design of the reference protocol (minibatch 100): each update '
+                    'is a chain of cross-workgroup hand-offs (tiles -> row owners -> tiles) around '
+                    '~8 us of fp32-MFMA work per CU; see DESIGN.md'}
 
 
 def time_rff_kernel(pkg, cfg, bsim, device):
@@ -315,6 +344,8 @@ def time_dominant_kernel(pkg, cfg, bsim, device):
     if cfg['model'] == 'MDRFF':
         return time_update_kernel(pkg, cfg, bsim, device)
     m = bsim.model
+    if m._dp is None and int(lib.bsig_fit_is_persistent(m._plan)) == 2:
+        return time_update_kernel(pkg, cfg, bsim, device)
     b, i, h0 = 100, m.input_dim, m._hidden[0]
     x = torch.randn(1000, L.round_up(i, 4), device=device)
     ids = torch.randint(0, 800, (b,), device=device, dtype=torch.int32)
