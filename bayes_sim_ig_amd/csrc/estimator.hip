@@ -434,6 +434,10 @@ static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st) {
   pb.wh_off = p->L.head_w_off; pb.bh_off = p->L.head_b_off;
   pb.state = b.state; pb.train_loss = b.train_loss;
   pb.workspace = m.persist_ws; pb.workspace_bytes = p->persist_bytes;
+  if (p->split_adam) {
+    pb.grads = b.grads; pb.adam_pending = p->adam_pending ? 1 : 0;
+    p->adam_pending = false;
+  }
   PersistHyper hy;
   hy.lr = p->cfg.lr; hy.beta1 = p->cfg.beta1; hy.beta2 = p->cfg.beta2;
   hy.adam_eps = p->cfg.adam_eps; hy.eps_noise = p->cfg.head.eps_noise;
@@ -565,7 +569,7 @@ static int capture(bsig_fit_plan* p, hipGraphExec_t* out, F&& body) {
 static int ensure_graphs(bsig_fit_plan* p) {
   if (!p->use_graph || p->g_eval) return BSIG_OK;
   if (p->split_adam) {
-    if (!p->persistent) {
+    if (!p->persistent && !p->persistent_mdnn) {
       BSIG_TRY(capture(p, &p->g_grad, [&](hipStream_t s) { return enqueue_grad(p, s, false); }));
       BSIG_TRY(capture(p, &p->g_apply, [&](hipStream_t s) { return enqueue_apply(p, s); }));
     }
@@ -774,6 +778,7 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
 extern "C" int bsig_fit_grad(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_grad: plan not bound with SPLIT_ADAM");
   if (p->persistent) return enqueue_persistent(p, 1, as_stream(stream));
+  if (p->persistent_mdnn) return enqueue_persistent_mdnn(p, 1, as_stream(stream));
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_grad, as_stream(stream))); return BSIG_OK; }
   return enqueue_grad(p, as_stream(stream), false);
 }
@@ -782,7 +787,7 @@ extern "C" int bsig_fit_apply(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_apply: plan not bound with SPLIT_ADAM");
   // persistent kernel: the step is taken by the next bsig_fit_grad launch while it
   // loads its tiles (bsig_fit_eval / bsig_fit_flush take it at once)
-  if (p->persistent) { p->adam_pending = true; return BSIG_OK; }
+  if (p->persistent || p->persistent_mdnn) { p->adam_pending = true; return BSIG_OK; }
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_apply, as_stream(stream))); return BSIG_OK; }
   return enqueue_apply(p, as_stream(stream));
 }
@@ -790,13 +795,15 @@ extern "C" int bsig_fit_apply(bsig_fit_plan* p, bsig_stream_t stream) {
 extern "C" int bsig_fit_is_persistent(const bsig_fit_plan* p) {
   if (!p) return 0;
   if (p->persistent) return 1;
-  return p->persistent_mdnn && !p->split_adam ? 2 : 0;
+  return p->persistent_mdnn ? 2 : 0;
 }
 
 extern "C" int bsig_fit_flush(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound, "fit_flush: plan not bound");
   if (p->persistent && p->split_adam && p->adam_pending)
     return enqueue_persistent(p, 0, as_stream(stream));
+  if (p->persistent_mdnn && p->split_adam && p->adam_pending)
+    return enqueue_persistent_mdnn(p, 0, as_stream(stream));
   return BSIG_OK;
 }
 
@@ -813,9 +820,9 @@ static int enqueue_updates(bsig_fit_plan* p, int64_t n, hipStream_t st) {
   if (n <= 0) return BSIG_OK;
   if (p->persistent && !p->split_adam) return enqueue_persistent(p, (int)n, st);
   if (p->persistent_mdnn && !p->split_adam) return enqueue_persistent_mdnn(p, (int)n, st);
-  if (p->persistent) {   // data-parallel plan driven without an exchange (one rank)
+  if (p->persistent || p->persistent_mdnn) {   // data-parallel plan driven without an exchange (one rank)
     for (int64_t it = 0; it < n; ++it) {
-      BSIG_TRY(enqueue_persistent(p, 1, st));
+      BSIG_TRY(p->persistent ? enqueue_persistent(p, 1, st) : enqueue_persistent_mdnn(p, 1, st));
       p->adam_pending = true;
     }
     return BSIG_OK;

@@ -73,8 +73,14 @@ struct MdnnArgs {
   float* w2f_pack;   // [8 waves][8 tt][2][64 lanes][2]: W2[16w + c16][16tt + 4g + 2half + e]
   float* w2b_pack;   // [8 waves][8 tt][2][64 lanes][2]: W2[16tt + 4g + 2half + e][16w + c16]
   unsigned* flag_fwd; unsigned* flag_own; unsigned* flag_small; unsigned* flag_pack;
-  unsigned launch_tag;   // flag_pack value of THIS launch (the packs are rebuilt per launch)
+  unsigned launch_tag;   // flag_pack value of THIS launch: the small weights (and the W2 packs)
+                         // as of its start are out, one flag per small-weight workgroup
   unsigned long long* gran;
+  // data-parallel ranks (one update per launch, the caller all-reduces `grads` between
+  // launches): weight / bias gradients go to `grads` (flat layout) instead of into Adam,
+  // and the Adam step of the PREVIOUS update (on the reduced gradients) is taken by the
+  // weights' owners while they load them (adam_pending)
+  float* grads; int adam_pending;
   long long* prof;   // diagnostics: [256][kMProfUpdates][16] wall-clock stamps, or null
 };
 
@@ -99,6 +105,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     const int64_t col = min((int64_t)k0 + (idx & 63) * 4, p.ldx - 4);                       \
     pf##u = *reinterpret_cast<const float4*>(p.x + fr * p.ldx + col);                       \
   }
+#define BSIG_MPF_ZERO(u) pf##u = make_float4(0.f, 0.f, 0.f, 0.f);
 // columns >= I (row padding, the tail of the last k-slice) enter as zeros
 #define BSIG_MPF_STORE(u)                                                                   \
   {                                                                                         \
@@ -113,6 +120,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   }
 
 // ---- tile workgroups: first-layer partial products, dW1, Adam -------------------
+template <bool DP>
 __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* smem) {
   float* Fl = smem;                          // [FR][kMPitch] minibatch summaries (this k-slice)
   float* Wl = Fl + p.FR * kMPitch;           // [32][kMPitch] weight tile (authoritative copy)
@@ -135,6 +143,9 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   float Mr[16], Vr[16];
   const int kcol = 32 * w + l31;
   const bool col_ok = k0 + kcol < p.I;
+  const bool pend = DP && p.adam_pending != 0;
+  const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
+  const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int n = n0 + acc_row(i, h);
@@ -143,13 +154,21 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     if (col_ok) {
       const int64_t off = p.w1_off + (int64_t)n * p.I + k0 + kcol;
       wv = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+      if (pend) {   // written back at once: a data-parallel launch changes the tile only here
+        wv = adam_weight(p.grads[off], Mr[i], Vr[i], wv, pa0, pa1, ak);
+        p.params[off] = wv; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+      }
     }
     Wl[acc_row(i, h) * kMPitch + kcol] = wv;
   }
   if (ks == 0 && tid < kMNB) {
-    biasl[tid] = p.params[p.b1_off + n0 + tid];
-    biasl[32 + tid] = p.m1[p.b1_off + n0 + tid];
-    biasl[64 + tid] = p.m2[p.b1_off + n0 + tid];
+    const int64_t off = p.b1_off + n0 + tid;
+    float bw = p.params[off], bm = p.m1[off], bv = p.m2[off];
+    if (pend) {
+      bw = adam_bias(p.grads[off], bm, bv, bw, pa0, pa1, ak);
+      p.params[off] = bw; p.m1[off] = bm; p.m2[off] = bv;
+    }
+    biasl[tid] = bw; biasl[32 + tid] = bm; biasl[64 + tid] = bv;
   }
   for (int idx = tid; idx < (p.FR - B) * kMPitch; idx += kMT) Fl[B * kMPitch + idx] = 0.f;
   const int DOP = p.FR + 4;
@@ -166,9 +185,11 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   };
 
   BSIG_MPF_LIST(BSIG_MPF_DECL)
-  {
+  if (p.n_updates > 0) {
     const int64_t pf_row0 = (int64_t)step0 * B;
     BSIG_MPF_LIST(BSIG_MPF_LOAD)
+  } else {
+    BSIG_MPF_LIST(BSIG_MPF_ZERO)
   }
   __syncthreads();
 
@@ -276,19 +297,34 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, f2, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, f3, acc, 0, 0, 0);
       }
+      if (DP) {
+        // this rank's share of the gradient: summed over the ranks by the caller
+        if (k0 + kcol_l < p.I) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* wp = Wl + acc_row(i, h_l) * kMPitch + kcol_l;
-        *wp = adam_weight(acc[i], Mr[i], Vr[i], *wp, a0, a1, ak);
+          for (int i = 0; i < 16; ++i)
+            p.grads[p.w1_off + (int64_t)(n0 + acc_row(i, h_l)) * p.I + k0 + kcol_l] = acc[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float* wp = Wl + acc_row(i, h_l) * kMPitch + kcol_l;
+          *wp = adam_weight(acc[i], Mr[i], Vr[i], *wp, a0, a1, ak);
+        }
       }
     }
-    bias_pending = ks == 0;
+    bias_pending = ks == 0 && !DP;
     __syncthreads();
+    if (DP && ks == 0 && tid_l < kMNB) {
+      float g = 0.f;
+#pragma unroll
+      for (int q = 0; q < kMT / 32; ++q) g += bpart[q * 32 + tid_l];
+      p.grads[p.b1_off + n0 + tid_l] = g;
+    }
     BSIG_MSTAMP(12);
   }
 
   // ---- write the tile back, advance the engine state ---------------------------
-  if (col_ok) {
+  if (col_ok && !DP) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int n = n0 + acc_row(i, h);
@@ -297,7 +333,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     }
   }
   if (bias_pending && tid < kMNB) bias_step(tid);
-  if (ks == 0 && tid < kMNB) {
+  if (!DP && ks == 0 && tid < kMNB) {
     p.params[p.b1_off + n0 + tid] = biasl[tid];
     p.m1[p.b1_off + n0 + tid] = biasl[32 + tid];
     p.m2[p.b1_off + n0 + tid] = biasl[64 + tid];
@@ -314,6 +350,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
 }
 
 // ---- small-weight workgroups: 32 rows of W2 or of the head matrix ----------------
+template <bool DP>
 __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* smem) {
   float* Hs = smem;                          // [FR][kMHP] input activations of the layer
   float* X = Hs + p.FR * kMHP;               // [32][FR + 4] output gradients, transposed
@@ -335,6 +372,9 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
   double b2t = reinterpret_cast<const double*>(p.state + 12)[1];
   const AdamK ak{1.0f - (float)p.beta1, (float)p.beta2, 1.0f - (float)p.beta2, p.adam_eps};
 
+  const bool pend = DP && p.adam_pending != 0;
+  const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
+  const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
   // waves 0-3: element i of lane (h, l31) of wave w <-> W[n0 + acc_row(i, h)][32w + l31]
   float Wr[16], Mr[16], Vr[16];
   const int kcol = 32 * (w & 3) + l31;
@@ -345,6 +385,10 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
     if (w < 4 && n < nrows) {
       const int64_t off = w_off + (int64_t)n * kMH + kcol;
       Wr[i] = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+      if (pend) {
+        Wr[i] = adam_weight(p.grads[off], Mr[i], Vr[i], Wr[i], pa0, pa1, ak);
+        xwg_store(p.params + off, Wr[i]); p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+      }
     }
   }
   // the owners' operand-order copies of W2 (see MdnnArgs)
@@ -354,22 +398,26 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
     xwg_store(p.w2f_pack + ((((n >> 4) * 8 + (kcol >> 4)) * 2 + ((kcol >> 1) & 1)) * 64 + lf) * 2 + (kcol & 1), Wr[i]);
     xwg_store(p.w2b_pack + ((((kcol >> 4) * 8 + (n >> 4)) * 2 + ((n >> 1) & 1)) * 64 + lb) * 2 + (n & 1), Wr[i]);
   };
-  if (is_w2) {
-    if (w < 4) {
+  if (is_w2 && w < 4) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) publish_w2(i, h, kcol);
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0)
-      __hip_atomic_store(p.flag_pack + sb, p.launch_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 16; ++i) publish_w2(i, h, kcol);
   }
   // wave 4, lanes 0-31: the 32 biases
   const bool bias_lane = w == 4 && lane < kMNB && n0 + lane < nrows;
   float bw = 0.f, bm = 0.f, bv = 0.f;
   if (bias_lane) {
-    bw = p.params[b_off + n0 + lane]; bm = p.m1[b_off + n0 + lane]; bv = p.m2[b_off + n0 + lane];
+    const int64_t off = b_off + n0 + lane;
+    bw = p.params[off]; bm = p.m1[off]; bv = p.m2[off];
+    if (pend) {
+      bw = adam_bias(p.grads[off], bm, bv, bw, pa0, pa1, ak);
+      xwg_store(p.params + off, bw); p.m1[off] = bm; p.m2[off] = bv;
+    }
   }
+  // the weights as of the start of this launch are out (owners wait for every block)
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0)
+    __hip_atomic_store(p.flag_pack + sb, p.launch_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int idx = tid; idx < (p.FR - B) * kMHP; idx += kMT) Hs[B * kMHP + idx] = 0.f;
   __syncthreads();
 
@@ -436,34 +484,47 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int n = n0 + acc_row(i, h_l);
-        Wr[i] = adam_weight(acc[i], Mr[i], Vr[i], Wr[i], a0, a1, ak);
-        if (n < nrows) xwg_store(p.params + w_off + (int64_t)n * kMH + kcol_l, Wr[i]);
-        if (is_w2) publish_w2(i, h_l, kcol_l);
+        if (DP) {
+          if (n < nrows) p.grads[w_off + (int64_t)n * kMH + kcol_l] = acc[i];
+        } else {
+          Wr[i] = adam_weight(acc[i], Mr[i], Vr[i], Wr[i], a0, a1, ak);
+          if (n < nrows) xwg_store(p.params + w_off + (int64_t)n * kMH + kcol_l, Wr[i]);
+          if (is_w2) publish_w2(i, h_l, kcol_l);
+        }
       }
     } else if (bias_lane) {
       float g = 0.f;
       for (int b = 0; b < B; ++b) g += X[lane * DOP + b];
-      bw = adam_bias(g, bm, bv, bw, a0, a1, ak);
-      xwg_store(p.params + b_off + n0 + lane, bw);
+      if (DP) {
+        p.grads[b_off + n0 + lane] = g;
+      } else {
+        bw = adam_bias(g, bm, bv, bw, a0, a1, ak);
+        xwg_store(p.params + b_off + n0 + lane, bw);
+      }
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0)
-      __hip_atomic_store(p.flag_small + sb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!DP) {
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(p.flag_small + sb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     BSIG_MSTAMP(6);
   }
+  if (!DP) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int n = n0 + acc_row(i, h);
-    if (w < 4 && n < nrows) {
-      const int64_t off = w_off + (int64_t)n * kMH + kcol;
-      p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + acc_row(i, h);
+      if (w < 4 && n < nrows) {
+        const int64_t off = w_off + (int64_t)n * kMH + kcol;
+        p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+      }
     }
+    if (bias_lane) { p.m1[b_off + n0 + lane] = bm; p.m2[b_off + n0 + lane] = bv; }
   }
-  if (bias_lane) { p.m1[b_off + n0 + lane] = bm; p.m2[b_off + n0 + lane] = bv; }
 }
 
 // ---- row-owner workgroups: layers 2.., NLL forward / backward ---------------------
+template <bool DP>
 __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
   const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
   const int po = Nh16 + 4;                   // pitch of a head-output row
@@ -497,7 +558,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   // k-slice sum), w2b[4t + j] = W2[16t + 4g + j][16w + c16] (backward, fetched under the
   // wait for the other owners' rows)
 
-  if (w_0 == 0) flags_wait(p.flag_pack, kMH / kMNB, p.launch_tag, tid_0 & 63, flagp);
+  if (w_0 == 0) flags_wait(p.flag_pack, p.n_small, p.launch_tag, tid_0 & 63, flagp);
   __syncthreads();
   for (int t = 0; t < p.n_updates; ++t) {
     // lane-derived indices are laundered once per update so that the address
@@ -519,7 +580,8 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     if (run_aborted(flagp, red, tid)) break;
     BSIG_MSTAMP(0);
     // ---- weights of this update (written by the small-weight workgroups) ---------
-    if (w == 0) flags_wait(p.flag_small, p.n_small, epoch - 1u, lane, flagp);
+    // (first update of a launch, and the only one of a data-parallel launch: flag_pack above)
+    if (!DP && t > 0 && w == 0) flags_wait(p.flag_small, p.n_small, epoch - 1u, lane, flagp);
     __syncthreads();
     BSIG_MSTAMP(4);
     for (int base = 0; base < Nh16 * (kMH / 2); base += kMT * 8) {
@@ -779,12 +841,14 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   }
 }
 
+// DP: data-parallel rank (gradients out, pending Adam step in; see MdnnArgs)
+template <bool DP>
 __global__ __launch_bounds__(kMT) void mdnn_updates_kernel(MdnnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wg = blockIdx.x;
-  if (wg < p.G1) mdnn_tile_workgroup(p, smem);
-  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup(p, smem);
-  else mdnn_small_workgroup(p, smem);
+  if (wg < p.G1) mdnn_tile_workgroup<DP>(p, smem);
+  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP>(p, smem);
+  else mdnn_small_workgroup<DP>(p, smem);
 }
 
 // ---------------------------------------------------------------- host side
@@ -878,10 +942,14 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
                "persistent MDNN updates: summaries must be 16-byte aligned rows");
   BSIG_REQUIRE(b.w2_off % 2 == 0 && b.wh_off % 2 == 0 && aligned(b.params, 16),
                "persistent MDNN updates: weight blocks must be 8-byte aligned");
-  if (n <= 0) return BSIG_OK;
+  BSIG_REQUIRE(!(b.adam_pending && !b.grads), "persistent MDNN updates: pending Adam step without gradients");
+  BSIG_REQUIRE(!(b.grads && n > 1), "persistent MDNN updates: data-parallel launches take one update");
+  if (n <= 0 && !b.adam_pending) return BSIG_OK;
   static bool attr_set = false;
   if (!attr_set) {
-    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mdnn_updates_kernel),
+    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mdnn_updates_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit));
+    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mdnn_updates_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit));
     attr_set = true;
   }
@@ -889,7 +957,8 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.B = s.batch; p.FR = g.FR; p.I = s.input_dim; p.Nh = g.Nh; p.Nh16 = g.Nh16; p.NhP = g.NhP;
   p.D = s.out_dim; p.K = s.n_comp;
   p.k_slices = g.k_slices; p.G1 = g.G1; p.n_owner = g.n_owner; p.n_small = g.n_small;
-  p.n_updates = n; p.x_floats = g.x_floats;
+  p.n_updates = std::max(n, 0); p.x_floats = g.x_floats;
+  p.grads = b.grads; p.adam_pending = b.adam_pending;
   p.x = b.x; p.ldx = b.ldx; p.ids = b.ids; p.y = b.y; p.ldy = b.ldy;
   p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq;
   p.w1_off = b.w1_off; p.b1_off = b.b1_off; p.w2_off = b.w2_off; p.b2_off = b.b2_off;
@@ -916,7 +985,10 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.launch_tag = ++launch_tag;
   p.gran = reinterpret_cast<unsigned long long*>(sync + 4 * kXwgMax * sizeof(unsigned));
   p.prof = reinterpret_cast<long long*>(persist_profile_buffer());
-  hipLaunchKernelGGL(mdnn_updates_kernel, dim3(g.G1 + g.n_owner + g.n_small), dim3(kMT), g.lds, st, p);
+  if (b.grads)
+    hipLaunchKernelGGL(mdnn_updates_kernel<true>, dim3(g.G1 + g.n_owner + g.n_small), dim3(kMT), g.lds, st, p);
+  else
+    hipLaunchKernelGGL(mdnn_updates_kernel<false>, dim3(g.G1 + g.n_owner + g.n_small), dim3(kMT), g.lds, st, p);
   BSIG_CHECK_LAUNCH("mdnn_updates");
   return BSIG_OK;
 }

@@ -20,6 +20,11 @@ struct PersistMdnnBuffers {
   int32_t* state;                         // the fit engine's 16-word state block
   float* train_loss;                      // [n_updates]
   void* workspace; size_t workspace_bytes;
+  // data-parallel ranks (null / 0 otherwise): the gradients of the update go to `grads`
+  // (flat layout) for the caller's all-reduce instead of into Adam; with `adam_pending` the
+  // launch first takes the Adam step of the previous update from the (reduced) `grads`.
+  // n = 0 with adam_pending: that step only.
+  float* grads = nullptr; int adam_pending = 0;
 };
 
 struct PersistHyper;   // persist.h

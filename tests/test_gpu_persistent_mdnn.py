@@ -149,3 +149,35 @@ def test_nonfinite_summary_raises_through_persistent_mdnn(B):
     ids[0, 0] = 5
     with pytest.raises(AssertionError):
         bs.model.run_training(bs._summarize(states, actions), theta, 100, 100, ids_table=ids)
+
+
+@pytest.mark.parametrize('eps', [0.0, 1e-5])
+def test_data_parallel_rank_in_persistent_mdnn_kernel_is_bitwise(B, eps):
+    """A data-parallel rank runs each update as ONE launch of the MDNN persistent
+    kernel (gradients out -> all-reduce -> the Adam step taken by the weights'
+    owners at the start of the next launch).  On a 1-rank group that is the same
+    arithmetic as the resident single-rank run: weights and losses bitwise equal."""
+    import bench
+    import torch.distributed as dist
+    cfg = _cfg(4, 6, 'summary_corrdiff', 12, 7, 3)
+    logs_p, flat_p, bs_p, _ = _chunk(B, cfg, eps=eps)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29579')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        B.MDNN.EPS_NOISE = eps
+        theta, states, actions = bench.synth_pairs(cfg, 1000, 3, DEV)
+        bs = bench.build_gpu_model(B, cfg, DEV, 77)
+        bs.model.enable_data_parallel()
+        ids = np.random.RandomState(5).randint(0, 800, (100, 100))
+        logs_d = bs.model.run_training(bs._summarize(states, actions), theta, 100, 100,
+                                       ids_table=ids)
+        flat_d = bs.model._flat.clone()
+        assert B._lib.load().bsig_fit_is_persistent(bs.model._plan) == 2
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert logs_d == logs_p
+    assert torch.equal(flat_d, flat_p)
