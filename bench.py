@@ -255,7 +255,7 @@ def time_update_kernel(pkg, cfg, bsim, device):
     us = total_ms * 1e3 / launches
     nh = cfg['k'] * (1 + 2 * cfg['d'])
     if cfg['model'] != 'MDRFF':
-        return mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh)
+        return mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp)
     f_in = m.rff.m_feat * 2
     per_visit = 2.0 * 2.0 * f_in * nh                 # SURVEY 8(d) K6+K7, MDRFF heads: fwd + dW
     flops = per_visit * batch * (float(n_updates) / len(runs))
@@ -280,7 +280,7 @@ def time_update_kernel(pkg, cfg, bsim, device):
                     'fp32-MFMA work per CU; see DESIGN.md and scaled_batch_mode for the MFMA-bound regime'}
 
 
-def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh):
+def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp=False):
     """MDNN [128, 128]: the persistent update kernel (csrc/fit_persistent_mdnn.hip).
     Algorithmic work per row visit (SURVEY.md 8(d) K5 + K6/K7): first layer forward + dW1
     (no dX of the input), second layer and heads forward + dW + dX."""
@@ -288,12 +288,15 @@ def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh):
     per_visit = 2.0 * (2.0 * i * h) + 3.0 * (2.0 * h * h) + 3.0 * (2.0 * h * nh)
     flops = per_visit * batch * (float(n_updates) / len(runs))
     ach = flops / (us * 1e-6) / 1e12
-    traffic, tsrc = pmc_traffic('mdnn_updates_kernel')
+    traffic, tsrc = pmc_traffic('mdnn_updates_kernel') if not dp else (None, None)
     return {'bound': 'mfma',
             'kernel': 'mdnn_updates_kernel: persistent update kernel of the two-layer MDNN, '
                       'trunk %d-128-128, heads %d, minibatch %d, %s updates per launch (mean %.1f): '
-                      'forward, NLL fwd/bwd, backward, Adam'
-                      % (i, nh, batch, '/'.join(str(r) for r in runs), float(n_updates) / len(runs)),
+                      'forward, NLL fwd/bwd, backward, Adam%s'
+                      % (i, nh, batch, '/'.join(str(r) for r in runs) if not dp else '1',
+                         float(n_updates) / len(runs),
+                         ' (data-parallel rank: gradients written for the all-reduce, Adam step of '
+                         'the previous update taken from the reduced gradients)' if dp else ''),
             'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
             'traffic': traffic, 'traffic_source': tsrc, 'avg_us': us,
             'us_per_update': us * len(runs) / n_updates,
@@ -344,7 +347,7 @@ def time_dominant_kernel(pkg, cfg, bsim, device):
     if cfg['model'] == 'MDRFF':
         return time_update_kernel(pkg, cfg, bsim, device)
     m = bsim.model
-    if m._dp is None and int(lib.bsig_fit_is_persistent(m._plan)) == 2:
+    if int(lib.bsig_fit_is_persistent(m._plan)) == 2:
         return time_update_kernel(pkg, cfg, bsim, device)
     b, i, h0 = 100, m.input_dim, m._hidden[0]
     x = torch.randn(1000, L.round_up(i, 4), device=device)
