@@ -82,13 +82,23 @@ constexpr int kProfUpdates = 8;
     const int idx = min((u) * kPT + tid, nvec - 1);                                       \
     const int64_t r = pf_row0 + (idx >> 6);                                               \
     const int64_t fr = p.feat_ids ? (int64_t)p.feat_ids[r] : r;                           \
-    pf##u = *reinterpret_cast<const float4*>(p.feats + fr * p.ld_feats + k0 + (idx & 63) * 4); \
+    const int64_t col = min((int64_t)k0 + (idx & 63) * 4, p.ld_feats - 4);                \
+    pf##u = *reinterpret_cast<const float4*>(p.feats + fr * p.ld_feats + col);            \
   }
 #define BSIG_PF_ZERO(u) pf##u = make_float4(0.f, 0.f, 0.f, 0.f);
+// (columns >= F, the tail of the last k-slice when F is not a multiple of 256, enter as zeros)
 #define BSIG_PF_STORE(u)                                                                  \
   {                                                                                       \
     const int idx = (u) * kPT + tid;                                                      \
-    if (idx < nvec) *reinterpret_cast<float4*>(Fl + (idx >> 6) * kPitch + (idx & 63) * 4) = pf##u; \
+    if (idx < nvec) {                                                                     \
+      const int col = k0 + (idx & 63) * 4;                                                \
+      float4 v = pf##u;                                                                   \
+      if (col + 3 >= p.Fdim) {                                                            \
+        v.x = col + 0 < p.Fdim ? v.x : 0.f; v.y = col + 1 < p.Fdim ? v.y : 0.f;           \
+        v.z = col + 2 < p.Fdim ? v.z : 0.f; v.w = col + 3 < p.Fdim ? v.w : 0.f;           \
+      }                                                                                   \
+      *reinterpret_cast<float4*>(Fl + (idx >> 6) * kPitch + (idx & 63) * 4) = v;          \
+    }                                                                                     \
   }
 
 // ---- tile workgroups: forward partial products, dW, Adam ----------------------
@@ -117,6 +127,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
   // lives in LDS (it is the B operand of the forward product)
   float Mr[16], Vr[16];
   const int kcol = 32 * w + l31;
+  const bool col_ok = k0 + kcol < p.Fdim;
   constexpr bool dp = DP;
   const bool pend = DP && p.adam_pending != 0;
   // data-parallel: Adam scalars of the update whose reduced gradients are pending
@@ -127,7 +138,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     const int n = n0 + acc_row(i, h);
     float wv = 0.f;
     Mr[i] = 0.f; Vr[i] = 0.f;
-    if (n < Nh) {
+    if (n < Nh && col_ok) {
       const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
       wv = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
       if (pend) {
@@ -301,7 +312,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int n = n0 + acc_row(i, h_l);
-          if (n < Nh) p.grads[p.w_off + (int64_t)n * p.Fdim + k0 + kcol_l] = acc[i];
+          if (n < Nh && k0 + kcol_l < p.Fdim) p.grads[p.w_off + (int64_t)n * p.Fdim + k0 + kcol_l] = acc[i];
         }
       } else {
 #pragma unroll
@@ -328,7 +339,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int n = n0 + acc_row(i, h);
-      if (n < Nh) {
+      if (n < Nh && col_ok) {
         const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
         p.params[off] = Wl[acc_row(i, h) * kPitch + kcol]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
       }
@@ -490,7 +501,7 @@ struct PersistGeom {
 };
 
 static bool persist_geom(const PersistShape& s, PersistGeom* g) {
-  if (s.batch < 1 || s.feat_dim < kPC || s.feat_dim % kPC != 0 || s.out_dim < 1 ||
+  if (s.batch < 1 || s.feat_dim < 4 || s.feat_dim % 4 != 0 || s.out_dim < 1 ||
       s.n_comp < 1 || s.n_comp > 64)
     return false;
   const int groups = 64 / s.n_comp;
@@ -500,7 +511,7 @@ static bool persist_geom(const PersistShape& s, PersistGeom* g) {
   g->Nh = s.n_comp + 2 * s.out_dim * s.n_comp;
   g->n_blocks = ceil_div(g->Nh, kNB);
   g->NhP = g->n_blocks * kNB;
-  g->k_slices = s.feat_dim / kPC;
+  g->k_slices = ceil_div(s.feat_dim, kPC);
   g->G = g->n_blocks * g->k_slices;          // tile workgroups
   if (g->G > kXwgMax - 8 || g->k_slices > 32) return false;
   // row owners: further workgroups, every workgroup of the launch on its own CU

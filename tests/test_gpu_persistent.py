@@ -54,7 +54,9 @@ def _chunk(B, cfg, n=1000, batch=100, n_updates=100, seed=3, eps=None, env=None)
 
 # (D, K, n_feat): two head blocks x two k-slices; the cfg2 head on 1024 features;
 # 11 head blocks x 16 k-slices (176 tile workgroups: two rows per owner workgroup)
-SHAPES = [(3, 5, 512), (13, 10, 1024), (40, 4, 4096)]
+# ; the reference's own feature counts (bayes_sim.py:81 n_feat=200, MDRFF default 500:
+# one / two k-slices with a masked tail)
+SHAPES = [(3, 5, 512), (13, 10, 1024), (40, 4, 4096), (2, 10, 200), (5, 3, 500)]
 
 
 @pytest.mark.parametrize('d,k,n_feat', SHAPES)
@@ -67,6 +69,7 @@ def test_persistent_chunk_matches_oracle(B, d, k, n_feat):
     cfg = _cfg(d, k, n_feat)
     torch.set_num_threads(8)
     logs, flat, bs, (theta, states, actions, ids) = _chunk(B, cfg, eps=0.0)
+    assert B._lib.load().bsig_fit_is_persistent(bs.model._plan) == 1
     ora = bench.build_oracle(cfg, bs.model.rff.d, 77, 0.0, freqs=bs.model.rff.freqs.cpu().numpy())
     bs0 = bench.build_gpu_model(B, cfg, DEV, 77)
     ora.load_state_dict({kk: v.cpu() for kk, v in bs0.model.state_dict().items()})
@@ -82,12 +85,13 @@ def test_persistent_chunk_matches_oracle(B, d, k, n_feat):
         assert torch.allclose(sd[name].cpu(), v, atol=2e-4, rtol=1e-3), name
 
 
+@pytest.mark.parametrize('n_feat', [512, 200])
 @pytest.mark.parametrize('eps', [0.0, 1e-5])
-def test_persistent_equals_phase_kernels(B, eps):
+def test_persistent_equals_phase_kernels(B, eps, n_feat):
     """Same chunk through the persistent kernel and through the per-phase
     kernels it replaces (BSIG_NO_PERSISTENT=1): the jitter RNG streams are the
     same, the arithmetic differs only in summation order."""
-    cfg = _cfg(4, 6, 512)
+    cfg = _cfg(4, 6, n_feat)
     logs_p, flat_p, _, _ = _chunk(B, cfg, eps=eps)
     logs_k, flat_k, _, _ = _chunk(B, cfg, eps=eps, env={'BSIG_NO_PERSISTENT': '1'})
     for key in ('train_loss', 'test_loss'):
