@@ -323,6 +323,12 @@ def test_data_parallel_path_single_rank_equals_fused(B):
     dict(n=30, i=6, d=2, k=3, hidden=(), full=False, nu=5, bs=8, tf=0.0),        # no held-out rows
     dict(n=64, i=130, d=4, k=5, hidden=None, full=False, nu=6, bs=32, tf=0.25),  # MDRFF
     dict(n=33, i=5, d=6, k=2, hidden=(12,), full=True, nu=4, bs=10, tf=0.2),
+    # the reference's default trunk: the persistent MDNN kernel (fit_persistent_mdnn.hip)
+    dict(n=50, i=7, d=1, k=1, hidden=(128, 128), full=False, nu=3, bs=16, tf=0.2),
+    dict(n=5, i=4, d=2, k=2, hidden=(128, 128), full=False, nu=1, bs=3, tf=0.2),
+    dict(n=40, i=9, d=3, k=4, hidden=(128, 128), full=False, nu=7, bs=100, tf=0.5),
+    dict(n=30, i=6, d=2, k=3, hidden=(128, 128), full=False, nu=5, bs=8, tf=0.0),
+    dict(n=33, i=301, d=6, k=2, hidden=(128, 128), full=False, nu=4, bs=10, tf=0.2),
 ])
 def test_run_training_edge_cases_match_oracle(B, case):
     """Shapes off the beaten path (K=1, D=1, one update, batch larger than the
@@ -351,6 +357,8 @@ def test_run_training_edge_cases_match_oracle(B, case):
     n_train = max(int(c['n'] * (1.0 - c['tf'])), 1)
     ids = np.random.RandomState(1).randint(0, n_train, (c['nu'], c['bs']))
     got = m.run_training(x.to(DEV), y.to(DEV), c['nu'], c['bs'], test_frac=c['tf'], ids_table=ids)
+    if c['hidden'] == (128, 128):
+        assert B._lib.load().bsig_fit_is_persistent(m._plan) == 2
     if c['tf'] == 0.0:
         # empty held-out split: torch 2.10's MultivariateNormal refuses an empty
         # batch (the reference would crash there); the HIP path logs NaN like
