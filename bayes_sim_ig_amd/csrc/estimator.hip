@@ -385,13 +385,16 @@ static void plan_mem(const bsig_fit_plan* p, PlanMem* m) {
 }
 
 static PersistShape persist_shape(const bsig_fit_plan* p) {
-  return PersistShape{(int)p->batch, (int)p->L.feat_dim, p->cfg.head.out_dim, p->cfg.head.n_comp};
+  return PersistShape{(int)p->batch, (int)p->L.feat_dim, p->cfg.head.out_dim, p->cfg.head.n_comp,
+                      (int)std::min<int64_t>(p->max_test, 1 << 20)};
 }
 
 // n consecutive updates in the persistent kernel.  Data-parallel plans
 // (split_adam): ONE update whose gradients go to the flat gradient buffer, after
 // the pending Adam step of the previous one; n = 0 flushes that step.
-static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st) {
+// with_eval: the n updates are a whole bsig_fit_run call and its held-out
+// evaluations run inside the launch.
+static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st, bool with_eval = false) {
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
   PersistBuffers pb;
@@ -405,6 +408,12 @@ static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st) {
   if (p->split_adam) {
     pb.grads = b.grads; pb.adam_pending = p->adam_pending ? 1 : 0;
     p->adam_pending = false;
+  }
+  if (with_eval) {
+    pb.do_eval = 1; pb.n_total = n; pb.eval_every = std::max(n / 5, 1);   // mdnn.py:235
+    pb.n_test = (int)b.n_test;
+    pb.eval_row0 = p->feat_unique ? b.n_train : p->n_updates * p->batch;  // as eval_inputs()
+    pb.y_test = b.y_test; pb.ldy_test = b.ldy_test; pb.test_loss = b.test_loss;
   }
   PersistHyper hy;
   hy.lr = p->cfg.lr; hy.beta1 = p->cfg.beta1; hy.beta2 = p->cfg.beta2;
@@ -859,6 +868,11 @@ extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t s
                (long long)p->n_updates);
   hipStream_t st = as_stream(stream);
   if (p->use_graph) BSIG_TRY(ensure_graphs(p));
+  // linear heads on cached features: the whole call, evaluations included, is ONE launch
+  const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
+  if (p->persistent && !p->split_adam && n_updates >= 1 && p->buf.n_test >= 1 &&
+      !(no_ike && no_ike[0] == '1') && persist_eval_supported(persist_shape(p)))
+    return enqueue_persistent(p, (int)n_updates, st, true);
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
   int64_t done = 0;
   for (int64_t it = 0; it < n_updates; ++it) {

@@ -63,8 +63,24 @@ struct PersistArgs {
   // Adam step of the PREVIOUS update (on the reduced gradients) is taken while the
   // tile is loaded (adam_pending)
   float* grads; int adam_pending;
+  // held-out evaluations inside the launch (mdnn.py:235-242; do_eval): after update `it`
+  // with it % eval_every == 0, or after the last of the call's n_total updates.  The tile
+  // workgroups form the held-out rows' products while they wait for the row owners of the
+  // NEXT update (their LDS still holds the evaluated weights), the owners evaluate their
+  // rows after they have published that update's rows.
+  int do_eval, eval_every, n_total, n_test, eval_passes;
+  int64_t eval_row0;                 // first held-out row in `feats`
+  const float* y_test; int64_t ldy_test;
+  float* test_loss;                  // [n_evals]
+  float* eval_slabs;                 // [2][eval_passes][k_slices][B][NhP]
+  unsigned* flag_eval;               // [G]      evaluation number + 1
+  unsigned long long* gran_eval;     // [2][kXwgMax] {tag, value}: sum exp(pre), sum logsumexp
   long long* prof;   // diagnostics: [G][kProfUpdates][16] wall-clock stamps, or null
 };
+
+// number of evaluation points it % every == 0 strictly before update s (the evaluation after
+// the last update of a call is not one of them)
+__device__ __forceinline__ int evals_before(int s, int every) { return s == 0 ? 0 : (s - 1) / every + 1; }
 
 constexpr int kProfUpdates = 8;
 #define BSIG_STAMP(k)                                                              \
@@ -100,6 +116,71 @@ constexpr int kProfUpdates = 8;
       *reinterpret_cast<float4*>(Fl + (idx >> 6) * kPitch + (idx & 63) * 4) = v;          \
     }                                                                                     \
   }
+
+// ---- tile workgroups, evaluation number eidx: held-out rows x this tile's weights (the A
+//      operand straight from memory: the minibatch tile in LDS is still needed for dW) ->
+//      evaluation slabs, flag.  Deliberately NOT inlined: it runs a few times per call, and
+//      its registers must not weigh on the update loop.
+__device__ __forceinline__ void tile_eval(const PersistArgs& p, const float* Wl, float* X,
+                                                    const float* biasl, int eidx) {
+  // (laundered: nothing below may be computed ahead of the update loop and kept live in it)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wg = blockIdx.x, ks = wg % p.k_slices, nb = wg / p.k_slices;
+  const int n0 = nb * kNB, k0 = ks * kPC;
+  const int B = p.B, NhP = p.NhP;
+  const int mt = w & 3, kh = w >> 2;
+  for (int pass = 0; pass < p.eval_passes; ++pass) {
+    const int rows = min(B, p.n_test - pass * B);
+    if (rows <= 0) break;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int64_t r = p.eval_row0 + pass * B + min(mt * 32 + l31, rows - 1);
+    const float* src = p.feats + r * p.ld_feats;
+    const float* bp = Wl + l31 * kPitch + kh * 128 + 4 * h;
+    // two halves of the k range: 8 x 16 bytes of the A operand in registers at a time
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      float4 areg[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int64_t col = min((int64_t)k0 + kh * 128 + 64 * half + 8 * q + 4 * h, p.ld_feats - 4);
+        areg[q] = *reinterpret_cast<const float4*>(src + col);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 64 * half + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].w, b4.w, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();                       // X free (previous pass read)
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h)) * kPbufPitch + l31] = acc[i];
+    }
+    __syncthreads();
+    if (kh == 0) {
+      const float bias = ks == 0 ? biasl[l31] : 0.f;
+      float* dst = p.eval_slabs + ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B) * NhP + n0 + l31;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = mt * 32 + acc_row(i, h);
+        const float v = acc[i] + X[row * kPbufPitch + l31] + bias;
+        if (row < rows) xwg_store(dst + (int64_t)row * NhP, v);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0)
+    __hip_atomic_store(p.flag_eval + wg, (unsigned)eidx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- tile workgroups: forward partial products, dW, Adam ----------------------
 template <bool DP>
@@ -244,7 +325,10 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
       BSIG_STAMP(3);
     }
 
-    // ---- while the row owners work: next feature tile, Adam scalars -----------
+    // ---- while the row owners work: the evaluation due after the previous update
+    //      (this tile still holds those weights), next feature tile, Adam scalars ------
+    if (__builtin_expect(!dp && p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
+      tile_eval(p, Wl, X, biasl, evals_before(step, p.eval_every) - 1);
     if (t + 1 < p.n_updates) {
       const int64_t pf_row0 = (int64_t)(step + 1) * B;
       BSIG_PF_LIST(BSIG_PF_LOAD)
@@ -333,6 +417,13 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     BSIG_STAMP(12);
   }
 
+  // ---- the evaluation after the last update of the call ----------------------------
+  if (!dp && p.do_eval && step0 + p.n_updates == p.n_total) {
+    if (bias_pending && tid < kNB) bias_step(tid);
+    bias_pending = false;
+    __syncthreads();
+    tile_eval(p, Wl, X, biasl, evals_before(p.n_total - 1, p.eval_every));
+  }
   // ---- write the tile back, advance the engine state -------------------------
   const bool dirty = !dp;
   if (dirty) {
@@ -358,7 +449,13 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     reinterpret_cast<double*>(st + 12)[1] = b2t;
     reinterpret_cast<float*>(st)[4] = a0;
     reinterpret_cast<float*>(st)[5] = a1;
-    reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)p.n_updates;
+    // (one jitter stream per update and per evaluation, in program order)
+    int n_ev = 0;
+    if (p.do_eval) {
+      n_ev = evals_before(step0 + p.n_updates, p.eval_every) - evals_before(step0, p.eval_every);
+      if (step0 + p.n_updates == p.n_total && (p.n_total - 1) % p.eval_every != 0) ++n_ev;
+    }
+    reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)(p.n_updates + n_ev);
     st[0] = step0 + p.n_updates;
   }
 }
@@ -391,6 +488,84 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
   const bool active = owner_wave && row < B;
   const int nelem = min(p.R, B - r0) * Nh;
   const int64_t zs = (int64_t)B * NhP;
+
+  // ---- held-out evaluation number eidx (jitter stream `stream`): slot s = pass * R + r
+  //      <-> held-out row pass * B + r0 + r, one wavefront per slot, forward only ---------
+  auto owner_eval = [&](int eidx, uint64_t stream) {
+    const unsigned etag = (unsigned)eidx + 1u;
+    const int nslots = p.eval_passes * p.R;
+    if (w == 0) flags_wait(p.flag_eval, p.G, etag, lane, flagp);
+    __syncthreads();
+    float eacc = 0.f;
+    for (int idx = tid; idx < nslots * Nh; idx += kPT) {
+      const int sl = idx / Nh, col = idx - sl * Nh;
+      const int pass = sl / p.R, r = sl - pass * p.R;
+      const bool valid = r0 + r < B && pass * B + r0 + r < p.n_test;
+      const float* src = p.eval_slabs +
+                         ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices) * B + min(r0 + r, B - 1)) * NhP + col;
+      float v = 0.f;
+      for (int z = 0; z < p.k_slices; z += 16) {
+        float q[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) q[u] = xwg_load(src + (int64_t)min(z + u, p.k_slices - 1) * zs);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (z + u < p.k_slices) v += q[u];
+      }
+      X[sl * per_wave + col] = valid ? v : 0.f;
+      if (valid && col >= K + DK && col < K + 2 * DK) eacc += expf(v);
+    }
+    eacc = wave_sum_dpp(eacc);
+    if (lane == 0) red[w] = eacc;
+    __syncthreads();
+    if (tid == 0) {
+      float sx = 0.f;
+      for (int q = 0; q < kPT / 64; ++q) sx += red[q];
+      granule_publish(p.gran_eval + o, etag, sx);
+    }
+    const int pass = w / p.R, r = w - pass * p.R;
+    const int erow = pass * B + r0 + r;
+    const bool act = w < nslots && r0 + r < B && erow < p.n_test;
+    if (act)
+      for (int j = lane; j < D; j += 64) yv[j] = p.y_test[(int64_t)erow * p.ldy_test + j];
+    RowOut ro;
+    ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
+#pragma unroll
+    for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
+    if (w < nslots) {
+      HeadArgs ae = a;
+      ae.d_out = nullptr;                    // forward only
+      ae.batch = p.n_test;
+      ae.stream_id = stream;
+      diag_row(ae, erow, act, lane, tile, yv, rk, lpk, dlg,
+               [&] {
+                 return p.eps_noise != 0.f
+                            ? p.eps_noise * (granule_gather(p.gran_eval, p.n_owner, etag, lane, flagp) /
+                                             ((float)p.n_test * (float)DK))
+                            : 0.f;
+               },
+               ro);
+    }
+    if (lane == 0) red[16 + w] = act ? ro.lse : 0.f;
+    __syncthreads();
+    if (tid == 0) {
+      float sl = 0.f;
+      for (int q = 0; q < kPT / 64; ++q) sl += red[16 + q];
+      granule_publish(p.gran_eval + kXwgMax + o, etag, sl);
+    }
+    if (o == 0 && w == 0) {
+      const float sum = granule_gather(p.gran_eval + kXwgMax, p.n_owner, etag, lane, flagp);
+      if (lane == 0) {
+        const float l = -sum / (float)p.n_test;
+        p.test_loss[p.state[1]] = l;
+        p.state[1] = p.state[1] + 1;
+        if (!isfinite(l)) atomicOr(flagp, 1);
+      }
+    }
+    if (ro.bad) atomicOr(flagp, 1);
+    __syncthreads();
+  };
+  const int ev0 = p.do_eval ? evals_before(step0, p.eval_every) : 0;
 
   for (int t = 0; t < p.n_updates; ++t) {
     const int step = step0 + t;
@@ -436,7 +611,9 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
     for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
     float uds_w = 0.f;
     if (owner_wave) {
-      a.stream_id = rng_ctr0 + (uint64_t)t;
+      // one jitter stream per update and per evaluation, in program order
+      a.stream_id = rng_ctr0 + (uint64_t)t +
+                    (uint64_t)(p.do_eval ? evals_before(step, p.eval_every) - ev0 : 0);
       diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg,
                [&] {
                  BSIG_STAMP(6);
@@ -482,7 +659,17 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
       }
     }
     if (ro.bad) atomicOr(flagp, 1);
+    // the evaluation due after the previous update: the tile workgroups formed its
+    // products while this update's rows were being finished
+    if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
+      __syncthreads();
+      owner_eval(evals_before(step, p.eval_every) - 1,
+                 rng_ctr0 + (uint64_t)t + (uint64_t)(evals_before(step, p.eval_every) - ev0) - 1u);
+    }
   }
+  if (p.do_eval && step0 + p.n_updates == p.n_total && !run_aborted(flagp, red, tid))
+    owner_eval(evals_before(p.n_total - 1, p.eval_every),
+               rng_ctr0 + (uint64_t)p.n_updates + (uint64_t)(evals_before(p.n_total - 1, p.eval_every) - ev0));
 }
 
 // DP: data-parallel rank (gradients out, pending Adam step in; see PersistArgs)
@@ -496,8 +683,9 @@ __global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p)
 // ---------------------------------------------------------------- host side
 struct PersistGeom {
   int FR, Nh, NhP, n_blocks, k_slices, G, n_owner, R, x_floats;
+  int eval_passes;              // 0: evaluations stay outside the launches
   size_t lds;
-  size_t slab_floats, dout_floats;
+  size_t slab_floats, dout_floats, eval_floats;
 };
 
 static bool persist_geom(const PersistShape& s, PersistGeom* g) {
@@ -528,6 +716,10 @@ static bool persist_geom(const PersistShape& s, PersistGeom* g) {
   if (g->lds > (size_t)kLdsLimit) return false;
   g->slab_floats = (size_t)g->k_slices * s.batch * g->NhP;
   g->dout_floats = (size_t)s.batch * g->NhP;
+  // in-launch evaluations: one wavefront of an owner workgroup per held-out row slot
+  g->eval_passes = s.max_test > 0 ? ceil_div(s.max_test, s.batch) : 0;
+  if (g->eval_passes * g->R > kPT / 64) g->eval_passes = 0;
+  g->eval_floats = (size_t)2 * g->eval_passes * g->slab_floats;
   return true;
 }
 
@@ -546,13 +738,20 @@ bool persist_supported(const PersistShape& s) {
   PersistGeom g;
   return persist_geom(s, &g) && device_can_host(g);
 }
+bool persist_eval_supported(const PersistShape& s) {
+  PersistGeom g;
+  return persist_geom(s, &g) && device_can_host(g) && g.eval_passes > 0;
+}
 
-static size_t sync_bytes() { return kXwgMax * sizeof(unsigned) + 3 * kXwgMax * 8; }
+static size_t data_bytes(const PersistGeom& g) {
+  return round_up<size_t>((g.slab_floats + 2 * g.dout_floats + g.eval_floats) * sizeof(float), 256);
+}
+static size_t sync_bytes() { return 2 * kXwgMax * sizeof(unsigned) + 5 * kXwgMax * 8; }
 
 size_t persist_workspace_bytes(const PersistShape& s) {
   PersistGeom g;
   if (!persist_geom(s, &g)) return 0;
-  return round_up<size_t>((g.slab_floats + 2 * g.dout_floats) * sizeof(float), 256) + sync_bytes();
+  return data_bytes(g) + sync_bytes();
 }
 
 int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -562,8 +761,9 @@ int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes
                "persistent updates: workspace too small");
   char* base = reinterpret_cast<char*>(workspace);
   const size_t slab_bytes = g.slab_floats * sizeof(float);
-  // d_out (its padding columns stay zero), flags and granules
-  BSIG_HIP(hipMemsetAsync(base + slab_bytes, 0, persist_workspace_bytes(s) - slab_bytes, st));
+  // d_out / exp(pre) rows (their padding columns stay zero), flags and granules
+  BSIG_HIP(hipMemsetAsync(base + slab_bytes, 0, 2 * g.dout_floats * sizeof(float), st));
+  BSIG_HIP(hipMemsetAsync(base + data_bytes(g), 0, sync_bytes(), st));
   return BSIG_OK;
 }
 
@@ -608,9 +808,20 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.slabs = reinterpret_cast<float*>(base);
   p.d_out = p.slabs + g.slab_floats;
   p.e_out = p.d_out + g.dout_floats;
-  char* sync = base + round_up<size_t>((g.slab_floats + 2 * g.dout_floats) * sizeof(float), 256);
+  p.eval_slabs = p.e_out + g.dout_floats;
+  char* sync = base + data_bytes(g);
   p.flag_fwd = reinterpret_cast<unsigned*>(sync);
-  p.gran = reinterpret_cast<unsigned long long*>(sync + kXwgMax * sizeof(unsigned));
+  p.flag_eval = p.flag_fwd + kXwgMax;
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 2 * kXwgMax * sizeof(unsigned));
+  p.gran_eval = p.gran + 3 * kXwgMax;
+  if (b.do_eval) {
+    BSIG_REQUIRE(!b.grads && g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
+                     b.y_test && b.test_loss && b.eval_every >= 1 && b.n_total >= 1,
+                 "persistent updates: in-launch evaluation not covered");
+    p.do_eval = 1; p.eval_every = b.eval_every; p.n_total = b.n_total; p.n_test = b.n_test;
+    p.eval_passes = ceil_div(b.n_test, s.batch); p.eval_row0 = b.eval_row0;
+    p.y_test = b.y_test; p.ldy_test = b.ldy_test; p.test_loss = b.test_loss;
+  }
   p.prof = g_prof;
   // (a pending-Adam-only launch needs the tile workgroups only)
   if (b.grads)

@@ -8,6 +8,7 @@ namespace bsig {
 
 struct PersistShape {
   int batch, feat_dim, out_dim, n_comp;
+  int max_test = 0;   // held-out rows the plan may evaluate inside the launches (0: none)
 };
 
 struct PersistBuffers {
@@ -26,6 +27,13 @@ struct PersistBuffers {
   // `adam_pending` the launch first takes the Adam step of the previous update
   // from the (reduced) `grads`.  n = 0 with adam_pending: that step only.
   float* grads = nullptr; int adam_pending = 0;
+  // held-out evaluations inside the launch (persist_eval_supported): after update `it` of the
+  // call with it % eval_every == 0 and after the last of its n_total updates (mdnn.py:235-242);
+  // evaluation k writes test_loss[state[1]] and advances state[1]
+  int do_eval = 0; int eval_every = 1; int n_total = 0;
+  int64_t eval_row0 = 0; int n_test = 0;   // held-out rows: feats[eval_row0 .. +n_test)
+  const float* y_test = nullptr; int64_t ldy_test = 0;
+  float* test_loss = nullptr;
 };
 
 struct PersistHyper {
@@ -35,6 +43,8 @@ struct PersistHyper {
 
 // true when the shape is covered (diagonal covariance, feat_dim % 256 == 0, ...)
 bool persist_supported(const PersistShape& s);
+// ... and the held-out evaluations of up to s.max_test rows can run inside the launches
+bool persist_eval_supported(const PersistShape& s);
 size_t persist_workspace_bytes(const PersistShape& s);
 // zero the cross-workgroup flags / gradient staging (once per fit call)
 int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes, hipStream_t st);
