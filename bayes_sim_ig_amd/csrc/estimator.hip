@@ -427,11 +427,13 @@ static PersistMdnnShape persist_mdnn_shape(const bsig_fit_plan* p) {
   const bsig_mdn_cfg& c = p->cfg;
   return PersistMdnnShape{(int)p->batch, c.input_dim, c.n_hidden > 0 ? c.hidden[0] : 0,
                           c.n_hidden > 1 ? c.hidden[1] : 0, c.activation, c.head.out_dim,
-                          c.head.n_comp, c.head.full_cov};
+                          c.head.n_comp, c.head.full_cov,
+                          (int)std::min<int64_t>(p->max_test, 1 << 20)};
 }
 
-// n consecutive updates of the two-layer MDNN in its persistent kernel
-static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st) {
+// n consecutive updates of the two-layer MDNN in its persistent kernel (with_eval: a whole
+// bsig_fit_run call, its held-out evaluations inside the launch)
+static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, bool with_eval = false) {
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
   PersistMdnnBuffers pb;
@@ -446,6 +448,12 @@ static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st) {
   if (p->split_adam) {
     pb.grads = b.grads; pb.adam_pending = p->adam_pending ? 1 : 0;
     p->adam_pending = false;
+  }
+  if (with_eval) {
+    pb.do_eval = 1; pb.n_total = n; pb.eval_every = std::max(n / 5, 1);   // mdnn.py:235
+    pb.n_test = (int)b.n_test;
+    pb.x_test = b.x_test; pb.ldx_test = b.ldx_test; pb.y_test = b.y_test; pb.ldy_test = b.ldy_test;
+    pb.test_loss = b.test_loss;
   }
   PersistHyper hy;
   hy.lr = p->cfg.lr; hy.beta1 = p->cfg.beta1; hy.beta2 = p->cfg.beta2;
@@ -868,11 +876,14 @@ extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t s
                (long long)p->n_updates);
   hipStream_t st = as_stream(stream);
   if (p->use_graph) BSIG_TRY(ensure_graphs(p));
-  // linear heads on cached features: the whole call, evaluations included, is ONE launch
+  // plans covered by a persistent kernel: the whole call, evaluations included, is ONE launch
   const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
   if (p->persistent && !p->split_adam && n_updates >= 1 && p->buf.n_test >= 1 &&
       !(no_ike && no_ike[0] == '1') && persist_eval_supported(persist_shape(p)))
     return enqueue_persistent(p, (int)n_updates, st, true);
+  if (p->persistent_mdnn && !p->split_adam && n_updates >= 1 && p->buf.n_test >= 1 &&
+      !(no_ike && no_ike[0] == '1') && persist_mdnn_eval_supported(persist_mdnn_shape(p)))
+    return enqueue_persistent_mdnn(p, (int)n_updates, st, true);
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
   int64_t done = 0;
   for (int64_t it = 0; it < n_updates; ++it) {

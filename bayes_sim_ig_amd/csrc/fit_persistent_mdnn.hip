@@ -70,8 +70,11 @@ struct MdnnArgs {
   float* d_out;   // [B][NhP]   ... (head blocks)
   // W2 again, in the order the owners' MFMA operands want it (one coalesced 8-byte load
   // per lane and instruction): written by the W2 small-weight workgroups next to `params`
-  float* w2f_pack;   // [8 waves][8 tt][2][64 lanes][2]: W2[16w + c16][16tt + 4g + 2half + e]
-  float* w2b_pack;   // [8 waves][8 tt][2][64 lanes][2]: W2[16tt + 4g + 2half + e][16w + c16]
+  // Two copies by the parity of the update that reads them: the copy of update t stays
+  // intact while update t's Adam step writes the copy of t+1 (an evaluation at the end of
+  // update t still reads W2 as of t).
+  float* w2f_pack;   // [2][8 waves][8 tt][2][64 lanes][2]: W2[16w + c16][16tt + 4g + 2half + e]
+  float* w2b_pack;   // [2][8 waves][8 tt][2][64 lanes][2]: W2[16tt + 4g + 2half + e][16w + c16]
   unsigned* flag_fwd; unsigned* flag_own; unsigned* flag_small; unsigned* flag_pack;
   unsigned launch_tag;   // flag_pack value of THIS launch: the small weights (and the W2 packs)
                          // as of its start are out, one flag per small-weight workgroup
@@ -81,6 +84,19 @@ struct MdnnArgs {
   // and the Adam step of the PREVIOUS update (on the reduced gradients) is taken by the
   // weights' owners while they load them (adam_pending)
   float* grads; int adam_pending;
+  // held-out evaluations inside the launch (mdnn.py:235-242; do_eval), as in
+  // fit_persistent.hip: the tile workgroups form the held-out rows' first-layer products
+  // while they wait for the row owners of the NEXT update (their LDS still holds the
+  // evaluated weights); the owners run layers 2.. and the forward NLL of their held-out
+  // rows after they have published that update's rows.
+  int do_eval, eval_every, n_total, n_test, eval_passes;
+  const float* x_test; int64_t ldx_test;
+  const float* y_test; int64_t ldy_test;
+  float* test_loss;                  // [n_evals]
+  float* eval_slabs;                 // [2][eval_passes][k_slices][B][128]
+  float* eval_out;                   // [n_test][NhP] head outputs of the held-out rows (staging)
+  unsigned* flag_eval;               // [G1]  evaluation number + 1
+  unsigned long long* gran_eval;     // [2][kXwgMax] {tag, value}: sum exp(pre), sum logsumexp
   long long* prof;   // diagnostics: [256][kMProfUpdates][16] wall-clock stamps, or null
 };
 
@@ -118,6 +134,76 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
       *reinterpret_cast<float4*>(Fl + (idx >> 6) * kMPitch + (idx & 63) * 4) = v;           \
     }                                                                                       \
   }
+
+// number of evaluation points it % every == 0 strictly before update s (the evaluation after
+// the last update of a call is not one of them)
+__device__ __forceinline__ int mdnn_evals_before(int s, int every) { return s == 0 ? 0 : (s - 1) / every + 1; }
+
+// ---- tile workgroups, evaluation number eidx: held-out summaries x this tile's weights (the
+//      A operand straight from memory: the minibatch tile in LDS is still needed for dW1)
+//      -> evaluation slabs, flag
+__device__ __forceinline__ void mdnn_tile_eval(const MdnnArgs& p, const float* Wl, float* X,
+                                               const float* biasl, int eidx) {
+  // (laundered: nothing below may be computed ahead of the update loop and kept live in it)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wg = blockIdx.x, ks = wg % p.k_slices, nb = wg / p.k_slices;
+  const int n0 = nb * kMNB, k0 = ks * kMC;
+  const int B = p.B;
+  const int mt = w & 3, kh = w >> 2;
+  for (int pass = 0; pass < p.eval_passes; ++pass) {
+    const int rows = min(B, p.n_test - pass * B);
+    if (rows <= 0) break;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* src = p.x_test + (int64_t)(pass * B + min(mt * 32 + l31, rows - 1)) * p.ldx_test;
+    const float* bp = Wl + l31 * kMPitch + kh * 128 + 4 * h;
+    // two halves of the k range: 8 x 16 bytes of the A operand in registers at a time
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      float4 areg[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int col = k0 + kh * 128 + 64 * half + 8 * q + 4 * h;
+        float4 v = *reinterpret_cast<const float4*>(src + min((int64_t)col, p.ldx_test - 4));
+        v.x = col + 0 < p.I ? v.x : 0.f; v.y = col + 1 < p.I ? v.y : 0.f;
+        v.z = col + 2 < p.I ? v.z : 0.f; v.w = col + 3 < p.I ? v.w : 0.f;
+        areg[q] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 64 * half + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].w, b4.w, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();                       // X free (previous pass read)
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h)) * kMPbuf + l31] = acc[i];
+    }
+    __syncthreads();
+    if (kh == 0) {
+      const float bias = ks == 0 ? biasl[l31] : 0.f;
+      float* dst = p.eval_slabs + ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B) * kMH + n0 + l31;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = mt * 32 + acc_row(i, h);
+        const float v = acc[i] + X[row * kMPbuf + l31] + bias;
+        if (row < rows) xwg_store(dst + (int64_t)row * kMH, v);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0)
+    __hip_atomic_store(p.flag_eval + wg, (unsigned)eidx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- tile workgroups: first-layer partial products, dW1, Adam -------------------
 template <bool DP>
@@ -247,7 +333,10 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
       BSIG_MSTAMP(3);
     }
 
-    // ---- while the owners work: next summary tile, Adam scalars ------------------
+    // ---- while the owners work: the evaluation due after the previous update (this tile
+    //      still holds those weights), next summary tile, Adam scalars -------------------
+    if (__builtin_expect(!DP && p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
+      mdnn_tile_eval(p, Wl, X, biasl, mdnn_evals_before(step, p.eval_every) - 1);
     if (t + 1 < p.n_updates) {
       const int64_t pf_row0 = (int64_t)(step + 1) * B;
       BSIG_MPF_LIST(BSIG_MPF_LOAD)
@@ -323,6 +412,13 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     BSIG_MSTAMP(12);
   }
 
+  // ---- the evaluation after the last update of the call ------------------------------
+  if (!DP && p.do_eval && step0 + p.n_updates == p.n_total) {
+    if (bias_pending && tid < kMNB) bias_step(tid);
+    bias_pending = false;
+    __syncthreads();
+    mdnn_tile_eval(p, Wl, X, biasl, mdnn_evals_before(p.n_total - 1, p.eval_every));
+  }
   // ---- write the tile back, advance the engine state ---------------------------
   if (col_ok && !DP) {
 #pragma unroll
@@ -344,7 +440,13 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     reinterpret_cast<double*>(st + 12)[1] = b2t;
     reinterpret_cast<float*>(st)[4] = a0;
     reinterpret_cast<float*>(st)[5] = a1;
-    reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)p.n_updates;
+    // (one jitter stream per update and per evaluation, in program order)
+    int n_ev = 0;
+    if (p.do_eval) {
+      n_ev = mdnn_evals_before(step0 + p.n_updates, p.eval_every) - mdnn_evals_before(step0, p.eval_every);
+      if (step0 + p.n_updates == p.n_total && (p.n_total - 1) % p.eval_every != 0) ++n_ev;
+    }
+    reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)(p.n_updates + n_ev);
     st[0] = step0 + p.n_updates;
   }
 }
@@ -392,15 +494,16 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
     }
   }
   // the owners' operand-order copies of W2 (see MdnnArgs)
-  auto publish_w2 = [&](int i, int h, int kcol) {
+  auto publish_w2 = [&](int i, int h, int kcol, int for_step) {
     const int n = n0 + acc_row(i, h);
     const int lf = ((kcol >> 2) & 3) * 16 + (n & 15), lb = ((n >> 2) & 3) * 16 + (kcol & 15);
-    xwg_store(p.w2f_pack + ((((n >> 4) * 8 + (kcol >> 4)) * 2 + ((kcol >> 1) & 1)) * 64 + lf) * 2 + (kcol & 1), Wr[i]);
-    xwg_store(p.w2b_pack + ((((kcol >> 4) * 8 + (n >> 4)) * 2 + ((n >> 1) & 1)) * 64 + lb) * 2 + (n & 1), Wr[i]);
+    const int par = (for_step & 1) * (kMH * kMH);
+    xwg_store(p.w2f_pack + par + ((((n >> 4) * 8 + (kcol >> 4)) * 2 + ((kcol >> 1) & 1)) * 64 + lf) * 2 + (kcol & 1), Wr[i]);
+    xwg_store(p.w2b_pack + par + ((((kcol >> 4) * 8 + (n >> 4)) * 2 + ((n >> 1) & 1)) * 64 + lb) * 2 + (n & 1), Wr[i]);
   };
   if (is_w2 && w < 4) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) publish_w2(i, h, kcol);
+    for (int i = 0; i < 16; ++i) publish_w2(i, h, kcol, step0);
   }
   // wave 4, lanes 0-31: the 32 biases
   const bool bias_lane = w == 4 && lane < kMNB && n0 + lane < nrows;
@@ -489,7 +592,7 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
         } else {
           Wr[i] = adam_weight(acc[i], Mr[i], Vr[i], Wr[i], a0, a1, ak);
           if (n < nrows) xwg_store(p.params + w_off + (int64_t)n * kMH + kcol_l, Wr[i]);
-          if (is_w2) publish_w2(i, h_l, kcol_l);
+          if (is_w2) publish_w2(i, h_l, kcol_l, step + 1);
         }
       }
     } else if (bias_lane) {
@@ -558,6 +661,196 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   // k-slice sum), w2b[4t + j] = W2[16t + 4g + j][16w + c16] (backward, fetched under the
   // wait for the other owners' rows)
 
+
+  // ---- held-out evaluation number eidx (jitter stream `stream`), forward only: per pass,
+  //      this owner's 4 rows of the pass go through layers 2.. (the weights in LDS / the
+  //      W2 pack are the evaluated ones); head outputs are parked in memory until the
+  //      batch-wide sum of exp(pre) is known, then one wavefront per row takes the NLL
+  auto owner_eval = [&](int eidx, uint64_t stream, int step, bool refresh) {
+    int c16 = c16_0, g = g_0, tid = tid_0;
+    const int w = w_0;
+    asm volatile("" : "+v"(c16), "+v"(g), "+v"(tid));
+    const int lane = tid & 63, rowA = c16 & (kMR - 1);
+    const unsigned etag = (unsigned)eidx + 1u;
+    float* tile = Os + (w & (kMR - 1)) * po;
+    float* yv = wsc + (w & (kMR - 1)) * per_wave;
+    float* rk = yv + D;
+    float* lpk = rk + K;
+    float* dlg = lpk + K;
+    if (refresh) {
+      // after the last update of the call: the head matrix and the biases in LDS are those
+      // of that update -- fetch what its Adam step published
+      if (w == 0) flags_wait(p.flag_small, p.n_small, (unsigned)step, lane, flagp);
+      __syncthreads();
+      for (int idx = tid; idx < Nh16 * (kMH / 2); idx += kMT) {
+        const int n = idx >> 6, c2 = (idx & 63) * 2;
+        const float2 q = n < Nh ? xwg_load2(Wh + (int64_t)n * kMH + c2) : make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(Whs + n * kMH + (c2 ^ (4 * (n & 15)))) = q;
+      }
+      if (tid < kMH) b2s[tid] = xwg_load(p.params + p.b2_off + tid);
+      for (int j = tid; j < Nh16; j += kMT) bhs[j] = j < Nh ? xwg_load(p.params + p.bh_off + j) : 0.f;
+    }
+    if (w == 0) flags_wait(p.flag_eval, p.G1, etag, lane, flagp);
+    __syncthreads();
+    float w2f[32];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const float* src = p.w2f_pack + (step & 1) * (kMH * kMH) + (((w * 8 + tt) * 2) * 64 + lane) * 2;
+      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);
+      w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y;
+    }
+    float eacc = 0.f;
+    for (int gp = 0; gp < p.eval_passes; ++gp) {
+      const float* slabs = p.eval_slabs + (((int64_t)(eidx & 1) * p.eval_passes + gp) * p.k_slices) * zs;
+      {
+        constexpr int kItems = kMR * 64, kSub = kMT / kItems;
+        const int item = tid & (kItems - 1), sub = tid / kItems;
+        const int r = item >> 6, c2 = (item & 63) * 2;
+        const bool ok = r0 + r < B && gp * B + r0 + r < p.n_test;
+        const float* src = slabs + (int64_t)min(r0 + r, B - 1) * kMH + c2;
+        const int per = ceil_div(p.k_slices, kSub);
+        const int z_lo = sub * per, z_hi = min(z_lo + per, p.k_slices);
+        float vx = 0.f, vy = 0.f;
+        for (int z = z_lo; z < z_hi; z += 24) {
+          float2 q[24];
+#pragma unroll
+          for (int u = 0; u < 24; ++u) q[u] = xwg_load2(src + (int64_t)min(z + u, z_hi - 1) * zs);
+#pragma unroll
+          for (int u = 0; u < 24; ++u)
+            if (z + u < z_hi) { vx += q[u].x; vy += q[u].y; }
+        }
+        if (kSub > 1) {
+          float* part = H2s;
+          if (sub > 0) { part[((sub - 1) * kItems + item) * 2] = vx; part[((sub - 1) * kItems + item) * 2 + 1] = vy; }
+          __syncthreads();
+          if (sub == 0) {
+#pragma unroll
+            for (int q = 1; q < kSub; ++q) { vx += part[((q - 1) * kItems + item) * 2]; vy += part[((q - 1) * kItems + item) * 2 + 1]; }
+          }
+        }
+        if (sub == 0) {
+          H1s[r * kMHP + c2] = ok ? tanhf(vx) : 0.f; H1s[r * kMHP + c2 + 1] = ok ? tanhf(vy) : 0.f;
+        }
+      }
+      __syncthreads();
+      {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = H1s + rowA * kMHP + 4 * g;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+          acc = mfma16(a4.x, w2f[4 * tt + 0], acc);
+          acc = mfma16(a4.y, w2f[4 * tt + 1], acc);
+          acc = mfma16(a4.z, w2f[4 * tt + 2], acc);
+          acc = mfma16(a4.w, w2f[4 * tt + 3], acc);
+        }
+        if (4 * g < kMR) {
+          const int n = 16 * w + c16;
+          const float bias = b2s[n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * kMHP + n] = tanhf(acc[r] + bias);
+        }
+      }
+      __syncthreads();
+      for (int cb = w; cb * 16 < Nh16; cb += 8) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int n = 16 * cb + c16;
+        const float* ap = H2s + rowA * kMHP + 4 * g;
+        const float* bp = Whs + n * kMH;
+        const int sw = 4 * c16;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+          const float4 b4 = *reinterpret_cast<const float4*>(bp + ((16 * tt + 4 * g) ^ sw));
+          acc = mfma16(a4.x, b4.x, acc);
+          acc = mfma16(a4.y, b4.y, acc);
+          acc = mfma16(a4.z, b4.z, acc);
+          acc = mfma16(a4.w, b4.w, acc);
+        }
+        if (4 * g < kMR) {
+          const float bias = bhs[n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * g + r;
+            const float v = acc[r] + bias;
+            Os[rr * po + n] = v;
+            if (r0 + rr < B && gp * B + r0 + rr < p.n_test && n >= K + DK && n < K + 2 * DK) eacc += expf(v);
+          }
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < kMR * Nh; idx += kMT) {
+        const int r = idx / Nh, j = idx - r * Nh;
+        const int erow = gp * B + r0 + r;
+        if (r0 + r < B && erow < p.n_test) xwg_store(p.eval_out + (int64_t)erow * p.NhP + j, Os[r * po + j]);
+      }
+      __syncthreads();
+    }
+    eacc = wave_sum_dpp(eacc);
+    if (lane == 0) red[w] = eacc;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+      float sx = 0.f;
+      for (int q = 0; q < kMT / 64; ++q) sx += red[q];
+      granule_publish(p.gran_eval + o, etag, sx);
+    }
+    HeadArgs ae = a;
+    ae.d_out = nullptr;                      // forward only
+    ae.batch = p.n_test;
+    ae.stream_id = stream;
+    float lse_acc = 0.f;
+    bool bad = false;
+    for (int gp = 0; gp < p.eval_passes; ++gp) {
+      for (int idx = tid; idx < kMR * Nh; idx += kMT) {
+        const int r = idx / Nh, j = idx - r * Nh;
+        const int erow = gp * B + r0 + r;
+        Os[r * po + j] = (r0 + r < B && erow < p.n_test) ? xwg_load(p.eval_out + (int64_t)erow * p.NhP + j) : 0.f;
+      }
+      const int erow = gp * B + r0 + w;
+      const bool act = w < kMR && r0 + w < B && erow < p.n_test;
+      if (act)
+        for (int j = lane; j < D; j += 64) yv[j] = p.y_test[(int64_t)erow * p.ldy_test + j];
+      __syncthreads();
+      if (w < kMR) {
+        RowOut ro;
+        ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
+#pragma unroll
+        for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
+        diag_row(ae, erow, act, lane, tile, yv, rk, lpk, dlg,
+                 [&] {
+                   return p.eps_noise != 0.f
+                              ? p.eps_noise * (granule_gather(p.gran_eval, p.n_owner, etag, lane, flagp) /
+                                               ((float)p.n_test * (float)DK))
+                              : 0.f;
+                 },
+                 ro);
+        if (act) lse_acc += ro.lse;
+        bad |= ro.bad;
+      }
+      __syncthreads();
+    }
+    if (lane == 0) red[16 + w] = lse_acc;
+    __syncthreads();
+    if (tid == 0) {
+      float sl = 0.f;
+      for (int q = 0; q < kMR; ++q) sl += red[16 + q];
+      granule_publish(p.gran_eval + kXwgMax + o, etag, sl);
+    }
+    if (o == 0 && w == 0) {
+      const float sum = granule_gather(p.gran_eval + kXwgMax, p.n_owner, etag, lane, flagp);
+      if (lane == 0) {
+        const float l = -sum / (float)p.n_test;
+        p.test_loss[p.state[1]] = l;
+        p.state[1] = p.state[1] + 1;
+        if (!isfinite(l)) atomicOr(flagp, 1);
+      }
+    }
+    if (bad) atomicOr(flagp, 1);
+    __syncthreads();
+  };
+  const int ev0 = p.do_eval ? mdnn_evals_before(step0, p.eval_every) : 0;
+
   if (w_0 == 0) flags_wait(p.flag_pack, p.n_small, p.launch_tag, tid_0 & 63, flagp);
   __syncthreads();
   for (int t = 0; t < p.n_updates; ++t) {
@@ -613,7 +906,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     float w2f[32];
 #pragma unroll
     for (int tt = 0; tt < 8; ++tt) {
-      const float* src = p.w2f_pack + (((w * 8 + tt) * 2) * 64 + lane) * 2;
+      const float* src = p.w2f_pack + (step & 1) * (kMH * kMH) + (((w * 8 + tt) * 2) * 64 + lane) * 2;
       const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);
       w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y;
     }
@@ -721,7 +1014,9 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
 #pragma unroll
     for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
-    a.stream_id = rng_ctr0 + (uint64_t)t;
+    // one jitter stream per update and per evaluation, in program order
+    a.stream_id = rng_ctr0 + (uint64_t)t +
+                  (uint64_t)(p.do_eval ? mdnn_evals_before(step, p.eval_every) - ev0 : 0);
     diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg,
              [&] {
                return p.eps_noise != 0.f
@@ -744,7 +1039,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     float w2b[32];
 #pragma unroll
     for (int tt = 0; tt < 8; ++tt) {
-      const float* src = p.w2b_pack + (((w * 8 + tt) * 2) * 64 + lane) * 2;
+      const float* src = p.w2b_pack + (step & 1) * (kMH * kMH) + (((w * 8 + tt) * 2) * 64 + lane) * 2;
       const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);
       w2b[4 * tt + 0] = lo.x; w2b[4 * tt + 1] = lo.y; w2b[4 * tt + 2] = hi.x; w2b[4 * tt + 3] = hi.y;
     }
@@ -838,7 +1133,18 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         if (!isfinite(l)) atomicOr(flagp, 1);
       }
     }
+    // the evaluation due after the previous update: the tile workgroups formed its
+    // first-layer products while this update's rows were being finished
+    if (__builtin_expect(!DP && p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
+      __syncthreads();
+      owner_eval(mdnn_evals_before(step, p.eval_every) - 1,
+                 rng_ctr0 + (uint64_t)t + (uint64_t)(mdnn_evals_before(step, p.eval_every) - ev0) - 1u, step, false);
+    }
   }
+  if (!DP && p.do_eval && step0 + p.n_updates == p.n_total && !run_aborted(flagp, red, tid_0))
+    owner_eval(mdnn_evals_before(p.n_total - 1, p.eval_every),
+               rng_ctr0 + (uint64_t)p.n_updates +
+                   (uint64_t)(mdnn_evals_before(p.n_total - 1, p.eval_every) - ev0), p.n_total, true);
 }
 
 // DP: data-parallel rank (gradients out, pending Adam step in; see MdnnArgs)
@@ -854,8 +1160,9 @@ __global__ __launch_bounds__(kMT) void mdnn_updates_kernel(MdnnArgs p) {
 // ---------------------------------------------------------------- host side
 struct MdnnGeom {
   int FR, Nh, Nh16, NhP, k_slices, G1, n_owner, n_small, x_floats;
+  int eval_passes;              // 0: evaluations stay outside the launches
   size_t lds;
-  size_t slab_floats, act_floats, dout_floats;
+  size_t slab_floats, act_floats, dout_floats, eval_floats;
 };
 
 static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
@@ -888,6 +1195,11 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   g->slab_floats = (size_t)g->k_slices * s.batch * kMH;
   g->act_floats = (size_t)s.batch * kMH;
   g->dout_floats = (size_t)s.batch * g->NhP;
+  // in-launch evaluations: slabs of both parities and the parked head outputs
+  g->eval_passes = s.max_test > 0 ? ceil_div(s.max_test, s.batch) : 0;
+  if (g->eval_passes > 8) g->eval_passes = 0;
+  g->eval_floats = (size_t)2 * g->eval_passes * g->slab_floats +
+                   (size_t)g->eval_passes * s.batch * g->NhP;
   return true;
 }
 
@@ -903,13 +1215,17 @@ bool persist_mdnn_supported(const PersistMdnnShape& s) {
   MdnnGeom g;
   return mdnn_geom(s, &g) && mdnn_device_can_host(g);
 }
-
-constexpr size_t kPackFloats = (size_t)kMH * kMH;
-static size_t mdnn_data_bytes(const MdnnGeom& g) {
-  return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats + 2 * kPackFloats) *
-                              sizeof(float), 256);
+bool persist_mdnn_eval_supported(const PersistMdnnShape& s) {
+  MdnnGeom g;
+  return mdnn_geom(s, &g) && mdnn_device_can_host(g) && g.eval_passes > 0;
 }
-static size_t mdnn_sync_bytes() { return 4 * kXwgMax * sizeof(unsigned) + 3 * kXwgMax * 8; }
+
+constexpr size_t kPackFloats = (size_t)2 * kMH * kMH;   // both parities
+static size_t mdnn_data_bytes(const MdnnGeom& g) {
+  return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats + 2 * kPackFloats +
+                           g.eval_floats) * sizeof(float), 256);
+}
+static size_t mdnn_sync_bytes() { return 5 * kXwgMax * sizeof(unsigned) + 5 * kXwgMax * 8; }
 
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
   MdnnGeom g;
@@ -926,7 +1242,8 @@ int persist_mdnn_reset(const PersistMdnnShape& s, void* workspace, size_t worksp
   char* base = reinterpret_cast<char*>(workspace);
   const size_t slab_bytes = g.slab_floats * sizeof(float);
   // activations / gradients (padding columns of d_out stay zero), flags and granules
-  BSIG_HIP(hipMemsetAsync(base + slab_bytes, 0, persist_mdnn_workspace_bytes(s) - slab_bytes, st));
+  BSIG_HIP(hipMemsetAsync(base + slab_bytes, 0, (4 * g.act_floats + g.dout_floats) * sizeof(float), st));
+  BSIG_HIP(hipMemsetAsync(base + mdnn_data_bytes(g), 0, mdnn_sync_bytes(), st));
   return BSIG_OK;
 }
 
@@ -976,14 +1293,28 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.d_out = p.dz2 + g.act_floats;
   p.w2f_pack = p.d_out + g.dout_floats;
   p.w2b_pack = p.w2f_pack + kPackFloats;
+  p.eval_slabs = p.w2b_pack + kPackFloats;
+  p.eval_out = p.eval_slabs + (size_t)2 * g.eval_passes * g.slab_floats;
   char* sync = base + mdnn_data_bytes(g);
   p.flag_fwd = reinterpret_cast<unsigned*>(sync);
   p.flag_own = p.flag_fwd + kXwgMax;
   p.flag_small = p.flag_own + kXwgMax;
   p.flag_pack = p.flag_small + kXwgMax;
+  p.flag_eval = p.flag_pack + kXwgMax;
   static unsigned launch_tag = 0;
   p.launch_tag = ++launch_tag;
-  p.gran = reinterpret_cast<unsigned long long*>(sync + 4 * kXwgMax * sizeof(unsigned));
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 5 * kXwgMax * sizeof(unsigned));
+  p.gran_eval = p.gran + 3 * kXwgMax;
+  if (b.do_eval) {
+    BSIG_REQUIRE(!b.grads && g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
+                     b.x_test && b.y_test && b.test_loss && b.eval_every >= 1 && b.n_total >= 1 &&
+                     b.ldx_test % 4 == 0 && b.ldx_test >= s.input_dim && aligned(b.x_test, 16),
+                 "persistent MDNN updates: in-launch evaluation not covered");
+    p.do_eval = 1; p.eval_every = b.eval_every; p.n_total = b.n_total; p.n_test = b.n_test;
+    p.eval_passes = ceil_div(b.n_test, s.batch);
+    p.x_test = b.x_test; p.ldx_test = b.ldx_test; p.y_test = b.y_test; p.ldy_test = b.ldy_test;
+    p.test_loss = b.test_loss;
+  }
   p.prof = reinterpret_cast<long long*>(persist_profile_buffer());
   if (b.grads)
     hipLaunchKernelGGL(mdnn_updates_kernel<true>, dim3(g.G1 + g.n_owner + g.n_small), dim3(kMT), g.lds, st, p);

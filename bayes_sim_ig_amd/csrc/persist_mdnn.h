@@ -9,6 +9,7 @@ namespace bsig {
 
 struct PersistMdnnShape {
   int batch, input_dim, h1, h2, activation, out_dim, n_comp, full_cov;
+  int max_test = 0;   // held-out rows the plan may evaluate inside the launches (0: none)
 };
 
 struct PersistMdnnBuffers {
@@ -25,11 +26,20 @@ struct PersistMdnnBuffers {
   // launch first takes the Adam step of the previous update from the (reduced) `grads`.
   // n = 0 with adam_pending: that step only.
   float* grads = nullptr; int adam_pending = 0;
+  // held-out evaluations inside the launch (persist_mdnn_eval_supported): after update `it`
+  // of the call with it % eval_every == 0 and after the last of its n_total updates
+  // (mdnn.py:235-242); evaluation k writes test_loss[state[1]] and advances state[1]
+  int do_eval = 0; int eval_every = 1; int n_total = 0; int n_test = 0;
+  const float* x_test = nullptr; int64_t ldx_test = 0;
+  const float* y_test = nullptr; int64_t ldy_test = 0;
+  float* test_loss = nullptr;
 };
 
 struct PersistHyper;   // persist.h
 
 bool persist_mdnn_supported(const PersistMdnnShape& s);
+// ... and the held-out evaluations of up to s.max_test rows can run inside the launches
+bool persist_mdnn_eval_supported(const PersistMdnnShape& s);
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s);
 int persist_mdnn_reset(const PersistMdnnShape& s, void* workspace, size_t workspace_bytes,
                        hipStream_t st);
