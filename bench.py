@@ -207,11 +207,12 @@ def _event_time(fn, reps, warm=5):
 
 
 def time_update_kernel(pkg, cfg, bsim, device):
-    """MDRFF: HIP-event timing of the dominant kernel of the fit, the persistent
-    update kernel (csrc/fit_persistent.hip) — every launch of one run_training
-    call (runs of 1, 20, 20, 20, 20, 19 updates between the six held-out
-    evaluations), launched through the C ABI (bsig_fit_updates) on the plan the
-    timed fit just used, events on the stream it launches on."""
+    """HIP-event timing of the dominant kernel of the fit, the persistent update
+    kernel (csrc/fit_persistent.hip / fit_persistent_mdnn.hip): ONE launch per
+    run_training call -- its 100 updates and the six held-out evaluations that
+    run inside it -- launched through the C ABI (bsig_fit_begin + bsig_fit_run)
+    on the plan the timed fit just used, events on the stream it launches on
+    around bsig_fit_run only.  Data-parallel ranks: one launch per update."""
     lib = pkg._lib.load()
     L = pkg._lib
     m = bsim.model
@@ -220,11 +221,9 @@ def time_update_kernel(pkg, cfg, bsim, device):
     stream = torch.cuda.current_stream()
     n_updates, batch = 100, 100
     every = max(n_updates // 5, 1)
-    runs, done = [], 0
-    for it in range(n_updates):
-        if it % every == 0 or it + 1 == n_updates:
-            runs.append(it + 1 - done)
-            done = it + 1
+    n_evals = len([it for it in range(n_updates) if it % every == 0 or it + 1 == n_updates])
+    n_test = 1000 - int(1000 * 0.8)                    # held-out rows of a 1000-pair chunk
+    runs = [n_updates]
     total_ms, launches = 0.0, 0
     dp = m._dp is not None
     if dp:
@@ -242,7 +241,7 @@ def time_update_kernel(pkg, cfg, bsim, device):
                 L.check(lib.bsig_fit_grad(plan, st))
                 L.check(lib.bsig_fit_apply(plan, st))
             else:
-                L.check(lib.bsig_fit_updates(plan, n, st))
+                L.check(lib.bsig_fit_run(plan, n, st))
             e1.record(stream)
             evs.append((e0, e1))
         if dp:
@@ -255,46 +254,52 @@ def time_update_kernel(pkg, cfg, bsim, device):
     us = total_ms * 1e3 / launches
     nh = cfg['k'] * (1 + 2 * cfg['d'])
     if cfg['model'] != 'MDRFF':
-        return mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp)
+        return mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp, n_evals, n_test)
     f_in = m.rff.m_feat * 2
     per_visit = 2.0 * 2.0 * f_in * nh                 # SURVEY 8(d) K6+K7, MDRFF heads: fwd + dW
     flops = per_visit * batch * (float(n_updates) / len(runs))
+    if not dp:
+        flops += 2.0 * f_in * nh * n_test * n_evals   # forward products of the evaluations
     ach = flops / (us * 1e-6) / 1e12
     traffic, tsrc = pmc_traffic('linear_head_updates_kernel') if not dp else (None, None)
     return {'bound': 'mfma',
             'kernel': 'linear_head_updates_kernel: persistent update kernel, heads %dx%d on cached '
-                      'RFF features, minibatch %d, %s updates per launch (mean %.1f): forward '
+                      'RFF features, minibatch %d, %s per launch: forward '
                       'product, NLL fwd/bwd, dW, Adam%s'
-                      % (nh, f_in, batch, '/'.join(str(r) for r in runs) if not dp else '1',
-                         float(n_updates) / len(runs),
+                      % (nh, f_in, batch, ('%d updates + %d held-out evaluations of %d rows'
+                                           % (n_updates, n_evals, n_test)) if not dp else '1 update',
                          ' (data-parallel rank: gradients written for the all-reduce, Adam step of '
                          'the previous update taken from the reduced gradients while the weight '
                          'tiles are loaded)' if dp else ''),
             'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
             'traffic': traffic, 'traffic_source': tsrc, 'avg_us': us,
             'us_per_update': us * len(runs) / n_updates,
-            'algorithmic': '2*2*F*Nh = %.3e flop per row visit x %d rows x %.1f updates = %.3e flop '
-                           'per launch' % (per_visit, batch, float(n_updates) / len(runs), flops),
+            'algorithmic': '2*2*F*Nh = %.3e flop per row visit x %d rows x %.1f updates%s = %.3e flop '
+                           'per launch' % (per_visit, batch, float(n_updates) / len(runs),
+                                           '' if dp else ' + 2*F*Nh x %d rows x %d evaluations'
+                                           % (n_test, n_evals), flops),
             'note': 'latency-bound by design of the reference protocol (minibatch 100): each update '
                     'is a chain of 4 cross-workgroup hand-offs (~1.5-3 us each) around ~6 us of '
                     'fp32-MFMA work per CU; see DESIGN.md and scaled_batch_mode for the MFMA-bound regime'}
 
 
-def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp=False):
+def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp=False, n_evals=0, n_test=0):
     """MDNN [128, 128]: the persistent update kernel (csrc/fit_persistent_mdnn.hip).
     Algorithmic work per row visit (SURVEY.md 8(d) K5 + K6/K7): first layer forward + dW1
     (no dX of the input), second layer and heads forward + dW + dX."""
     i, h = m.input_dim, 128
     per_visit = 2.0 * (2.0 * i * h) + 3.0 * (2.0 * h * h) + 3.0 * (2.0 * h * nh)
     flops = per_visit * batch * (float(n_updates) / len(runs))
+    if not dp:                                          # forward passes of the evaluations
+        flops += (2.0 * i * h + 2.0 * h * h + 2.0 * h * nh) * n_test * n_evals
     ach = flops / (us * 1e-6) / 1e12
     traffic, tsrc = pmc_traffic('mdnn_updates_kernel') if not dp else (None, None)
     return {'bound': 'mfma',
             'kernel': 'mdnn_updates_kernel: persistent update kernel of the two-layer MDNN, '
-                      'trunk %d-128-128, heads %d, minibatch %d, %s updates per launch (mean %.1f): '
+                      'trunk %d-128-128, heads %d, minibatch %d, %s per launch: '
                       'forward, NLL fwd/bwd, backward, Adam%s'
-                      % (i, nh, batch, '/'.join(str(r) for r in runs) if not dp else '1',
-                         float(n_updates) / len(runs),
+                      % (i, nh, batch, ('%d updates + %d held-out evaluations of %d rows'
+                                        % (n_updates, n_evals, n_test)) if not dp else '1 update',
                          ' (data-parallel rank: gradients written for the all-reduce, Adam step of '
                          'the previous update taken from the reduced gradients)' if dp else ''),
             'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
