@@ -82,15 +82,18 @@ class BayesSim(object):
             n = n_train_trajs - n_train_trajs_done
         return n
 
-    def _summarize(self, states, actions):
+    def _summarize(self, states, actions, finite_flag=None):
         if self.summarizer_name == 'summary_signatory' and self._sig_depth:
             return self.summarizer_fxn(states, actions, depth=self._sig_depth)
+        if finite_flag is not None and self.summarizer_name in ('summary_corr', 'summary_corrdiff'):
+            # the isfinite assert of summarizers.py:120, deferred with the chunk's logs
+            return self.summarizer_fxn(states, actions, check_finite=finite_flag)
         return self.summarizer_fxn(states, actions)
 
-    def run_training(self, params, traj_states, traj_actions, _defer=False):
+    def run_training(self, params, traj_states, traj_actions, _defer=False, _finite_flag=None):
         """One chunk: summarize, then NUM_GRAD_UPDATES Adam updates of
         MINIBATCH_SIZE (reference bayes_sim.py:91-114)."""
-        traj_summaries = self._summarize(traj_states, traj_actions)
+        traj_summaries = self._summarize(traj_states, traj_actions, _finite_flag)
         return self.model.run_training(
             x_data=traj_summaries, y_data=params,
             n_updates=BayesSim.NUM_GRAD_UPDATES,
@@ -103,15 +106,21 @@ class BayesSim(object):
         NUM_TRAIN_TRAJ_PER_BATCH pairs, ``run_training`` on each.
         Returns the list of per-chunk log dicts."""
         n, done, pending = params.shape[0], 0, []
+        flag = None
+        if torch.is_tensor(traj_states) and traj_states.is_cuda:
+            flag = torch.zeros(1, dtype=torch.int32, device=traj_states.device)
         while done < n:
             m = BayesSim.get_n_trajs_per_batch(n, done)
             pending.append(self.run_training(params[done:done + m],
                                              traj_states[done:done + m],
-                                             traj_actions[done:done + m], _defer=True))
+                                             traj_actions[done:done + m], _defer=True,
+                                             _finite_flag=flag))
             done += m
         # one host synchronisation for the whole fit: the chunks' logs (and the
         # isfinite asserts) are read back after the last chunk is enqueued
-        return [p.result() for p in pending]
+        logs = [p.result() for p in pending]
+        assert flag is None or int(flag.item()) == 0   # summarizers.py:120
+        return logs
 
     def predict(self, states, actions, threshold=0.005):
         """Posterior for the given real trajectories (reference

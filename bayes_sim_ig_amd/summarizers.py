@@ -99,11 +99,15 @@ def cross_correlation(states, actions, use_state_diff=False, out=None,
     width = summary_dim('summary_corrdiff' if use_state_diff else 'summary_corr',
                         t, sd, ad)
     buf, ld = _alloc(n, width, s.device, out)
-    flag = torch.zeros(1, dtype=torch.int32, device=s.device) if check_finite else None
+    # check_finite may be a 1-element int32 device tensor: the kernel raises its flag there
+    # and the caller asserts later (BayesSim.fit: one read-back for all chunks)
+    deferred = torch.is_tensor(check_finite)
+    flag = check_finite if deferred else (
+        torch.zeros(1, dtype=torch.int32, device=s.device) if check_finite else None)
     _lib.check(_lib.load().bsig_crosscorr(
         _lib.ptr(s), _lib.ptr(a), _lib.ptr(buf), n, t, a.shape[1], sd, ad,
         1 if use_state_diff else 0, ld, _lib.ptr(flag), _lib.stream()))
-    if check_finite:
+    if check_finite is not None and check_finite is not False and not deferred:
         assert int(flag.item()) == 0  # summarizers.py:120
     return _finish(buf, n, width, home, out)
 

@@ -404,6 +404,27 @@ def test_nonfinite_input_raises_assertion(B):
         m.forward(xb)
 
 
+def test_fit_defers_the_summarizer_finiteness_assert(B):
+    """BayesSim.fit raises the cross-correlation summarizer's isfinite assert
+    (summarizers.py:120) with the chunks' logs, after the last chunk is enqueued,
+    instead of synchronising the host once per chunk; a direct summarizer call
+    still asserts at once."""
+    import bench
+    cfg = dict(task='synthetic', model='MDNN', summarizer='summary_corrdiff', t=12, sd=6, ad=2,
+               d=3, k=4, hidden=[128, 128], n_feat=0, pairs=2000)
+    theta, states, actions = bench.synth_pairs(cfg, 2000, 3, DEV)
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    logs = bs.fit(theta, states, actions)
+    assert len(logs) == 2 and all(np.isfinite(lg['test_loss']).all() for lg in logs)
+    bad = states.clone()
+    bad[1500, 3, 2] = float('inf')                    # second chunk, a held-out row
+    with pytest.raises(AssertionError):
+        B.summary_corrdiff(bad[1000:], actions[1000:])
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    with pytest.raises(AssertionError):
+        bs.fit(theta, bad, actions)
+
+
 def test_full_size_chunk_protocol_fit(B):
     """cfg5-shaped fit (ShadowHand MDRFF-4096, summary_start) over 20 chunks with
     the reference defaults (EPS_NOISE=1e-5, numpy-RNG ids): finite, 6+6 logs per

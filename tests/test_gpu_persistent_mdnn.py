@@ -184,3 +184,22 @@ def test_data_parallel_rank_in_persistent_mdnn_kernel_is_bitwise(B, eps):
     assert logs_d['train_loss'] == logs_p['train_loss']
     assert np.allclose(logs_d['test_loss'], logs_p['test_loss'], rtol=1e-6, atol=1e-6)
     assert torch.equal(flat_d, flat_p)
+
+
+@pytest.mark.parametrize('n,batch,n_updates', [(1000, 100, 100), (1000, 100, 3), (60, 100, 5), (300, 64, 37)])
+@pytest.mark.parametrize('eps', [0.0, 1e-5])
+def test_in_launch_evaluations_equal_the_evaluation_graphs(B, eps, n, batch, n_updates):
+    """The held-out evaluations run inside the launch of the MDNN persistent kernel
+    or as separate graphs between launches (BSIG_NO_INKERNEL_EVAL=1): same weights
+    bit for bit, same held-out NLLs up to the summation order."""
+    cfg = _cfg(4, 6, 'summary_corrdiff', 12, 7, 3)
+    a = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=eps)
+    os.environ['BSIG_NO_INKERNEL_EVAL'] = '1'
+    try:
+        b = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=eps)
+    finally:
+        os.environ.pop('BSIG_NO_INKERNEL_EVAL', None)
+    assert a[0]['train_loss'] == b[0]['train_loss']
+    assert len(a[0]['test_loss']) == len(b[0]['test_loss'])
+    assert np.allclose(a[0]['test_loss'], b[0]['test_loss'], rtol=2e-6, atol=2e-6), (a[0], b[0])
+    assert torch.equal(a[1], b[1])
