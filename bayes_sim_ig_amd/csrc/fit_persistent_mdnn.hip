@@ -1166,7 +1166,7 @@ struct MdnnGeom {
 };
 
 static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
-  if (s.batch < 1 || s.input_dim < 4 || s.h1 != kMH || s.h2 != kMH ||
+  if (s.batch < 1 || s.input_dim < 1 || s.h1 != kMH || s.h2 != kMH ||
       s.activation != BSIG_ACT_TANH || s.full_cov != 0 || s.out_dim < 1 || s.n_comp < 1 ||
       s.n_comp > 64)
     return false;
