@@ -33,6 +33,10 @@ CONFIGS = {
                  d=17, k=5, hidden=[128, 128], n_feat=0, pairs=50_000),
     'cfg4': dict(task='ShadowHand', model='MDNN', summarizer='summary_signatory', t=11,
                  sd=211, ad=20, d=32, k=4, hidden=[128, 128], n_feat=0, pairs=25_000),
+    # the depth-3 signature variant of cfg4: 22 channels
+    # (time + 19 observations + 2 actions) -> the reference's depth rule gives 3, I = 11154
+    'cfg4b': dict(task='ShadowHand-22ch', model='MDNN', summarizer='summary_signatory', t=11,
+                  sd=19, ad=2, d=32, k=4, hidden=[128, 128], n_feat=0, pairs=25_000),
     'cfg5': dict(task='ShadowHand', model='MDRFF', summarizer='summary_start', t=11, sd=211,
                  ad=20, d=32, k=4, hidden=[], n_feat=4096, pairs=100_000),
 }
