@@ -555,7 +555,8 @@ def main():
                 # transparency (opt-in, so that a profile of the default run shows the
                 # product path only): the same fit with pieces of the design switched off
                 out['variants_pairs_per_s'] = {}
-                for tag, env in (('phase_kernels_no_persistent', {'BSIG_NO_PERSISTENT': '1'}),
+                for tag, env in (('evaluation_graphs_between_launches', {'BSIG_NO_INKERNEL_EVAL': '1'}),
+                                 ('phase_kernels_no_persistent', {'BSIG_NO_PERSISTENT': '1'}),
                                  ('no_feature_cache', {'BSIG_NO_FEAT_CACHE': '1'}),
                                  ('phase_kernels_no_feature_cache',
                                   {'BSIG_NO_PERSISTENT': '1', 'BSIG_NO_FEAT_CACHE': '1'}),
