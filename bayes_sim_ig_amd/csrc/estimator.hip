@@ -356,6 +356,7 @@ struct bsig_fit_plan {
   bool use_graph, split_adam;
   bool persistent;             // updates run in the persistent kernel (persist.h)
   bool persistent_mdnn;        // single-rank MDNN [128, 128] updates: fit_persistent_mdnn.hip
+  int dp_evals_done;           // data-parallel + in-launch evaluations: bsig_fit_eval calls so far
   bool adam_pending;           // ... data-parallel: the Adam step on the reduced gradients is
                                // taken by the next launch (or flushed before an evaluation)
   size_t persist_bytes;
@@ -392,9 +393,9 @@ static PersistShape persist_shape(const bsig_fit_plan* p) {
 // n consecutive updates in the persistent kernel.  Data-parallel plans
 // (split_adam): ONE update whose gradients go to the flat gradient buffer, after
 // the pending Adam step of the previous one; n = 0 flushes that step.
-// with_eval: the n updates are a whole bsig_fit_run call and its held-out
-// evaluations run inside the launch.
-static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st, bool with_eval = false) {
+// eval_total > 0: the launch belongs to a call of eval_total updates whose held-out
+// evaluations run inside the launches.
+static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st, int eval_total = 0) {
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
   PersistBuffers pb;
@@ -409,8 +410,8 @@ static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st, bool with
     pb.grads = b.grads; pb.adam_pending = p->adam_pending ? 1 : 0;
     p->adam_pending = false;
   }
-  if (with_eval) {
-    pb.do_eval = 1; pb.n_total = n; pb.eval_every = std::max(n / 5, 1);   // mdnn.py:235
+  if (eval_total > 0) {
+    pb.do_eval = 1; pb.n_total = eval_total; pb.eval_every = std::max(eval_total / 5, 1);   // mdnn.py:235
     pb.n_test = (int)b.n_test;
     pb.eval_row0 = p->feat_unique ? b.n_train : p->n_updates * p->batch;  // as eval_inputs()
     pb.y_test = b.y_test; pb.ldy_test = b.ldy_test; pb.test_loss = b.test_loss;
@@ -433,7 +434,7 @@ static PersistMdnnShape persist_mdnn_shape(const bsig_fit_plan* p) {
 
 // n consecutive updates of the two-layer MDNN in its persistent kernel (with_eval: a whole
 // bsig_fit_run call, its held-out evaluations inside the launch)
-static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, bool with_eval = false) {
+static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, int eval_total = 0) {
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
   PersistMdnnBuffers pb;
@@ -449,8 +450,8 @@ static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, bool
     pb.grads = b.grads; pb.adam_pending = p->adam_pending ? 1 : 0;
     p->adam_pending = false;
   }
-  if (with_eval) {
-    pb.do_eval = 1; pb.n_total = n; pb.eval_every = std::max(n / 5, 1);   // mdnn.py:235
+  if (eval_total > 0) {
+    pb.do_eval = 1; pb.n_total = eval_total; pb.eval_every = std::max(eval_total / 5, 1);   // mdnn.py:235
     pb.n_test = (int)b.n_test;
     pb.x_test = b.x_test; pb.ldx_test = b.ldx_test; pb.y_test = b.y_test; pb.ldy_test = b.ldy_test;
     pb.test_loss = b.test_loss;
@@ -777,6 +778,7 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
   hipLaunchKernelGGL(fit_begin_kernel, dim3(1), dim3(64), 0, st, p->buf.state, seed);
   BSIG_CHECK_LAUNCH("fit_begin");
   p->adam_pending = false;
+  p->dp_evals_done = 0;
   if (p->persistent) {
     PlanMem m; plan_mem(p, &m);
     BSIG_TRY(persist_reset(persist_shape(p), m.persist_ws, p->persist_bytes, st));
@@ -792,10 +794,21 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
   return ensure_graphs(p);
 }
 
+// data-parallel plans covered by a persistent kernel: the held-out evaluations run inside
+// the per-update launches too (the one after the last update in the launch that takes its
+// pending Adam step)
+static int dp_eval_total(const bsig_fit_plan* p) {
+  const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
+  if (!p->split_adam || p->buf.n_test < 1 || p->n_updates < 1 || (no_ike && no_ike[0] == '1')) return 0;
+  if (p->persistent && persist_eval_supported(persist_shape(p))) return (int)p->n_updates;
+  if (p->persistent_mdnn && persist_mdnn_eval_supported(persist_mdnn_shape(p))) return (int)p->n_updates;
+  return 0;
+}
+
 extern "C" int bsig_fit_grad(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_grad: plan not bound with SPLIT_ADAM");
-  if (p->persistent) return enqueue_persistent(p, 1, as_stream(stream));
-  if (p->persistent_mdnn) return enqueue_persistent_mdnn(p, 1, as_stream(stream));
+  if (p->persistent) return enqueue_persistent(p, 1, as_stream(stream), dp_eval_total(p));
+  if (p->persistent_mdnn) return enqueue_persistent_mdnn(p, 1, as_stream(stream), dp_eval_total(p));
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_grad, as_stream(stream))); return BSIG_OK; }
   return enqueue_grad(p, as_stream(stream), false);
 }
@@ -826,6 +839,12 @@ extern "C" int bsig_fit_flush(bsig_fit_plan* p, bsig_stream_t stream) {
 
 extern "C" int bsig_fit_eval(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound, "fit_eval: plan not bound");
+  if (const int total = dp_eval_total(p)) {
+    // evaluations inside the launches: all but the last are already under way
+    if (++p->dp_evals_done < count_evals(total)) return BSIG_OK;
+    return p->persistent ? enqueue_persistent(p, 0, as_stream(stream), total)
+                         : enqueue_persistent_mdnn(p, 0, as_stream(stream), total);
+  }
   BSIG_TRY(bsig_fit_flush(p, stream));
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_eval, as_stream(stream))); return BSIG_OK; }
   return enqueue_eval(p, as_stream(stream));
@@ -839,7 +858,8 @@ static int enqueue_updates(bsig_fit_plan* p, int64_t n, hipStream_t st) {
   if (p->persistent_mdnn && !p->split_adam) return enqueue_persistent_mdnn(p, (int)n, st);
   if (p->persistent || p->persistent_mdnn) {   // data-parallel plan driven without an exchange (one rank)
     for (int64_t it = 0; it < n; ++it) {
-      BSIG_TRY(p->persistent ? enqueue_persistent(p, 1, st) : enqueue_persistent_mdnn(p, 1, st));
+      BSIG_TRY(p->persistent ? enqueue_persistent(p, 1, st, dp_eval_total(p))
+                             : enqueue_persistent_mdnn(p, 1, st, dp_eval_total(p)));
       p->adam_pending = true;
     }
     return BSIG_OK;
@@ -880,10 +900,10 @@ extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t s
   const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
   if (p->persistent && !p->split_adam && n_updates >= 1 && p->buf.n_test >= 1 &&
       !(no_ike && no_ike[0] == '1') && persist_eval_supported(persist_shape(p)))
-    return enqueue_persistent(p, (int)n_updates, st, true);
+    return enqueue_persistent(p, (int)n_updates, st, (int)n_updates);
   if (p->persistent_mdnn && !p->split_adam && n_updates >= 1 && p->buf.n_test >= 1 &&
       !(no_ike && no_ike[0] == '1') && persist_mdnn_eval_supported(persist_mdnn_shape(p)))
-    return enqueue_persistent_mdnn(p, (int)n_updates, st, true);
+    return enqueue_persistent_mdnn(p, (int)n_updates, st, (int)n_updates);
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
   int64_t done = 0;
   for (int64_t it = 0; it < n_updates; ++it) {

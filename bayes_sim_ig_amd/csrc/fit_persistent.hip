@@ -327,7 +327,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
 
     // ---- while the row owners work: the evaluation due after the previous update
     //      (this tile still holds those weights), next feature tile, Adam scalars ------
-    if (__builtin_expect(!dp && p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
+    if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
       tile_eval(p, Wl, X, biasl, evals_before(step, p.eval_every) - 1);
     if (t + 1 < p.n_updates) {
       const int64_t pf_row0 = (int64_t)(step + 1) * B;
@@ -418,7 +418,8 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
   }
 
   // ---- the evaluation after the last update of the call ----------------------------
-  if (!dp && p.do_eval && step0 + p.n_updates == p.n_total) {
+  // (a data-parallel rank: in the launch that only takes the pending Adam step of that update)
+  if (p.do_eval && step0 + p.n_updates == p.n_total && (!dp || p.n_updates == 0)) {
     if (bias_pending && tid < kNB) bias_step(tid);
     bias_pending = false;
     __syncthreads();
@@ -453,7 +454,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     int n_ev = 0;
     if (p.do_eval) {
       n_ev = evals_before(step0 + p.n_updates, p.eval_every) - evals_before(step0, p.eval_every);
-      if (step0 + p.n_updates == p.n_total && (p.n_total - 1) % p.eval_every != 0) ++n_ev;
+      if (!dp && step0 + p.n_updates == p.n_total && (p.n_total - 1) % p.eval_every != 0) ++n_ev;
     }
     reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)(p.n_updates + n_ev);
     st[0] = step0 + p.n_updates;
@@ -667,7 +668,8 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
                  rng_ctr0 + (uint64_t)t + (uint64_t)(evals_before(step, p.eval_every) - ev0) - 1u);
     }
   }
-  if (p.do_eval && step0 + p.n_updates == p.n_total && !run_aborted(flagp, red, tid))
+  if (p.do_eval && step0 + p.n_updates == p.n_total && (p.grads == nullptr || p.n_updates == 0) &&
+      !run_aborted(flagp, red, tid))
     owner_eval(evals_before(p.n_total - 1, p.eval_every),
                rng_ctr0 + (uint64_t)p.n_updates + (uint64_t)(evals_before(p.n_total - 1, p.eval_every) - ev0));
 }
@@ -783,7 +785,7 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
                "persistent updates: features must be 16-byte aligned rows");
   BSIG_REQUIRE(!(b.adam_pending && !b.grads), "persistent updates: pending Adam step without gradients");
   BSIG_REQUIRE(!(b.grads && n > 1), "persistent updates: data-parallel launches take one update");
-  if (n <= 0 && !b.adam_pending) return BSIG_OK;
+  if (n <= 0 && !b.adam_pending && !b.do_eval) return BSIG_OK;
   static bool attr_set = false;
   if (!attr_set) {
     BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_head_updates_kernel<false>),
@@ -815,7 +817,7 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.gran = reinterpret_cast<unsigned long long*>(sync + 2 * kXwgMax * sizeof(unsigned));
   p.gran_eval = p.gran + 3 * kXwgMax;
   if (b.do_eval) {
-    BSIG_REQUIRE(!b.grads && g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
+    BSIG_REQUIRE(g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
                      b.y_test && b.test_loss && b.eval_every >= 1 && b.n_total >= 1,
                  "persistent updates: in-launch evaluation not covered");
     p.do_eval = 1; p.eval_every = b.eval_every; p.n_total = b.n_total; p.n_test = b.n_test;
@@ -825,7 +827,7 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.prof = g_prof;
   // (a pending-Adam-only launch needs the tile workgroups only)
   if (b.grads)
-    hipLaunchKernelGGL(linear_head_updates_kernel<true>, dim3(n > 0 ? g.G + g.n_owner : g.G),
+    hipLaunchKernelGGL(linear_head_updates_kernel<true>, dim3(n > 0 || b.do_eval ? g.G + g.n_owner : g.G),
                        dim3(kPT), g.lds, st, p);
   else
     hipLaunchKernelGGL(linear_head_updates_kernel<false>, dim3(g.G + g.n_owner), dim3(kPT), g.lds,

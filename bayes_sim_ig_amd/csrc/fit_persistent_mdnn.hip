@@ -335,7 +335,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
 
     // ---- while the owners work: the evaluation due after the previous update (this tile
     //      still holds those weights), next summary tile, Adam scalars -------------------
-    if (__builtin_expect(!DP && p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
+    if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
       mdnn_tile_eval(p, Wl, X, biasl, mdnn_evals_before(step, p.eval_every) - 1);
     if (t + 1 < p.n_updates) {
       const int64_t pf_row0 = (int64_t)(step + 1) * B;
@@ -413,7 +413,8 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   }
 
   // ---- the evaluation after the last update of the call ------------------------------
-  if (!DP && p.do_eval && step0 + p.n_updates == p.n_total) {
+  // (a data-parallel rank: in the launch that only takes the pending Adam step of that update)
+  if (p.do_eval && step0 + p.n_updates == p.n_total && (!DP || p.n_updates == 0)) {
     if (bias_pending && tid < kMNB) bias_step(tid);
     bias_pending = false;
     __syncthreads();
@@ -444,7 +445,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     int n_ev = 0;
     if (p.do_eval) {
       n_ev = mdnn_evals_before(step0 + p.n_updates, p.eval_every) - mdnn_evals_before(step0, p.eval_every);
-      if (step0 + p.n_updates == p.n_total && (p.n_total - 1) % p.eval_every != 0) ++n_ev;
+      if (!DP && step0 + p.n_updates == p.n_total && (p.n_total - 1) % p.eval_every != 0) ++n_ev;
     }
     reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)(p.n_updates + n_ev);
     st[0] = step0 + p.n_updates;
@@ -680,7 +681,8 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     if (refresh) {
       // after the last update of the call: the head matrix and the biases in LDS are those
       // of that update -- fetch what its Adam step published
-      if (w == 0) flags_wait(p.flag_small, p.n_small, (unsigned)step, lane, flagp);
+      // (a data-parallel rank has them behind flag_pack, waited for at the top)
+      if (!DP && w == 0) flags_wait(p.flag_small, p.n_small, (unsigned)step, lane, flagp);
       __syncthreads();
       for (int idx = tid; idx < Nh16 * (kMH / 2); idx += kMT) {
         const int n = idx >> 6, c2 = (idx & 63) * 2;
@@ -1135,13 +1137,14 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     }
     // the evaluation due after the previous update: the tile workgroups formed its
     // first-layer products while this update's rows were being finished
-    if (__builtin_expect(!DP && p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
+    if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
       __syncthreads();
       owner_eval(mdnn_evals_before(step, p.eval_every) - 1,
                  rng_ctr0 + (uint64_t)t + (uint64_t)(mdnn_evals_before(step, p.eval_every) - ev0) - 1u, step, false);
     }
   }
-  if (!DP && p.do_eval && step0 + p.n_updates == p.n_total && !run_aborted(flagp, red, tid_0))
+  if (p.do_eval && step0 + p.n_updates == p.n_total && (!DP || p.n_updates == 0) &&
+      !run_aborted(flagp, red, tid_0))
     owner_eval(mdnn_evals_before(p.n_total - 1, p.eval_every),
                rng_ctr0 + (uint64_t)p.n_updates +
                    (uint64_t)(mdnn_evals_before(p.n_total - 1, p.eval_every) - ev0), p.n_total, true);
@@ -1261,7 +1264,7 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
                "persistent MDNN updates: weight blocks must be 8-byte aligned");
   BSIG_REQUIRE(!(b.adam_pending && !b.grads), "persistent MDNN updates: pending Adam step without gradients");
   BSIG_REQUIRE(!(b.grads && n > 1), "persistent MDNN updates: data-parallel launches take one update");
-  if (n <= 0 && !b.adam_pending) return BSIG_OK;
+  if (n <= 0 && !b.adam_pending && !b.do_eval) return BSIG_OK;
   static bool attr_set = false;
   if (!attr_set) {
     BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mdnn_updates_kernel<false>),
@@ -1306,7 +1309,7 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.gran = reinterpret_cast<unsigned long long*>(sync + 5 * kXwgMax * sizeof(unsigned));
   p.gran_eval = p.gran + 3 * kXwgMax;
   if (b.do_eval) {
-    BSIG_REQUIRE(!b.grads && g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
+    BSIG_REQUIRE(g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
                      b.x_test && b.y_test && b.test_loss && b.eval_every >= 1 && b.n_total >= 1 &&
                      b.ldx_test % 4 == 0 && b.ldx_test >= s.input_dim && aligned(b.x_test, 16),
                  "persistent MDNN updates: in-launch evaluation not covered");
