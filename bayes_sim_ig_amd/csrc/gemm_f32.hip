@@ -722,7 +722,7 @@ static int launch_tile(const GemmParams& p, bool akm, bool bkm, int avec, int bv
   return BSIG_EUNSUPPORTED;
 }
 
-enum { TILE_64 = 0, TILE_128 = 1, TILE_128x32 = 2 };
+enum { TILE_64 = 0, TILE_128 = 1, TILE_128x32 = 2, TILE_128x64 = 3 };
 struct GemmPlan { int tile; int splits; int k_chunk; };
 
 static int env_int(const char* name, int dflt) {
@@ -737,8 +737,13 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
   GemmPlan pl;
   const int64_t t128 = ceil_div<int64_t>(m, 128) * ceil_div<int64_t>(n, 128);
   int64_t tiles, target;
+  const int64_t t12864 = ceil_div<int64_t>(m, 128) * ceil_div<int64_t>(n, 64);
   if (m >= 256 && n >= 128 && t128 >= 192) {
     pl.tile = TILE_128; tiles = t128; target = 256;
+  } else if (m >= 256 && n >= 128 && t12864 >= 160 && t12864 <= 512) {
+    // mid-sized (a chunk's RFF projection, 800 x 2048): 128x64 tiles give one round of
+    // ~224 workgroups on the 256 CUs where 64x64 tiles give 1.6 rounds of smaller ones
+    pl.tile = TILE_128x64; tiles = t12864; target = 256;
   } else if (m <= 128 && n >= 64) {
     pl.tile = TILE_128x32; tiles = ceil_div<int64_t>(n, 32); target = 512;
   } else {
@@ -748,7 +753,8 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
   if (forced_tile >= 0) {
     pl.tile = forced_tile;
     const int bm = forced_tile == TILE_64 ? 64 : 128;
-    const int bn = forced_tile == TILE_64 ? 64 : (forced_tile == TILE_128 ? 128 : 32);
+    const int bn = forced_tile == TILE_64 || forced_tile == TILE_128x64 ? 64
+                   : (forced_tile == TILE_128 ? 128 : 32);
     tiles = ceil_div<int64_t>(m, bm) * ceil_div<int64_t>(n, bn);
   }
   int64_t splits = 1;
@@ -758,6 +764,9 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
     if (splits > max_by_k) splits = max_by_k;
     if (splits > 64) splits = 64;
   }
+  // (measured, tools/micro/rff_shape_sweep.py: 800..1000 x 2048 x 2310 runs 101-104 us as
+  // 128x64 tiles with two k-halves, 118-121 us as 64x64 tiles, 129-135 us unsplit)
+  if (pl.tile == TILE_128x64 && forced_tile < 0 && k >= 8 * BK) splits = 2;
   const int forced = env_int("BSIG_GEMM_SPLITS", 0);
   if (forced > 0) splits = forced;
   const int64_t max_by_ws = (int64_t)(ws_bytes / (sizeof(float) * (size_t)(m * n)));
@@ -801,6 +810,8 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     rc = launch_tile<2, 2, 2, 2>(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else if (pl.tile == TILE_128x32)
     rc = launch_tile<4, 1, 1, 1>(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
+  else if (pl.tile == TILE_128x64)
+    rc = launch_tile<2, 2, 2, 1>(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else
     rc = launch_tile<2, 2, 1, 1>(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   if (rc != BSIG_OK) return rc;
@@ -813,7 +824,7 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     if (n_expsum && p.expsum) *n_expsum = blocks;
   } else if (n_expsum && p.expsum) {
     const int bm = pl.tile == TILE_64 ? 64 : 128;
-    const int bn = pl.tile == TILE_64 ? 64 : (pl.tile == TILE_128 ? 128 : 32);
+    const int bn = pl.tile == TILE_64 || pl.tile == TILE_128x64 ? 64 : (pl.tile == TILE_128 ? 128 : 32);
     *n_expsum = ceil_div(p.m, bm) * ceil_div(p.n, bn);
   }
   return BSIG_OK;
