@@ -88,6 +88,7 @@ _PROTOS = {
     'bsig_fit_workspace_bytes': (sz, [vp]),
     'bsig_fit_bind': (C.c_int, [vp, C.POINTER(FitBuffers), C.c_int]),
     'bsig_fit_begin': (C.c_int, [vp, u64, i64, vp]),
+    'bsig_fit_set_features': (C.c_int, [vp, vp, i64, i64, vp]),
     'bsig_fit_run': (C.c_int, [vp, i64, vp]),
     'bsig_fit_grad': (C.c_int, [vp, vp]),
     'bsig_fit_apply': (C.c_int, [vp, vp]),

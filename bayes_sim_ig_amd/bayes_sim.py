@@ -8,6 +8,8 @@ hard-coded chunk schedule of bayes_sim.py:20-25, the multi-trajectory refit
 of :148-179) and drives the HIP summarizers and estimators.  ``fit`` adds the
 caller-side chunk loop of bayes_sim_main.py:157-167 for pre-recorded pairs.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -29,6 +31,7 @@ _MODELS = {'MDNN': MDNN, 'MDRFF': MDRFF}
 
 class BayesSim(object):
     NUM_TRAIN_TRAJ_PER_BATCH = 1000  # num trajs for each training batch
+    FIT_BLOCK_CHUNKS = 32            # (not in the reference) chunks summarised / projected at once by fit()
     NUM_TRAIN_EPOCHS = 10            # num times to go over the batch
     MINIBATCH_SIZE = 100             # minibatch size for NN training
     NUM_GRAD_UPDATES = NUM_TRAIN_EPOCHS * NUM_TRAIN_TRAJ_PER_BATCH // MINIBATCH_SIZE
@@ -90,15 +93,18 @@ class BayesSim(object):
             return self.summarizer_fxn(states, actions, check_finite=finite_flag)
         return self.summarizer_fxn(states, actions)
 
-    def run_training(self, params, traj_states, traj_actions, _defer=False, _finite_flag=None):
+    def run_training(self, params, traj_states, traj_actions, _defer=False, _finite_flag=None,
+                     _summaries=None, _feats=None):
         """One chunk: summarize, then NUM_GRAD_UPDATES Adam updates of
         MINIBATCH_SIZE (reference bayes_sim.py:91-114)."""
-        traj_summaries = self._summarize(traj_states, traj_actions, _finite_flag)
+        traj_summaries = _summaries if _summaries is not None else \
+            self._summarize(traj_states, traj_actions, _finite_flag)
+        kw = {} if _feats is None else {'_feats': _feats}
         return self.model.run_training(
             x_data=traj_summaries, y_data=params,
             n_updates=BayesSim.NUM_GRAD_UPDATES,
             batch_size=BayesSim.MINIBATCH_SIZE,
-            test_frac=BayesSim.TEST_FRACTION, _defer=_defer)
+            test_frac=BayesSim.TEST_FRACTION, _defer=_defer, **kw)
 
     def fit(self, params, traj_states, traj_actions):
         """The caller-side loop of bayes_sim_main.py:157-167 over
@@ -109,12 +115,30 @@ class BayesSim(object):
         flag = None
         if torch.is_tensor(traj_states) and traj_states.is_cuda:
             flag = torch.zeros(1, dtype=torch.int32, device=traj_states.device)
+        # MDRFF: the summaries and their RFF features are pure functions of the row
+        # (rff.py:128-132): both are computed for a block of chunks at once -- one
+        # summarizer launch and one large MFMA GEMM instead of one small one per chunk
+        block = 0
+        if flag is not None and getattr(self.model, 'rff', None) is not None and \
+                os.environ.get('BSIG_NO_FIT_PREPROJECT') != '1' and self.model._dp is None:
+            block = BayesSim.FIT_BLOCK_CHUNKS * BayesSim.NUM_TRAIN_TRAJ_PER_BATCH
+        lo = hi = 0
+        summ = feats = None
         while done < n:
             m = BayesSim.get_n_trajs_per_batch(n, done)
-            pending.append(self.run_training(params[done:done + m],
-                                             traj_states[done:done + m],
-                                             traj_actions[done:done + m], _defer=True,
-                                             _finite_flag=flag))
+            if block and done + m > hi:
+                lo, hi = done, min(n, done + block)
+                summ = self._summarize(traj_states[lo:hi], traj_actions[lo:hi], flag)
+                feats = self.model.rff.to_features(summ)
+            if block:
+                pending.append(self.run_training(params[done:done + m], None, None, _defer=True,
+                                                 _summaries=summ[done - lo:done - lo + m],
+                                                 _feats=feats[done - lo:done - lo + m]))
+            else:
+                pending.append(self.run_training(params[done:done + m],
+                                                 traj_states[done:done + m],
+                                                 traj_actions[done:done + m], _defer=True,
+                                                 _finite_flag=flag))
             done += m
         # one host synchronisation for the whole fit: the chunks' logs (and the
         # isfinite asserts) are read back after the last chunk is enqueued

@@ -348,6 +348,7 @@ struct bsig_fit_plan {
   int64_t batch, max_test, n_updates, n_evals;
   bool hoist;                  // RFF projection once per run_training call
   bool feat_unique;            // ... of the distinct training rows (else of every gathered minibatch row)
+  bool feats_preloaded;        // ... already handed over by the caller (bsig_fit_set_features)
   int64_t feat_rows;           // n_updates*batch + max_test
   bsig_fit_buffers buf;
   bool bound;
@@ -769,6 +770,21 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
   return BSIG_OK;
 }
 
+extern "C" int bsig_fit_set_features(bsig_fit_plan* p, const float* feats, int64_t ld_feats,
+                                     int64_t rows, bsig_stream_t stream) {
+  BSIG_REQUIRE(p && p->bound && feats, "fit_set_features: plan not bound / null");
+  BSIG_REQUIRE(p->hoist && p->feat_unique, "fit_set_features: the plan keeps no per-row feature cache");
+  BSIG_REQUIRE(rows == p->buf.n_train + p->buf.n_test && ld_feats >= p->cfg.rff_feats,
+               "fit_set_features: need the %lld training + %lld held-out rows",
+               (long long)p->buf.n_train, (long long)p->buf.n_test);
+  PlanMem m; plan_mem(p, &m);
+  const size_t w = (size_t)p->cfg.rff_feats * sizeof(float);
+  BSIG_HIP(hipMemcpy2DAsync(m.feats, w, feats, (size_t)ld_feats * sizeof(float), w, (size_t)rows,
+                            hipMemcpyDeviceToDevice, as_stream(stream)));
+  p->feats_preloaded = true;
+  return BSIG_OK;
+}
+
 extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batch,
                               bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound, "fit_begin: plan not bound");
@@ -790,7 +806,10 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
   // fresh optimizer state for every run_training call (mdnn.py:203)
   BSIG_HIP(hipMemsetAsync(p->buf.exp_avg, 0, (size_t)p->L.total * sizeof(float), st));
   BSIG_HIP(hipMemsetAsync(p->buf.exp_avg_sq, 0, (size_t)p->L.total * sizeof(float), st));
-  if (p->hoist) BSIG_TRY(enqueue_hoisted_rff(p, st));
+  if (p->hoist) {
+    if (p->feats_preloaded) p->feats_preloaded = false;   // handed over for this call
+    else BSIG_TRY(enqueue_hoisted_rff(p, st));
+  }
   return ensure_graphs(p);
 }
 

@@ -350,7 +350,7 @@ class MDNN(nn.Module):
         return self
 
     def run_training(self, x_data, y_data, n_updates, batch_size, test_frac=0.2,
-                     ids_table=None, _defer=False):
+                     ids_table=None, _defer=False, _feats=None):
         """Reference mdnn.py:180-243.  Returns {'train_loss': [...],
         'test_loss': [...]} with the same 6 logging points.  ``ids_table``
         [n_updates, batch] (optional) overrides the numpy-RNG minibatch draw
@@ -445,6 +445,11 @@ class MDNN(nn.Module):
         flags = (_lib.FIT_GRAPH if type(self).USE_GRAPH else 0) | \
             (_lib.FIT_SPLIT_ADAM if self._dp is not None else 0)
         _lib.check(lib.bsig_fit_bind(self._plan, C.byref(fb), flags))
+        if _feats is not None:
+            # MDRFF: the rows' RFF features, already projected by the caller (BayesSim.fit)
+            assert _feats.shape[0] == n_tot and _feats.is_cuda and _feats.dtype == torch.float32
+            _lib.check(lib.bsig_fit_set_features(self._plan, _lib.ptr(_feats), _feats.stride(0),
+                                                 n_tot, st))
         world = 1 if self._dp is None else self._dp.world
         _lib.check(lib.bsig_fit_begin(self._plan, self._seed(), batch_size * world, st))
         if self._dp is None:

@@ -255,6 +255,13 @@ size_t bsig_fit_workspace_bytes(const bsig_fit_plan* plan);
 #define BSIG_FIT_GRAPH 1
 #define BSIG_FIT_SPLIT_ADAM 2
 int bsig_fit_bind(bsig_fit_plan* plan, const bsig_fit_buffers* buffers, int flags);
+/* MDRFF: hand the RFF features of this call's rows over instead of having bsig_fit_begin
+ * project them (rff.py:128-132 is a pure function of the row): `feats` [rows, ld_feats],
+ * rows = n_train + n_test in the order of x_train / x_test.  A caller that fits many chunks
+ * (BayesSim.fit) projects all their rows in one large GEMM.  Valid for the next
+ * bsig_fit_begin only. */
+int bsig_fit_set_features(bsig_fit_plan* plan, const float* feats, int64_t ld_feats,
+                          int64_t rows, bsig_stream_t stream);
 /* Reset step counter / Adam state (fresh optimizer per call, mdnn.py:203). */
 int bsig_fit_begin(bsig_fit_plan* plan, uint64_t seed, int64_t norm_batch,
                    bsig_stream_t stream);

@@ -427,6 +427,34 @@ def test_fit_defers_the_summarizer_finiteness_assert(B):
         bs.fit(theta, bad, actions)
 
 
+def test_fit_projects_blocks_of_chunks_at_once(B):
+    """BayesSim.fit with an MDRFF summarises and RFF-projects blocks of chunks in one
+    launch each (the features are a pure function of the row) and hands every chunk
+    its rows' features; BSIG_NO_FIT_PREPROJECT=1 projects per chunk inside
+    bsig_fit_begin.  Same minibatches, same jitter streams: the logs agree to fp32
+    GEMM summation order (another tile shape for the large product)."""
+    import os
+    import bench
+    cfg = dict(task='synthetic', model='MDRFF', summarizer='summary_start', t=11, sd=5, ad=2,
+               d=4, k=6, hidden=[], n_feat=512, pairs=3500)
+    theta, states, actions = bench.synth_pairs(cfg, 3500, 3, DEV)
+    out = []
+    for env in ('0', '1'):
+        os.environ['BSIG_NO_FIT_PREPROJECT'] = env
+        try:
+            bs = bench.build_gpu_model(B, cfg, DEV, 77)
+            np.random.seed(11)
+            out.append((bs.fit(theta, states, actions), bs.model._flat.clone()))
+        finally:
+            os.environ.pop('BSIG_NO_FIT_PREPROJECT', None)
+    (la, fa), (lb, fb) = out
+    assert len(la) == len(lb) == 4                       # 1000 + 1000 + 1000 + 500 pairs
+    for x, y in zip(la, lb):
+        np.testing.assert_allclose(x['train_loss'], y['train_loss'], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(x['test_loss'], y['test_loss'], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(fa, fb, rtol=1e-2, atol=2e-3)
+
+
 def test_full_size_chunk_protocol_fit(B):
     """cfg5-shaped fit (ShadowHand MDRFF-4096, summary_start) over 20 chunks with
     the reference defaults (EPS_NOISE=1e-5, numpy-RNG ids): finite, 6+6 logs per
