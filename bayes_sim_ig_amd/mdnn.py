@@ -448,8 +448,8 @@ class MDNN(nn.Module):
         if _feats is not None:
             # MDRFF: the rows' RFF features, already projected by the caller (BayesSim.fit)
             assert _feats.shape[0] == n_tot and _feats.is_cuda and _feats.dtype == torch.float32
-            _lib.check(lib.bsig_fit_set_features(self._plan, _lib.ptr(_feats), _feats.stride(0),
-                                                 n_tot, st))
+            # (a plan without a per-row feature cache declines: bsig_fit_begin then projects)
+            lib.bsig_fit_set_features(self._plan, _lib.ptr(_feats), _feats.stride(0), n_tot, st)
         world = 1 if self._dp is None else self._dp.world
         _lib.check(lib.bsig_fit_begin(self._plan, self._seed(), batch_size * world, st))
         if self._dp is None:

@@ -124,22 +124,31 @@ def cpu_baseline(cfg, theta, states, actions, budget_s=12.0, max_chunks=12):
             break
     torch.set_num_threads(best_nt)
     model = build_oracle(cfg, in_dim, 1234, 1e-5)
-    done, chunks, n = 0, 0, th.shape[0]
-    t0 = time.perf_counter()
-    while done < n and chunks < max_chunks:
-        m = min(1000, n - done)
-        summ = fn(st[done:done + m], ac[done:done + m])
-        model.run_training(summ, th[done:done + m], 100, 100)
-        done += m
-        chunks += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {'value': done / dt, 'unit': 'pairs/s', 'cores': best_nt, 'kind': 'port',
+    # two passes over consecutive halves of the sample; the faster one is reported (a shared
+    # host can lose a factor of two for seconds at a time)
+    done, n, passes = 0, th.shape[0], []
+    for half in range(2):
+        p_done, chunks = 0, 0
+        t0 = time.perf_counter()
+        while done < n and chunks < max_chunks // 2:
+            m = min(1000, n - done)
+            summ = fn(st[done:done + m], ac[done:done + m])
+            model.run_training(summ, th[done:done + m], 100, 100)
+            done += m
+            p_done += m
+            chunks += 1
+            if time.perf_counter() - t0 > budget_s / 2:
+                break
+        if p_done:
+            passes.append((p_done / (time.perf_counter() - t0), p_done, chunks,
+                           time.perf_counter() - t0))
+    rate, p_done, chunks, dt = max(passes)
+    return {'value': rate, 'unit': 'pairs/s', 'cores': best_nt, 'kind': 'port',
             'sample': '%d pairs (%d chunks of the same synthetic workload, reference chunk '
-                      'protocol) in %.1f s; torch %s CPU, %d threads (best of 1..32 by '
-                      'calibration; host has %d logical CPUs)'
-                      % (done, chunks, dt, torch.__version__, best_nt, ncpu)}
+                      'protocol) in %.1f s, the faster of two such passes (%s pairs/s); torch %s '
+                      'CPU, %d threads (best of 1..32 by calibration; host has %d logical CPUs)'
+                      % (p_done, chunks, dt, ' / '.join('%.0f' % q[0] for q in passes),
+                         torch.__version__, best_nt, ncpu)}
 
 
 def nll_check(pkg, cfg, theta, states, actions, device):
