@@ -36,6 +36,10 @@ class BayesSim(object):
     MINIBATCH_SIZE = 100             # minibatch size for NN training
     NUM_GRAD_UPDATES = NUM_TRAIN_EPOCHS * NUM_TRAIN_TRAJ_PER_BATCH // MINIBATCH_SIZE
     TEST_FRACTION = 0.2              # fraction of dataset to use as test
+    # the multi-trajectory refit of predict(): literals in the reference (bayes_sim.py:162,173-174)
+    REFIT_SAMPLES = int(1e4)         # samples drawn from the per-trajectory MoGs
+    REFIT_MINIBATCH = 100
+    REFIT_EPOCHS = 5
 
     def __init__(self, model_cfg, obs_dim, act_dim, params_dim, params_lows,
                  params_highs, prior, proposal=None, device='cpu'):
@@ -170,14 +174,14 @@ class BayesSim(object):
             n_gaussians=self.model.n_gaussians, hidden_layers=(128, 128),
             lr=self.model.lr, activation=self.model.activation,
             full_covariance=self.model.L_size > 0, device=self.model.device)
-        tot_smpls = int(1e4)
+        tot_smpls = BayesSim.REFIT_SAMPLES
         per_mog = int(tot_smpls / xs.shape[0])
         smpls = np.concatenate([m.gen(n_samples=per_mog) for m in mogs], axis=0)
         smpls = torch.from_numpy(smpls).float().to(self.model.device)
         if MDNN.VERBOSE:
             print(f'Fitting posterior from {len(mogs):d} mogs')
-        batch_size = 100
-        n_updates = 5 * tot_smpls // batch_size
+        batch_size = BayesSim.REFIT_MINIBATCH
+        n_updates = BayesSim.REFIT_EPOCHS * tot_smpls // batch_size
         inp = torch.zeros(smpls.shape[0], 1, device=smpls.device)
         mog_model.run_training(inp, smpls, n_updates, batch_size)
         fitted = mog_model.predict_MoGs(inp[0:1, :])
