@@ -97,7 +97,20 @@ _PROTOS = {
     'bsig_fit_eval': (C.c_int, [vp, vp]),
     'bsig_fit_updates': (C.c_int, [vp, i64, vp]),
     'bsig_debug_persist_profile': (None, [vp]),
+    'bsig_comm_unique_id': (C.c_int, [vp]),
+    'bsig_comm_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    'bsig_comm_init_external': (C.c_int, [C.c_int, C.c_int, vp, vp, C.POINTER(vp)]),
+    'bsig_comm_world': (C.c_int, [vp]),
+    'bsig_comm_rank': (C.c_int, [vp]),
+    'bsig_comm_allreduce': (C.c_int, [vp, vp, i64, vp]),
+    'bsig_comm_broadcast': (C.c_int, [vp, vp, i64, C.c_int, vp]),
+    'bsig_comm_destroy': (None, [vp]),
+    'bsig_fit_pack_logs': (C.c_int, [vp, i64, vp, vp]),
+    'bsig_fit_run_dp': (C.c_int, [vp, vp, i64, vp, vp]),
 }
+COMM_ID_BYTES = 128
+EXCHANGE_SUM, EXCHANGE_BROADCAST = 0, 1
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, vp, i64, C.c_int, vp)
 
 _lib = None
 
@@ -148,8 +161,15 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream(device=None):
+    """torch's current stream of ``device`` (default: the current device) as a hipStream_t."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device(device):
+    """Context: make ``device`` the current HIP device (kernels launch on the current
+    device; a model built on cuda:1 must not launch on cuda:0's stream)."""
+    return torch.cuda.device(device)
 
 
 def as_f32_rows(t, device=None):

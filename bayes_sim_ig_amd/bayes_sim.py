@@ -116,6 +116,14 @@ class BayesSim(object):
         NUM_TRAIN_TRAJ_PER_BATCH pairs, ``run_training`` on each.
         Returns the list of per-chunk log dicts."""
         n, done, pending = params.shape[0], 0, []
+        dp = getattr(self.model, '_dp', None)
+        if dp is not None:
+            # one all-reduce per update: every rank must run the same chunk schedule, or the
+            # rank with an extra chunk waits for its peers forever
+            counts = dp.gather_counts(n, device=self.model._flat.device)
+            if len(set(counts)) != 1:
+                raise ValueError('data-parallel fit needs the same number of pairs on every rank '
+                                 '(got %s); see dp.equal_shards' % (counts,))
         flag = None
         if torch.is_tensor(traj_states) and traj_states.is_cuda:
             flag = torch.zeros(1, dtype=torch.int32, device=traj_states.device)
@@ -124,7 +132,7 @@ class BayesSim(object):
         # summarizer launch and one large MFMA GEMM instead of one small one per chunk
         block = 0
         if flag is not None and getattr(self.model, 'rff', None) is not None and \
-                os.environ.get('BSIG_NO_FIT_PREPROJECT') != '1' and self.model._dp is None:
+                os.environ.get('BSIG_NO_FIT_PREPROJECT') != '1':
             block = BayesSim.FIT_BLOCK_CHUNKS * BayesSim.NUM_TRAIN_TRAJ_PER_BATCH
         lo = hi = 0
         summ = feats = None

@@ -1,0 +1,180 @@
+// The one exchange of the data-parallel fit: a sum all-reduce of the
+// flat fp32 gradient buffer across the ranks of one node, RCCL over xGMI, enqueued on
+// the fit's stream.  The reference has no counterpart (single device); the call site is
+// between loss.backward() and optimizer.step() of mdnn.py:233-234.
+//
+// RCCL is bound at run time (dlopen "librccl.so.1"): a process that already carries an
+// RCCL (PyTorch-ROCm bundles one next to its HIP runtime) keeps using that one — the
+// collective must run on the HIP runtime that owns the caller's streams — and the
+// library stays loadable on hosts without RCCL (single-GPU use never touches this file).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "common.h"
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclBroadcast) broadcast = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+  bool ok = false;
+};
+
+Rccl g_rccl;
+std::once_flag g_once;
+char g_load_error[256] = "";
+
+void load_rccl() {
+  const char* names[] = {"librccl.so.1", "librccl.so"};
+  for (const char* n : names) {
+    g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (g_rccl.handle) break;
+  }
+  if (!g_rccl.handle) {
+    snprintf(g_load_error, sizeof(g_load_error), "dlopen(librccl.so.1): %s", dlerror());
+    return;
+  }
+#define BSIG_SYM(field, name)                                                         \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.handle, name)); \
+  if (!g_rccl.field) {                                                                \
+    snprintf(g_load_error, sizeof(g_load_error), "librccl: no symbol %s", name);      \
+    return;                                                                           \
+  }
+  BSIG_SYM(get_unique_id, "ncclGetUniqueId")
+  BSIG_SYM(comm_init_rank, "ncclCommInitRank")
+  BSIG_SYM(comm_destroy, "ncclCommDestroy")
+  BSIG_SYM(all_reduce, "ncclAllReduce")
+  BSIG_SYM(broadcast, "ncclBroadcast")
+  BSIG_SYM(error_string, "ncclGetErrorString")
+#undef BSIG_SYM
+  g_rccl.ok = true;
+}
+
+int need_rccl() {
+  std::call_once(g_once, load_rccl);
+  if (!g_rccl.ok) {
+    bsig::set_error("RCCL is not available: %s", g_load_error);
+    return BSIG_EUNSUPPORTED;
+  }
+  return BSIG_OK;
+}
+
+#define BSIG_NCCL(call)                                                          \
+  do {                                                                           \
+    ncclResult_t r__ = (call);                                                   \
+    if (r__ != ncclSuccess) {                                                    \
+      ::bsig::set_error("%s: %s", #call, g_rccl.error_string(r__));              \
+      return BSIG_ELAUNCH;                                                       \
+    }                                                                            \
+  } while (0)
+
+}  // namespace
+
+struct bsig_comm {
+  ncclComm_t nccl = nullptr;       // RCCL communicator, or
+  bsig_exchange_fn external = nullptr;   // a caller-supplied exchange (tests, other transports)
+  void* external_ctx = nullptr;
+  int world = 1, rank = 0, device = -1;
+};
+
+static_assert(sizeof(ncclUniqueId) == BSIG_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+
+extern "C" int bsig_comm_unique_id(void* id_out) {
+  BSIG_REQUIRE(id_out, "comm_unique_id: null");
+  BSIG_TRY(need_rccl());
+  ncclUniqueId id;
+  BSIG_NCCL(g_rccl.get_unique_id(&id));
+  std::memcpy(id_out, &id, sizeof(id));
+  return BSIG_OK;
+}
+
+extern "C" int bsig_comm_init(const void* unique_id, int world, int rank, int device,
+                              bsig_comm** comm) {
+  BSIG_REQUIRE(comm, "comm_init: null handle");
+  *comm = nullptr;
+  BSIG_REQUIRE(unique_id, "comm_init: null unique id");
+  BSIG_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_init: rank %d of world %d", rank,
+               world);
+  int n_dev = 0;
+  BSIG_HIP(hipGetDeviceCount(&n_dev));
+  BSIG_REQUIRE(device >= 0 && device < n_dev, "comm_init: device %d of %d", device, n_dev);
+  BSIG_TRY(need_rccl());
+  bsig_comm* c = new (std::nothrow) bsig_comm();
+  BSIG_REQUIRE(c, "comm_init: out of memory");
+  c->world = world; c->rank = rank; c->device = device;
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof(id));
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  hipError_t e = hipSetDevice(device);
+  ncclResult_t r = e == hipSuccess ? g_rccl.comm_init_rank(&c->nccl, world, id, rank)
+                                   : ncclUnhandledCudaError;
+  (void)hipSetDevice(prev);
+  if (r != ncclSuccess) {
+    bsig::set_error("ncclCommInitRank(world %d, rank %d, device %d): %s", world, rank, device,
+                    e == hipSuccess ? g_rccl.error_string(r) : hipGetErrorString(e));
+    delete c;
+    return BSIG_ELAUNCH;
+  }
+  *comm = c;
+  return BSIG_OK;
+}
+
+extern "C" int bsig_comm_init_external(int world, int rank, bsig_exchange_fn exchange, void* ctx,
+                                       bsig_comm** comm) {
+  BSIG_REQUIRE(comm, "comm_init_external: null handle");
+  *comm = nullptr;
+  BSIG_REQUIRE(exchange, "comm_init_external: null exchange function");
+  BSIG_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_init_external: rank %d of world %d",
+               rank, world);
+  bsig_comm* c = new (std::nothrow) bsig_comm();
+  BSIG_REQUIRE(c, "comm_init_external: out of memory");
+  c->world = world; c->rank = rank; c->external = exchange; c->external_ctx = ctx;
+  *comm = c;
+  return BSIG_OK;
+}
+
+extern "C" int bsig_comm_world(const bsig_comm* c) { return c ? c->world : 0; }
+extern "C" int bsig_comm_rank(const bsig_comm* c) { return c ? c->rank : -1; }
+
+extern "C" int bsig_comm_allreduce(bsig_comm* c, float* buf, int64_t n, bsig_stream_t stream) {
+  BSIG_REQUIRE(c && buf && n >= 0, "comm_allreduce: bad args");
+  if (n == 0) return BSIG_OK;
+  if (c->external) {
+    const int rc = c->external(c->external_ctx, BSIG_EXCHANGE_SUM, buf, n, 0, stream);
+    if (rc != 0) { bsig::set_error("comm_allreduce: external exchange failed (%d)", rc); return BSIG_ELAUNCH; }
+    return BSIG_OK;
+  }
+  BSIG_NCCL(g_rccl.all_reduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->nccl,
+                              bsig::as_stream(stream)));
+  return BSIG_OK;
+}
+
+extern "C" int bsig_comm_broadcast(bsig_comm* c, float* buf, int64_t n, int root,
+                                   bsig_stream_t stream) {
+  BSIG_REQUIRE(c && buf && n >= 0 && root >= 0 && root < c->world, "comm_broadcast: bad args");
+  if (n == 0) return BSIG_OK;
+  if (c->external) {
+    const int rc = c->external(c->external_ctx, BSIG_EXCHANGE_BROADCAST, buf, n, root, stream);
+    if (rc != 0) { bsig::set_error("comm_broadcast: external exchange failed (%d)", rc); return BSIG_ELAUNCH; }
+    return BSIG_OK;
+  }
+  BSIG_NCCL(g_rccl.broadcast(buf, buf, (size_t)n, ncclFloat32, root, c->nccl,
+                             bsig::as_stream(stream)));
+  return BSIG_OK;
+}
+
+extern "C" void bsig_comm_destroy(bsig_comm* c) {
+  if (!c) return;
+  if (c->nccl && g_rccl.ok) (void)g_rccl.comm_destroy(c->nccl);
+  delete c;
+}

@@ -935,5 +935,77 @@ extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t s
   return BSIG_OK;
 }
 
+namespace bsig {
+// [train_loss at the logging points | test_loss | flag word] of one call, for its single read-back
+__global__ void pack_logs_kernel(const float* train_loss, const float* test_loss,
+                                 const int32_t* state, int n_updates, int n_evals, float* out) {
+  const int every = n_updates / 5 > 1 ? n_updates / 5 : 1;        // mdnn.py:235
+  if (threadIdx.x == 0) {
+    int e = 0;
+    for (int it = 0; it < n_updates; ++it)
+      if (it % every == 0 || it + 1 == n_updates) { out[e] = train_loss[it]; ++e; }
+    out[2 * n_evals] = (float)state[ST_NONFINITE];
+  }
+  for (int i = threadIdx.x; i < n_evals; i += blockDim.x) out[n_evals + i] = test_loss[i];
+}
+}  // namespace bsig
+
+extern "C" int bsig_fit_pack_logs(bsig_fit_plan* p, int64_t n_updates, float* out,
+                                  bsig_stream_t stream) {
+  BSIG_REQUIRE(p && p->bound && out, "fit_pack_logs: plan not bound / null");
+  BSIG_REQUIRE(n_updates >= 0 && n_updates <= p->n_updates, "fit_pack_logs: bad n_updates");
+  hipLaunchKernelGGL(pack_logs_kernel, dim3(1), dim3(64), 0, as_stream(stream), p->buf.train_loss,
+                     p->buf.test_loss, p->buf.state, (int)n_updates, (int)count_evals(n_updates), out);
+  BSIG_CHECK_LAUNCH("pack_logs");
+  return BSIG_OK;
+}
+
+namespace bsig {
+// the data-parallel rank's logs, ready to be summed over the ranks
+__global__ void pack_dp_logs_kernel(const float* train_loss, const float* test_loss,
+                                    const int32_t* state, int n_updates, int n_evals, float n_test,
+                                    float* out) {
+  const int n = n_updates + n_evals + 3;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float v;
+    if (i < n_updates) v = train_loss[i];
+    else if (i < n_updates + n_evals) v = n_test > 0.f ? test_loss[i - n_updates] * n_test : 0.f;
+    else if (i == n_updates + n_evals) v = n_test;
+    else v = (state[ST_NONFINITE] >> (i - n_updates - n_evals - 1)) & 1 ? 1.f : 0.f;
+    out[i] = v;
+  }
+}
+}  // namespace bsig
+
+extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates,
+                               float* reduced_logs, bsig_stream_t stream) {
+  BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_run_dp: plan not bound with SPLIT_ADAM");
+  BSIG_REQUIRE(comm, "fit_run_dp: null communicator");
+  BSIG_REQUIRE(n_updates >= 0 && n_updates <= p->n_updates,
+               "fit_run_dp: n_updates %lld exceeds the plan's %lld", (long long)n_updates,
+               (long long)p->n_updates);
+  BSIG_REQUIRE(p->norm_batch == p->batch * bsig_comm_world(comm),
+               "fit_run_dp: bsig_fit_begin's norm_batch %lld != batch %lld x world %d",
+               (long long)p->norm_batch, (long long)p->batch, bsig_comm_world(comm));
+  if (p->use_graph) BSIG_TRY(ensure_graphs(p));
+  const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
+  int64_t n_evals = 0;
+  for (int64_t it = 0; it < n_updates; ++it) {
+    BSIG_TRY(bsig_fit_grad(p, stream));
+    BSIG_TRY(bsig_comm_allreduce(comm, p->buf.grads, p->L.total, stream));
+    BSIG_TRY(bsig_fit_apply(p, stream));
+    if (it % every == 0 || it + 1 == n_updates) { BSIG_TRY(bsig_fit_eval(p, stream)); ++n_evals; }
+  }
+  BSIG_TRY(bsig_fit_flush(p, stream));
+  if (reduced_logs) {
+    hipLaunchKernelGGL(pack_dp_logs_kernel, dim3(1), dim3(256), 0, as_stream(stream),
+                       p->buf.train_loss, p->buf.test_loss, p->buf.state, (int)n_updates,
+                       (int)n_evals, (float)p->buf.n_test, reduced_logs);
+    BSIG_CHECK_LAUNCH("pack_dp_logs");
+    BSIG_TRY(bsig_comm_allreduce(comm, reduced_logs, n_updates + n_evals + 3, stream));
+  }
+  return BSIG_OK;
+}
+
 // diagnostics (tools/persist_prof.py): phase time stamps of the persistent kernel
 extern "C" void bsig_debug_persist_profile(void* buffer) { persist_set_profile_buffer(buffer); }

@@ -786,7 +786,12 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   BSIG_REQUIRE(!(b.adam_pending && !b.grads), "persistent updates: pending Adam step without gradients");
   BSIG_REQUIRE(!(b.grads && n > 1), "persistent updates: data-parallel launches take one update");
   if (n <= 0 && !b.adam_pending && !b.do_eval) return BSIG_OK;
-  static bool attr_set = false;
+  // the > 64 KB dynamic-LDS attribute is per device (the plan's device is the current one:
+  // the Python mirror enters the model's device around every call)
+  static bool attr_set_dev[64] = {};
+  int attr_dev = 0;
+  BSIG_HIP(hipGetDevice(&attr_dev));
+  bool& attr_set = attr_set_dev[attr_dev & 63];
   if (!attr_set) {
     BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_head_updates_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));

@@ -25,18 +25,42 @@ _ACT_CODES = {nn.Tanh: _lib.ACT_TANH, nn.ReLU: _lib.ACT_RELU,
               nn.Identity: _lib.ACT_IDENTITY}
 
 
+def _on_model_device(fn):
+    """Run a method with the model's GPU as the current HIP device and its torch stream
+    as the launch stream (a model built with device='cuda:1' must not launch on cuda:0)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        flat = getattr(self, '_flat', None)
+        if flat is None or not flat.is_cuda or flat.device.index == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with _lib.on_device(flat.device):
+            return fn(self, *args, **kwargs)
+    return wrapped
+
+
 class PendingLogs:
     """The 6+6 losses and the non-finite flag of one run_training call, still on
     the device; ``result()`` is the call's single host read-back.  BayesSim.fit
     defers it to the end of the chunk loop so the GPU never waits for the host."""
 
-    def __init__(self, packed, n_e, n_test, verbose):
+    def __init__(self, packed, n_e, n_test, verbose, dp=None):
         self.packed, self.n_e, self.n_test, self.verbose = packed, n_e, n_test, verbose
+        self.dp = dp      # (eval_its, n_updates, world): `packed` is bsig_fit_run_dp's reduced_logs
 
     def result(self):
         host = self.packed.cpu().tolist()
         n_e = self.n_e
-        train_list, test_list, bad = host[:n_e], host[n_e:2 * n_e], host[2 * n_e]
+        if self.dp is not None:
+            eval_its, n_updates, world = self.dp
+            train_list = [host[it] / world for it in eval_its]
+            n_test_all = host[n_updates + n_e]
+            test_list = [v / max(n_test_all, 1.0) for v in host[n_updates:n_updates + n_e]]
+            bad = (1 if host[n_updates + n_e + 1] > 0 else 0) | (2 if host[n_updates + n_e + 2] > 0 else 0)
+            self.n_test = int(n_test_all)
+        else:
+            train_list, test_list, bad = host[:n_e], host[n_e:2 * n_e], host[2 * n_e]
         if int(bad) & 2:      # a bounded cross-workgroup poll of the persistent kernel gave up
             raise RuntimeError('persistent update kernel timed out waiting for another workgroup '
                                '(GPU shared or partitioned?); set BSIG_NO_PERSISTENT=1 to use the '
@@ -227,6 +251,7 @@ class MDNN(nn.Module):
         return int(torch.randint(0, 2 ** 62, (1,)).item())
 
     # ----------------------------------------------------------- forward
+    @_on_model_device
     def _head_forward(self, x):
         lib = self._gpu()
         cfg = self._cfg()
@@ -244,6 +269,7 @@ class MDNN(nn.Module):
             ws.numel() * 4, _lib.stream()))
         return cfg, out
 
+    @_on_model_device
     def forward(self, x, noise=None):
         """Reference mdnn.py:89-125 -> (weights[B,K], mu[B,D,K], L_d[B,D,K],
         L[B,L_size,K] | None).  ``noise`` injects the rand_like draw."""
@@ -270,6 +296,7 @@ class MDNN(nn.Module):
         self._fwd_ctx = (weights, x, nz, seed) if torch.is_grad_enabled() else None
         return weights, mu, l_d, low
 
+    @_on_model_device
     def mdn_loss_fn(self, weights, mu, L_d, L, y):
         """Reference mdnn.py:127-178 -> 0-dim loss tensor."""
         lib = self._gpu()
@@ -298,6 +325,7 @@ class MDNN(nn.Module):
             return _FusedNLL.apply(loss[0], self, ctx[1], ys, ctx[2], ctx[3], *self.parameters())
         return loss[0]
 
+    @_on_model_device
     def loss_and_grad(self, x, y, rows=None, noise=None, norm_batch=None, seed=None,
                       grads_out=None):
         """forward + mdn_loss_fn + backward for one minibatch
@@ -330,6 +358,7 @@ class MDNN(nn.Module):
         assert int(flag.item()) == 0
         return loss[0]
 
+    @_on_model_device
     def adam_step(self, t):
         """One torch.optim.Adam step (defaults) over the flat buffers; t is
         the 1-based step number since the optimizer was created."""
@@ -340,15 +369,26 @@ class MDNN(nn.Module):
             1e-8, int(t), _lib.stream()))
 
     # ---------------------------------------------------------- training
-    def enable_data_parallel(self, group=None):
+    def enable_data_parallel(self, group=None, transport=None):
         """Shard run_training's minibatch over the ranks of ``group``: every
         rank keeps a full replica, computes the gradient of its B/R rows and
         the flat gradient buffer is all-reduced (RCCL) before the identical
-        Adam step.  Parameters are broadcast from rank 0."""
+        Adam step.  Parameters are broadcast from rank 0.
+        The exchange is the C ABI's communicator (bsig_comm_*: RCCL, or with
+        ``transport='torch'`` the group's own collectives behind the same entry
+        points) and run_training's update loop is bsig_fit_run_dp."""
         self._dp = _dp.DataParallel(group)
+        if self._flat.is_cuda:
+            with _lib.on_device(self._flat.device):
+                self._dp.init_comm(self._flat.device, transport)
         self._dp.broadcast(self._flat)
+        self._dp_sync_extra()
         return self
 
+    def _dp_sync_extra(self):
+        """Replica state outside the flat parameter buffer (MDRFF: the RFF frequencies)."""
+
+    @_on_model_device
     def run_training(self, x_data, y_data, n_updates, batch_size, test_frac=0.2,
                      ids_table=None, _defer=False, _feats=None):
         """Reference mdnn.py:180-243.  Returns {'train_loss': [...],
@@ -409,9 +449,6 @@ class MDNN(nn.Module):
         every = max(n_updates // 5, 1)
         eval_its = [it for it in range(n_updates)
                     if it % every == 0 or it + 1 == n_updates]
-        eval_key = ('eval_idx', n_updates)
-        if eval_key not in self._bufs:
-            self._bufs[eval_key] = torch.tensor(eval_its, dtype=torch.int64, device=dev)
         train_loss = self._buf('train_loss', n_updates)
         test_loss = self._buf('test_loss', len(eval_its))
         state = self._buf('state', 16, torch.int32)
@@ -454,26 +491,26 @@ class MDNN(nn.Module):
         _lib.check(lib.bsig_fit_begin(self._plan, self._seed(), batch_size * world, st))
         if self._dp is None:
             _lib.check(lib.bsig_fit_run(self._plan, n_updates, st))
+            # single read-back per call: 6+6 losses and the isfinite flag
+            # (a fresh allocation per call -- no kernel: BayesSim.fit reads all chunks' logs at the end)
+            packed = torch.empty(2 * len(eval_its) + 1, dtype=torch.float32, device=dev)
+            _lib.check(lib.bsig_fit_pack_logs(self._plan, n_updates, _lib.ptr(packed), st))
+            pending = PendingLogs(packed, len(eval_its), n_test, type(self).VERBOSE)
         else:
-            eval_set = set(eval_its)
-            _dp.run_updates(
-                n_updates, eval_set,
-                grad=lambda: _lib.check(lib.bsig_fit_grad(self._plan, st)),
-                allreduce=lambda: self._dp.allreduce_sum(self._flat_grad),
-                apply=lambda: _lib.check(lib.bsig_fit_apply(self._plan, st)),
-                evaluate=lambda: _lib.check(lib.bsig_fit_eval(self._plan, st)))
-            _lib.check(lib.bsig_fit_flush(self._plan, st))
-        # single read-back per call: 6+6 losses and the isfinite flag
-        tl = train_loss[:n_updates]
-        te = test_loss[:len(eval_its)]
-        if self._dp is not None:
-            tl, te = self._dp.mean_losses(tl, te, n_test)
-        packed = torch.cat([tl[self._bufs[eval_key]], te, state[2:3].to(torch.float32)])
-        pending = PendingLogs(packed, len(eval_its), n_test, type(self).VERBOSE)
+            # data parallel: grad -> all-reduce -> apply per update, driven from C
+            self._dp._on_gpu = True
+            logs = torch.empty(n_updates + len(eval_its) + 3, dtype=torch.float32, device=dev)
+            _lib.check(lib.bsig_fit_run_dp(self._plan, self._dp.comm, n_updates, _lib.ptr(logs), st))
+            if self._dp._error is not None:
+                err, self._dp._error = self._dp._error, None
+                raise err
+            pending = PendingLogs(logs, len(eval_its), n_test, type(self).VERBOSE,
+                                  dp=(eval_its, n_updates, world))
         return pending if _defer else pending.result()
 
     fit = run_training   # the north-star name for the same call
 
+    @_on_model_device
     def normalize_samples(self, params):
         """Reference mdnn.py:245-248."""
         lib = self._gpu()

@@ -1,9 +1,13 @@
 """Mixture Density NN on Random Fourier Features — mirror of the reference's
 bayes_sim_ig/models/mdrff.py (class MDRFF).  ``forward`` = RFF projection
-(fp32-MFMA GEMM + sincos epilogue) followed by the MDNN heads; in
-``run_training`` the projection runs inside every captured update, on the
-gathered minibatch rows, exactly where the reference computes it
-(mdrff.py:28-30 inside mdnn.py:231)."""
+(fp32-MFMA GEMM + sincos epilogue) followed by the MDNN heads.  The reference
+projects the gathered minibatch inside every update (mdrff.py:28-30 inside
+mdnn.py:231); the features are a pure function of the row, so ``run_training``
+projects every distinct row of the chunk ONCE per call (feature cache,
+csrc/estimator.hip) and ``BayesSim.fit`` projects blocks of chunks in one GEMM --
+bitwise the same features, 12.5x fewer row projections."""
+import torch
+
 from .mdnn import MDNN
 from .rff import RFF
 
@@ -39,3 +43,17 @@ class MDRFF(MDNN):
     def _rff_args(self):
         co = self.rff.coeff()
         return co, co.stride(0), None
+
+    def _dp_sync_extra(self):
+        """Data-parallel replicas must share the feature map: the frequencies come from
+        the global numpy RNG (rff.py:111-120), which ranks may have seeded differently, and
+        are not part of the flat parameter buffer -- rank 0's are broadcast."""
+        rff = self.rff
+        for name in ('freqs', 'sigma', 'offset'):
+            t = getattr(rff, name)
+            if t is None:
+                continue
+            flat = t.to(self._flat.device, torch.float32).contiguous().view(-1).clone()
+            self._dp.broadcast(flat)
+            setattr(rff, name, flat.view(t.shape).to(t.device))
+        rff._coeff = None

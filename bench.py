@@ -265,9 +265,27 @@ def time_update_kernel(pkg, cfg, bsim, device):
         total_ms += sum(a.elapsed_time(b) for a, b in evs)
         launches += len(evs)
     us = total_ms * 1e3 / launches
+    loop_us = None
+    if dp:
+        # the whole data-parallel loop as the fit runs it: bsig_fit_run_dp = per update one
+        # launch + the all-reduce of the flat gradient buffer (+ the evaluations), from C
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        L.check(lib.bsig_fit_begin(plan, 99, batch * m._dp.world, st))
+        L.check(lib.bsig_fit_run_dp(plan, m._dp.comm, n_updates, None, st))
+        e0.record(stream)
+        for rep in range(reps):
+            L.check(lib.bsig_fit_begin(plan, 100 + rep, batch * m._dp.world, st))
+            L.check(lib.bsig_fit_run_dp(plan, m._dp.comm, n_updates, None, st))
+        e1.record(stream)
+        torch.cuda.synchronize()
+        loop_us = e0.elapsed_time(e1) * 1e3 / (reps * n_updates)
     nh = cfg['k'] * (1 + 2 * cfg['d'])
     if cfg['model'] != 'MDRFF':
-        return mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp, n_evals, n_test)
+        out = mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp, n_evals, n_test)
+        if loop_us is not None:
+            out['us_per_update_with_exchange'] = loop_us
+        return out
     f_in = m.rff.m_feat * 2
     per_visit = 2.0 * 2.0 * f_in * nh                 # SURVEY 8(d) K6+K7, MDRFF heads: fwd + dW
     flops = per_visit * batch * (float(n_updates) / len(runs))
@@ -287,6 +305,7 @@ def time_update_kernel(pkg, cfg, bsim, device):
             'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
             'traffic': traffic, 'traffic_source': tsrc, 'avg_us': us,
             'us_per_update': us * len(runs) / n_updates,
+            'us_per_update_with_exchange': loop_us,
             'algorithmic': '2*2*F*Nh = %.3e flop per row visit x %d rows x %.1f updates%s = %.3e flop '
                            'per launch' % (per_visit, batch, float(n_updates) / len(runs),
                                            '' if dp else ' + 2*F*Nh x %d rows x %d evaluations'
@@ -436,6 +455,23 @@ def scaled_batch(pkg, cfg, theta, states, actions, device, batch=8192, epochs=10
 T0 = time.perf_counter()
 
 
+def launch_ranks(n):
+    """Run this script as n ranks (one per GPU) under torch.distributed.run on
+    127.0.0.1, pass rank 0's JSON line through, return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max((os.cpu_count() or n) // n, 1)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -463,9 +499,11 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start one rank per GPU ourselves.  Nothing in this
+        # process has touched the GPU yet (children are started, not exec'ed into).
+        raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
         args.gpus = world
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import bayes_sim_ig_amd as pkg

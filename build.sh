@@ -13,10 +13,12 @@ for f in summarizers gemm_f32 gemm_tile_64 gemm_tile_128 gemm_tile_128x32 gemm_t
     pids+=($!)
   fi
 done
-if [ ! -f "$OUT/obj/api.o" ] || [ "$SRC/api.cpp" -nt "$OUT/obj/api.o" ]; then
-  hipcc $FLAGS -x hip -c "$SRC/api.cpp" -o "$OUT/obj/api.o" &
-  pids+=($!)
-fi
+for f in api comm; do
+  if [ ! -f "$OUT/obj/$f.o" ] || [ "$SRC/$f.cpp" -nt "$OUT/obj/$f.o" ] || [ include/bsig.h -nt "$OUT/obj/$f.o" ] || [ "$SRC/common.h" -nt "$OUT/obj/$f.o" ]; then
+    hipcc $FLAGS -x hip -c "$SRC/$f.cpp" -o "$OUT/obj/$f.o" &
+    pids+=($!)
+  fi
+done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbsig_hip.so" "$OUT"/obj/*.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbsig_hip.so" "$OUT"/obj/*.o -ldl
 echo "built $OUT/libbsig_hip.so"

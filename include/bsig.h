@@ -274,6 +274,11 @@ int bsig_fit_run(bsig_fit_plan* plan, int64_t n_updates, bsig_stream_t stream);
  * n_updates replays of the update graph.  bsig_fit_run = runs of these between
  * the held-out evaluations. */
 int bsig_fit_updates(bsig_fit_plan* plan, int64_t n_updates, bsig_stream_t stream);
+/* The call's logs for ONE read-back: out[2*E + 1] (device) = train_loss at the E
+ * logging points of mdnn.py:235-242 | test_loss[E] | the state block's flag word
+ * (bit 0 non-finite, bit 1 poll time-out) as a float. */
+int bsig_fit_pack_logs(bsig_fit_plan* plan, int64_t n_updates, float* out,
+                       bsig_stream_t stream);
 /* Data-parallel pieces (BSIG_FIT_SPLIT_ADAM; mdnn.py:229-233 with the exchange
  * the reference does not have between loss.backward() and optimizer.step()):
  * bsig_fit_grad = forward + NLL + backward of one minibatch into `grads`
@@ -290,6 +295,54 @@ int bsig_fit_flush(bsig_fit_plan* plan, bsig_stream_t stream);
  * per-phase kernels (diagnostics / tests). */
 int bsig_fit_is_persistent(const bsig_fit_plan* plan);
 int bsig_fit_eval(bsig_fit_plan* plan, bsig_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* Data-parallel exchange (no counterpart in the reference, which is   */
+/* single-device; the site is between loss.backward() and              */
+/* optimizer.step(), mdnn.py:233-234): every rank holds a replica and  */
+/* a shard of the pairs; the flat fp32 gradient buffer is summed over  */
+/* the ranks once per update, RCCL over xGMI, on the fit's stream.     */
+/* ------------------------------------------------------------------ */
+typedef struct bsig_comm bsig_comm;
+#define BSIG_COMM_ID_BYTES 128
+/* Rank 0: fill `id_out` (HOST, BSIG_COMM_ID_BYTES) with a fresh rendezvous id
+ * (ncclGetUniqueId); the caller hands the bytes to every rank by its own means. */
+int bsig_comm_unique_id(void* id_out);
+/* Collective over all `world` ranks: join the communicator `unique_id` names as
+ * `rank`, on HIP device `device` (ncclCommInitRank).  BSIG_EUNSUPPORTED when no
+ * RCCL can be loaded. */
+int bsig_comm_init(const void* unique_id, int world, int rank, int device,
+                   bsig_comm** comm);
+/* A communicator over a caller-supplied exchange instead of RCCL (another
+ * transport, or tests of the multi-rank path on one GPU, where RCCL refuses two
+ * ranks per device).  `exchange(ctx, op, buf, n, root, stream)` must leave the
+ * sum over ranks (op BSIG_EXCHANGE_SUM) / root's values (BSIG_EXCHANGE_BROADCAST)
+ * in the DEVICE buffer `buf[n]`, ordered after the work already enqueued on
+ * `stream` and before anything enqueued later; it returns 0 on success. */
+enum { BSIG_EXCHANGE_SUM = 0, BSIG_EXCHANGE_BROADCAST = 1 };
+typedef int (*bsig_exchange_fn)(void* ctx, int op, float* buf, int64_t n, int root,
+                                bsig_stream_t stream);
+int bsig_comm_init_external(int world, int rank, bsig_exchange_fn exchange, void* ctx,
+                            bsig_comm** comm);
+int bsig_comm_world(const bsig_comm* comm);
+int bsig_comm_rank(const bsig_comm* comm);
+/* buf[n] (device, fp32) <- sum over ranks, in place, asynchronous on `stream`. */
+int bsig_comm_allreduce(bsig_comm* comm, float* buf, int64_t n, bsig_stream_t stream);
+/* buf[n] <- rank `root`'s buf (replica initialisation). */
+int bsig_comm_broadcast(bsig_comm* comm, float* buf, int64_t n, int root,
+                        bsig_stream_t stream);
+void bsig_comm_destroy(bsig_comm* comm);
+
+/* run_training's loop for a data-parallel rank (plan bound with
+ * BSIG_FIT_SPLIT_ADAM, after bsig_fit_begin with norm_batch = batch * world):
+ * per update bsig_fit_grad -> bsig_comm_allreduce(grads) -> bsig_fit_apply, the
+ * held-out evaluations at the reference's logging points (mdnn.py:235-242),
+ * bsig_fit_flush at the end -- all enqueued from here, no host work in between.
+ * `reduced_logs` (device, n_updates + n_evals + 3 floats, may be NULL) receives,
+ * summed over the ranks: train_loss[n_updates] | test_loss[e] * n_test |
+ * n_test | #ranks with the non-finite flag | #ranks with a poll time-out. */
+int bsig_fit_run_dp(bsig_fit_plan* plan, bsig_comm* comm, int64_t n_updates,
+                    float* reduced_logs, bsig_stream_t stream);
 
 /* Diagnostics: device buffer of [256][8][16] int64 wall-clock stamps filled by the
  * persistent update kernel (first 8 updates of every later launch); NULL = off.

@@ -120,3 +120,58 @@ def test_fit_plan_argument_errors(lib):
     need = lib.bsig_fit_workspace_bytes(plan)
     assert need > (100 * 100 + 6 * 200) * 4096 * 4
     lib.bsig_fit_destroy(plan)
+
+
+def test_comm_argument_errors_and_external_exchange(lib):
+    """bsig_comm_*: validation before any RCCL / HIP call, and a communicator over a
+    caller-supplied exchange moving HOST buffers (the entry points only pass pointers on)."""
+    handle = C.c_void_p()
+    raw = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+    assert lib.bsig_comm_unique_id(None) == _lib.BSIG_EINVAL
+    rc = lib.bsig_comm_init(None, 2, 0, 0, C.byref(handle))
+    assert rc == _lib.BSIG_EINVAL and 'unique id' in err(lib)
+    rc = lib.bsig_comm_init(raw, 2, 2, 0, C.byref(handle))
+    assert rc == _lib.BSIG_EINVAL and 'rank 2 of world 2' in err(lib)
+    rc = lib.bsig_comm_init(raw, 0, 0, 0, C.byref(handle))
+    assert rc == _lib.BSIG_EINVAL
+    assert lib.bsig_comm_init(raw, 1, 0, 0, None) == _lib.BSIG_EINVAL
+    rc = lib.bsig_comm_init_external(2, 0, None, None, C.byref(handle))
+    assert rc == _lib.BSIG_EINVAL and 'exchange' in err(lib)
+    assert lib.bsig_comm_allreduce(None, FAKE, 4, None) == _lib.BSIG_EINVAL
+    assert lib.bsig_comm_world(None) == 0 and lib.bsig_comm_rank(None) == -1
+    lib.bsig_comm_destroy(None)                              # no-op
+    assert lib.bsig_fit_run_dp(None, None, 1, None, None) == _lib.BSIG_EINVAL
+
+    calls = []
+
+    def exchange(ctx, op, buf, n, root, stream):
+        arr = (C.c_float * n).from_address(buf)
+        calls.append((op, n, root))
+        if op == _lib.EXCHANGE_SUM:
+            for i in range(n):
+                arr[i] *= 3.0                               # "three identical ranks"
+        return 0 if n != 7 else 5
+
+    fn = _lib.EXCHANGE_FN(exchange)
+    assert lib.bsig_comm_init_external(3, 1, C.cast(fn, C.c_void_p), None, C.byref(handle)) == 0
+    assert lib.bsig_comm_world(handle) == 3 and lib.bsig_comm_rank(handle) == 1
+    data = (C.c_float * 4)(1.0, 2.0, 3.0, 4.0)
+    assert lib.bsig_comm_allreduce(handle, data, 4, None) == 0
+    assert list(data) == [3.0, 6.0, 9.0, 12.0]
+    assert lib.bsig_comm_broadcast(handle, data, 4, 2, None) == 0
+    assert lib.bsig_comm_broadcast(handle, data, 4, 3, None) == _lib.BSIG_EINVAL   # root outside the group
+    assert lib.bsig_comm_allreduce(handle, data, 0, None) == 0                    # empty: no call
+    assert calls == [(_lib.EXCHANGE_SUM, 4, 0), (_lib.EXCHANGE_BROADCAST, 4, 2)]
+    seven = (C.c_float * 7)()
+    rc = lib.bsig_comm_allreduce(handle, seven, 7, None)                          # exchange reports failure
+    assert rc == _lib.BSIG_ELAUNCH and 'external exchange failed (5)' in err(lib)
+    lib.bsig_comm_destroy(handle)
+
+
+def test_comm_unique_ids_are_fresh(lib):
+    a, b = (C.c_ubyte * _lib.COMM_ID_BYTES)(), (C.c_ubyte * _lib.COMM_ID_BYTES)()
+    rc = lib.bsig_comm_unique_id(a)
+    if rc == _lib.BSIG_EUNSUPPORTED:
+        pytest.skip('no RCCL on this host: ' + err(lib))
+    assert rc == 0 and lib.bsig_comm_unique_id(b) == 0
+    assert bytes(a) != bytes(b) and any(bytes(a))

@@ -1,7 +1,8 @@
 """Data-parallel orchestration (bayes_sim_ig_amd/dp.py) on CPU with the gloo
-backend, world_size 2: the gradient exchange, loss reduction and shard bounds
-are exercised with the oracle as the local gradient engine (the HIP engine
-needs a GPU).  Property: R ranks with B/R rows each == one rank with the B
+backend, world_size 2: the gradient exchange (through the C ABI's communicator,
+bsig_comm_allreduce / _broadcast over a gloo-backed exchange, host buffers), loss
+reduction and shard bounds are exercised with the oracle as the local gradient
+engine (the HIP engine needs a GPU).  Property: R ranks with B/R rows each == one rank with the B
 rows (same weights after every update, up to fp32 summation order)."""
 import os
 
@@ -34,7 +35,8 @@ def _worker(rank, world, port, out):
     model = oest.OracleMDNN(**kw)
     params = [p for p in model.parameters()]
     flat = torch.cat([p.detach().reshape(-1) for p in params])
-    group = dp.DataParallel()
+    group = dp.DataParallel().init_comm()     # gloo group: the group's collectives behind bsig_comm_*
+    assert group.transport == 'torch' and group.comm is not None
     group.broadcast(flat)
     off = 0
     with torch.no_grad():
