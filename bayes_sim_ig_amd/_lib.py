@@ -84,6 +84,7 @@ _PROTOS = {
                                      vp, i64, vp, i64, i64, vp, u64, u64, vp, vp,
                                      vp, vp, sz, vp]),
     'bsig_fit_create': (C.c_int, [C.POINTER(MdnCfg), i64, i64, i64, C.POINTER(vp)]),
+    'bsig_fit_create_sized': (C.c_int, [C.POINTER(MdnCfg), i64, i64, i64, i64, C.POINTER(vp)]),
     'bsig_fit_destroy': (None, [vp]),
     'bsig_fit_workspace_bytes': (sz, [vp]),
     'bsig_fit_bind': (C.c_int, [vp, C.POINTER(FitBuffers), C.c_int]),

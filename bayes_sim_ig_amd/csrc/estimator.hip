@@ -349,7 +349,8 @@ struct bsig_fit_plan {
   bool hoist;                  // RFF projection once per run_training call
   bool feat_unique;            // ... of the distinct training rows (else of every gathered minibatch row)
   bool feats_preloaded;        // ... already handed over by the caller (bsig_fit_set_features)
-  int64_t feat_rows;           // n_updates*batch + max_test
+  int64_t feat_rows;           // rows of the hoisted feature block (+ max_test)
+  int64_t max_train;           // caller's bound on n_train (0: none)
   bsig_fit_buffers buf;
   bool bound;
   int64_t norm_batch;
@@ -687,8 +688,14 @@ extern "C" int bsig_mdn_loss_grad(const bsig_mdn_cfg* cfg, const float* params,
 
 extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t max_test_rows,
                                int64_t n_updates, bsig_fit_plan** plan) {
-  BSIG_REQUIRE(cfg && plan && batch >= 1 && max_test_rows >= 0 && n_updates >= 0,
-               "fit_create: bad args");
+  return bsig_fit_create_sized(cfg, batch, 0, max_test_rows, n_updates, plan);
+}
+
+extern "C" int bsig_fit_create_sized(const bsig_mdn_cfg* cfg, int64_t batch,
+                                     int64_t max_train_rows, int64_t max_test_rows,
+                                     int64_t n_updates, bsig_fit_plan** plan) {
+  BSIG_REQUIRE(cfg && plan && batch >= 1 && max_train_rows >= 0 && max_test_rows >= 0 &&
+               n_updates >= 0, "fit_create: bad args");
   bsig_fit_plan* p = new (std::nothrow) bsig_fit_plan();
   BSIG_REQUIRE(p, "fit_create: out of memory");
   std::memset(p, 0, sizeof(*p));
@@ -701,7 +708,11 @@ extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t m
   carve(cfg, p->L, batch, nullptr, &s); p->train_ws_bytes = s.total_bytes;
   carve(cfg, p->L, std::max<int64_t>(max_test_rows, 1), nullptr, &s);
   p->test_ws_bytes = s.total_bytes;
-  p->feat_rows = n_updates * batch + max_test_rows;
+  // MDRFF feature block: one row per gathered minibatch row, or -- when the caller bounds the
+  // training rows and they are fewer -- one per distinct training row (feature cache)
+  p->max_train = max_train_rows;
+  p->feat_rows = (max_train_rows > 0 ? std::min(n_updates * batch, max_train_rows)
+                                     : n_updates * batch) + max_test_rows;
   const size_t feats = (size_t)p->feat_rows * (size_t)std::max(cfg->rff_feats, 0) * sizeof(float);
   const char* no_hoist = getenv("BSIG_NO_RFF_HOIST");
   p->hoist = cfg->rff_feats > 0 && n_updates > 0 && feats <= ((size_t)4 << 30) &&
@@ -720,7 +731,7 @@ extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t m
     p->feats_bytes = round_up<size_t>(feats, 256);
     const int64_t mf = cfg->rff_cos_only ? cfg->rff_feats : cfg->rff_feats / 2;
     p->big_gemm_ws_bytes = round_up<size_t>(
-        std::max(bsig_gemm_workspace_bytes(n_updates * batch, mf, cfg->input_dim),
+        std::max(bsig_gemm_workspace_bytes(p->feat_rows - max_test_rows, mf, cfg->input_dim),
                  bsig_gemm_workspace_bytes(std::max<int64_t>(max_test_rows, 1), mf,
                                            cfg->input_dim)) + 256, 256);
   }
@@ -746,6 +757,9 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
                b->test_loss, "fit_bind: null buffer");
   BSIG_REQUIRE(b->workspace_bytes >= plan_ws_bytes(p), "fit_bind: workspace %zu < %zu",
                b->workspace_bytes, plan_ws_bytes(p));
+  BSIG_REQUIRE(!(p->max_train > 0 && b->n_train > p->max_train),
+               "fit_bind: %lld training rows exceed the %lld the plan was sized for",
+               (long long)b->n_train, (long long)p->max_train);
   BSIG_REQUIRE(b->n_train >= 1 && b->n_test >= 0 && b->n_test <= std::max<int64_t>(p->max_test, 0),
                "fit_bind: n_train=%lld n_test=%lld (max %lld)", (long long)b->n_train,
                (long long)b->n_test, (long long)p->max_test);
@@ -761,6 +775,12 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
     const char* no_cache = getenv("BSIG_NO_FEAT_CACHE");
     p->feat_unique = p->hoist && b->n_train <= p->n_updates * p->batch &&
                      !(no_cache && no_cache[0] == '1');
+    if (p->hoist && !p->feat_unique && p->feat_rows - p->max_test < p->n_updates * p->batch) {
+      p->bound = false;
+      set_error("fit_bind: %lld training rows exceed the %lld the plan was sized for",
+                (long long)b->n_train, (long long)p->max_train);
+      return BSIG_EINVAL;
+    }
     p->bound = true;
     p->use_graph = graph;
     p->split_adam = split;

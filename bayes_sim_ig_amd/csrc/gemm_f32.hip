@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
   }
 }
 
-enum { TILE_64 = 0, TILE_128 = 1, TILE_128x32 = 2, TILE_128x64 = 3 };
+enum { TILE_64 = 0, TILE_128 = 1, TILE_128x32 = 2, TILE_128x64 = 3, TILE_128x96 = 4,
+       TILE_96x128 = 5, N_TILES = 6 };
+static const int kTileM[N_TILES] = {64, 128, 128, 128, 128, 96};
+static const int kTileN[N_TILES] = {64, 128, 32, 64, 96, 128};
 struct GemmPlan { int tile; int splits; int k_chunk; };
 
 static int env_int(const char* name, int dflt) {
@@ -69,8 +72,45 @@ static int env_int(const char* name, int dflt) {
 // Tile / split-K choice.  Large problems: 128x128 tiles, no split.  Minibatch
 // sized M (<= 128 rows): 128x32 tiles so the big operand (weights / RFF
 // coefficients) is streamed exactly once, split-K until ~4 workgroups per CU.
+// Large-minibatch shapes (the scaled-batch fit: thousands of rows per update, or a
+// contraction over thousands of rows): pick the tile with the least padded area -- a
+// head of 260 outputs on 128-wide tiles wastes a third of every block -- and split K
+// until there are ~3 workgroups per CU: one 256-thread workgroup per CU hides neither
+// the global nor the LDS latency (8192 x 260 x 4096 ran at 34 TFLOP/s on 192 unsplit
+// 128 x 128 tiles).
+static bool plan_gemm_large(int64_t m, int64_t n, int64_t k, size_t ws_bytes, GemmPlan* pl) {
+  if (!((m >= 4096 || k >= 4096) && m * n >= ((int64_t)1 << 20) && k >= 1024 && m > 128)) return false;
+  static const int cand[] = {TILE_128, TILE_128x96, TILE_96x128, TILE_128x64, TILE_64};
+  static const double cost[] = {1.00, 1.04, 1.04, 1.15, 1.40};   // per-flop cost of the tile shape
+  double best = 0.0;
+  int best_t = -1;
+  int64_t best_tiles = 0;
+  for (int i = 0; i < 5; ++i) {
+    const int t = cand[i];
+    const int64_t tm = ceil_div<int64_t>(m, kTileM[t]), tn = ceil_div<int64_t>(n, kTileN[t]);
+    const double padded = (double)(tm * kTileM[t]) * (double)(tn * kTileN[t]) * cost[i];
+    if (best_t < 0 || padded < best) { best = padded; best_t = t; best_tiles = tm * tn; }
+  }
+  int64_t splits = 1;
+  if (best_tiles < 640) {
+    splits = ceil_div<int64_t>(768, best_tiles);
+    splits = std::min<int64_t>(splits, std::max<int64_t>(k / (8 * BK), 1));
+    splits = std::min<int64_t>(splits, 32);
+  }
+  const int64_t max_by_ws = (int64_t)(ws_bytes / (sizeof(float) * (size_t)(m * n)));
+  splits = std::max<int64_t>(std::min(splits, max_by_ws), 1);
+  const int64_t chunk = round_up<int64_t>(ceil_div<int64_t>(k, splits), BK);
+  pl->tile = best_t;
+  pl->splits = (int)ceil_div<int64_t>(k, chunk);
+  pl->k_chunk = (int)chunk;
+  return true;
+}
+
 static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
   GemmPlan pl;
+  if (env_int("BSIG_GEMM_TILE", -1) < 0 && env_int("BSIG_GEMM_SPLITS", 0) <= 0 &&
+      env_int("BSIG_GEMM_NO_LARGE_PLAN", 0) == 0 && plan_gemm_large(m, n, k, ws_bytes, &pl))
+    return pl;
   const int64_t t128 = ceil_div<int64_t>(m, 128) * ceil_div<int64_t>(n, 128);
   int64_t tiles, target;
   const int64_t t12864 = ceil_div<int64_t>(m, 128) * ceil_div<int64_t>(n, 64);
@@ -88,9 +128,7 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
   const int forced_tile = env_int("BSIG_GEMM_TILE", -1);
   if (forced_tile >= 0) {
     pl.tile = forced_tile;
-    const int bm = forced_tile == TILE_64 ? 64 : 128;
-    const int bn = forced_tile == TILE_64 || forced_tile == TILE_128x64 ? 64
-                   : (forced_tile == TILE_128 ? 128 : 32);
+    const int bm = kTileM[forced_tile % N_TILES], bn = kTileN[forced_tile % N_TILES];
     tiles = ceil_div<int64_t>(m, bm) * ceil_div<int64_t>(n, bn);
   }
   int64_t splits = 1;
@@ -148,6 +186,10 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     rc = launch_tile_128x32(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else if (pl.tile == TILE_128x64)
     rc = launch_tile_128x64(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
+  else if (pl.tile == TILE_128x96)
+    rc = launch_tile_128x96(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
+  else if (pl.tile == TILE_96x128)
+    rc = launch_tile_96x128(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else
     rc = launch_tile_64(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   if (rc != BSIG_OK) return rc;
@@ -159,8 +201,7 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     BSIG_CHECK_LAUNCH("gemm_reduce");
     if (n_expsum && p.expsum) *n_expsum = blocks;
   } else if (n_expsum && p.expsum) {
-    const int bm = pl.tile == TILE_64 ? 64 : 128;
-    const int bn = pl.tile == TILE_64 || pl.tile == TILE_128x64 ? 64 : (pl.tile == TILE_128 ? 128 : 32);
+    const int bm = kTileM[pl.tile], bn = kTileN[pl.tile];
     *n_expsum = ceil_div(p.m, bm) * ceil_div(p.n, bn);
   }
   return BSIG_OK;

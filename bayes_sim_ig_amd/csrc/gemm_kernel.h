@@ -415,9 +415,14 @@ struct TileLoader {
           if (gk + v >= kend) r[it][v] = 0.f;
     } else {
       constexpr int per_k = ROWS / VEC;
-      const int cc = (tid % per_k) * VEC;
-      const int gr = row0 + cc;
-      const int grc = (VEC == 4) ? min(gr, (int)ld - 4) : min(gr, nrows - 1);
+      // (96-row tiles: per_k = 24 does not divide the thread count, the column of an item
+      // then depends on the item)
+      constexpr bool kSameCol = NT % per_k == 0;
+      auto col_of = [&](int it) {
+        const int gr = row0 + ((kSameCol ? tid : tid + it * NT) % per_k) * VEC;
+        return (VEC == 4) ? min(gr, (int)ld - 4) : min(gr, nrows - 1);
+      };
+      const int grc0 = col_of(0);
       int krow[kItems];
 #pragma unroll
       for (int it = 0; it < kItems; ++it) {
@@ -426,7 +431,7 @@ struct TileLoader {
       }
 #pragma unroll
       for (int it = 0; it < kItems; ++it) {
-        const float* src = g + (int64_t)krow[it] * ld + grc;
+        const float* src = g + (int64_t)krow[it] * ld + (kSameCol ? grc0 : col_of(it));
         if constexpr (VEC == 4) {
           const float4 q = *reinterpret_cast<const float4*>(src);
           r[it][0] = q.x; r[it][1] = q.y; r[it][2] = q.z; r[it][3] = q.w;
@@ -637,10 +642,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   }
   BSIG_TILE_EPILOGUE(0, 0)
   BSIG_TILE_EPILOGUE(0, 1)
+  BSIG_TILE_EPILOGUE(0, 2)
   BSIG_TILE_EPILOGUE(1, 0)
   BSIG_TILE_EPILOGUE(1, 1)
+  BSIG_TILE_EPILOGUE(1, 2)
+  BSIG_TILE_EPILOGUE(2, 0)
+  BSIG_TILE_EPILOGUE(2, 1)
+  BSIG_TILE_EPILOGUE(2, 2)
 #undef BSIG_TILE_EPILOGUE
-  static_assert(TM <= 2 && TN <= 2, "extend the tile enumeration");
+  static_assert(TM <= 3 && TN <= 3, "extend the tile enumeration");
   if (p.expsum && p.splits == 1) {   // one partial per workgroup, fixed order
     const float s = block_sum(exp_acc, smem);
     if (tid == 0) p.expsum[blockIdx.y * gridDim.x + blockIdx.x] = s;
@@ -678,5 +688,7 @@ int launch_tile_64(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, 
 int launch_tile_128(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
 int launch_tile_128x32(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
 int launch_tile_128x64(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
+int launch_tile_128x96(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
+int launch_tile_96x128(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
 
 }  // namespace bsig

@@ -454,15 +454,16 @@ class MDNN(nn.Module):
         state = self._buf('state', 16, torch.int32)
         # plan (graphs) keyed by everything baked into the captured kernels
         key = (batch_size, max(n_test, self._bufs.get('cap_test', 0)), n_updates,
-               cfg.head.eps_noise, cfg.lr, cfg.head.min_weight, cfg.head.ll_limit)
+               cfg.head.eps_noise, cfg.lr, cfg.head.min_weight, cfg.head.ll_limit,
+               max(n_train, self._bufs.get('cap_train', 0)))
         if self._plan is None or self._plan_key != key:
             if self._plan:
                 lib.bsig_fit_destroy(self._plan)
             handle = C.c_void_p()
-            _lib.check(lib.bsig_fit_create(C.byref(cfg), batch_size, key[1], n_updates,
-                                           C.byref(handle)))
+            _lib.check(lib.bsig_fit_create_sized(C.byref(cfg), batch_size, key[7], key[1],
+                                                 n_updates, C.byref(handle)))
             self._plan, self._plan_key = handle, key
-            self._bufs['cap_test'] = key[1]
+            self._bufs['cap_test'], self._bufs['cap_train'] = key[1], key[7]
         ws = self._buf('fit_ws', int(lib.bsig_fit_workspace_bytes(self._plan)) // 4 + 1)
         coeff, ldc, off = self._rff_args()
         fb = _lib.FitBuffers()

@@ -219,6 +219,27 @@ def _event_time(fn, reps, warm=5):
     return start.elapsed_time(stop) * 1e3 / reps
 
 
+DP_LOOP_US = {}
+
+
+def time_dp_loop(pkg, bsim):
+    """COLLECTIVE (every rank calls it): the data-parallel update loop as the fit runs it,
+    bsig_fit_run_dp = per update one launch + the all-reduce of the flat gradient buffer
+    (+ the held-out evaluations), enqueued from C; HIP events on the fit's stream."""
+    lib, L, m = pkg._lib.load(), pkg._lib, bsim.model
+    plan, st, stream = m._plan, pkg._lib.stream(), torch.cuda.current_stream()
+    n_updates, batch, reps = 100, 100, 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(reps + 1):
+        if rep == 1:
+            e0.record(stream)
+        L.check(lib.bsig_fit_begin(plan, 99 + rep, batch * m._dp.world, st))
+        L.check(lib.bsig_fit_run_dp(plan, m._dp.comm, n_updates, None, st))
+    e1.record(stream)
+    torch.cuda.synchronize()
+    DP_LOOP_US['us'] = e0.elapsed_time(e1) * 1e3 / (reps * n_updates)
+
+
 def time_update_kernel(pkg, cfg, bsim, device):
     """HIP-event timing of the dominant kernel of the fit, the persistent update
     kernel (csrc/fit_persistent.hip / fit_persistent_mdnn.hip): ONE launch per
@@ -265,21 +286,7 @@ def time_update_kernel(pkg, cfg, bsim, device):
         total_ms += sum(a.elapsed_time(b) for a, b in evs)
         launches += len(evs)
     us = total_ms * 1e3 / launches
-    loop_us = None
-    if dp:
-        # the whole data-parallel loop as the fit runs it: bsig_fit_run_dp = per update one
-        # launch + the all-reduce of the flat gradient buffer (+ the evaluations), from C
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 3
-        L.check(lib.bsig_fit_begin(plan, 99, batch * m._dp.world, st))
-        L.check(lib.bsig_fit_run_dp(plan, m._dp.comm, n_updates, None, st))
-        e0.record(stream)
-        for rep in range(reps):
-            L.check(lib.bsig_fit_begin(plan, 100 + rep, batch * m._dp.world, st))
-            L.check(lib.bsig_fit_run_dp(plan, m._dp.comm, n_updates, None, st))
-        e1.record(stream)
-        torch.cuda.synchronize()
-        loop_us = e0.elapsed_time(e1) * 1e3 / (reps * n_updates)
+    loop_us = DP_LOOP_US.get('us')
     nh = cfg['k'] * (1 + 2 * cfg['d'])
     if cfg['model'] != 'MDRFF':
         out = mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp, n_evals, n_test)
@@ -432,8 +439,8 @@ def summarizer_roofline(pkg, cfg, bsim, n, device):
 
 def scaled_batch(pkg, cfg, theta, states, actions, device, batch=8192, epochs=10):
     """Clearly separate from the headline: the same pairs as ONE chunk with a
-    large minibatch (B=8192, 10 epochs, one optimizer) — the regime where the
-    GEMMs are MFMA bound rather than latency bound."""
+    large minibatch (B=8192, 10 epochs, one optimizer) -- the regime where the
+    GEMMs are MFMA bound rather than latency bound (SURVEY.md 8(d))."""
     bs = build_gpu_model(pkg, cfg, device, 4321)
     n = theta.shape[0]
     n_updates = max(epochs * n // batch, 1)
@@ -447,9 +454,99 @@ def scaled_batch(pkg, cfg, theta, states, actions, device, batch=8192, epochs=10
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    return {'pairs_per_s': n / best, 'sgd_visits_per_s': n_updates * batch / best,
-            'batch': batch, 'n_updates': n_updates, 'heldout_nll': logs['test_loss'][-1],
-            'protocol': 'all %d pairs as one chunk, %d epochs of minibatch %d' % (n, epochs, batch)}
+    # algorithmic flops of the whole fit: per row visit K6+K7 (MDRFF heads:
+    # 2*2*F*Nh; MDNN: K5 + heads), the RFF projection once per distinct row, the forward
+    # products of the held-out evaluations
+    nh = cfg['k'] * (1 + 2 * cfg['d'])
+    m = bs.model
+    n_test = n - max(int(n * 0.8), 1)
+    n_evals = len([it for it in range(n_updates) if it % max(n_updates // 5, 1) == 0 or it + 1 == n_updates])
+    if cfg['model'] == 'MDRFF':
+        f_in = m.rff.m_feat * 2
+        per_visit, fwd_row = 2.0 * 2.0 * f_in * nh, 2.0 * f_in * nh
+        once = 2.0 * m.input_dim * m.rff.m_feat * n
+    else:
+        i, h = m.input_dim, 128
+        per_visit = 2.0 * (2.0 * i * h) + 3.0 * (2.0 * h * h) + 3.0 * (2.0 * h * nh)
+        fwd_row, once = 2.0 * i * h + 2.0 * h * h + 2.0 * h * nh, 0.0
+    flops = per_visit * batch * n_updates + once + fwd_row * n_test * n_evals
+    out = {'pairs_per_s': n / best, 'sgd_visits_per_s': n_updates * batch / best,
+           'batch': batch, 'n_updates': n_updates, 'heldout_nll': logs['test_loss'][-1],
+           'effective_tflops': flops / best / 1e12, 'frac_of_fp32_mfma_peak': flops / best / 1e12 / PEAK_F32_TFLOPS,
+           'algorithmic_flops': flops,
+           'protocol': 'all %d pairs as one chunk, %d epochs of minibatch %d' % (n, epochs, batch)}
+    out['roofline_scaled'] = scaled_gemm_roofline(pkg, cfg, m, batch, nh, device)
+    out['nll_match'] = scaled_nll_check(pkg, cfg, theta, states, actions, device, batch)
+    return out
+
+
+def scaled_gemm_roofline(pkg, cfg, m, batch, nh, device):
+    """The two products that dominate a scaled-batch update, timed with HIP events through
+    the C ABI at the update's shapes and access patterns (minibatch rows gathered from the
+    chunk's rows): forward  O = X[ids] W^T  and the weight gradient  dW = dO^T X[ids]."""
+    lib, L = pkg._lib.load(), pkg._lib
+    k_in = m.rff.m_feat * 2 if cfg['model'] == 'MDRFF' else m.input_dim
+    n_out = nh if cfg['model'] == 'MDRFF' else 128
+    pool = 40000
+    x = torch.randn(pool, L.round_up(k_in, 4), device=device)
+    ids = torch.randint(0, pool, (batch,), device=device, dtype=torch.int32)
+    w = torch.randn(n_out, L.round_up(k_in, 4), device=device)
+    o = torch.empty(batch, n_out, device=device)
+    d_o = torch.randn(batch, n_out, device=device)
+    dw = torch.empty(n_out, L.round_up(k_in, 4), device=device)
+    ws = torch.empty(max(int(lib.bsig_gemm_workspace_bytes(batch, n_out, k_in)),
+                         int(lib.bsig_gemm_workspace_bytes(n_out, k_in, batch))) // 4 + 1, device=device)
+
+    def fwd():
+        L.check(lib.bsig_gemm_f32(L.ptr(x), x.stride(0), 0, L.ptr(ids), L.ptr(w), w.stride(0), 0, None,
+                                  L.ptr(o), n_out, batch, n_out, k_in, L.EPI_NONE, 0, None, None, 0, 1.0,
+                                  L.ptr(ws), ws.numel() * 4, L.stream()))
+
+    def dwf():
+        L.check(lib.bsig_gemm_f32(L.ptr(d_o), n_out, 1, None, L.ptr(x), x.stride(0), 1, L.ptr(ids),
+                                  L.ptr(dw), dw.stride(0), n_out, k_in, batch, L.EPI_NONE, 0, None, None, 0,
+                                  1.0, L.ptr(ws), ws.numel() * 4, L.stream()))
+    res = {}
+    flops = 2.0 * batch * n_out * k_in
+    for tag, fn in (('forward', fwd), ('weight_gradient', dwf)):
+        us = _event_time(fn, 20, 3)
+        res[tag] = {'shape': '%dx%dx%d' % ((batch, n_out, k_in) if tag == 'forward' else (n_out, k_in, batch)),
+                    'avg_us': us, 'achieved': flops / us / 1e6, 'frac': flops / us / 1e6 / PEAK_F32_TFLOPS}
+    return {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel (fp32 32x32x2 MFMA; least-padding tile + split-K '
+                                       'picked by plan_gemm_large) incl. its split-K reduce',
+            'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'algorithmic': '2*B*N*K = %.3e flop per launch' % flops,
+            **res}
+
+
+def scaled_nll_check(pkg, cfg, theta, states, actions, device, batch, n=20000, n_updates=8):
+    """the scaled-batch schedule (one chunk, minibatch 8192, one optimizer)
+    teacher-forced against the oracle on a short run: same start weights, same ids, EPS_NOISE=0."""
+    from oracle import summarize as osum
+    old = pkg.MDNN.EPS_NOISE
+    pkg.MDNN.EPS_NOISE = 0.0
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        n = min(n, theta.shape[0])
+        th, st, ac = theta[:n], states[:n], actions[:n]
+        n_train = max(int(n * 0.8), 1)
+        ids = np.random.RandomState(6).randint(0, n_train, (n_updates, batch))
+        bsg = build_gpu_model(pkg, cfg, device, 78)
+        w0 = {k: v.cpu().clone() for k, v in bsg.model.state_dict().items()}
+        got = bsg.model.run_training(bsg._summarize(st, ac), th, n_updates, batch, ids_table=ids)
+        ora = build_oracle(cfg, bsg.model.input_dim, 78, 0.0,
+                           freqs=bsg.model.rff.freqs.cpu().numpy() if cfg['model'] == 'MDRFF' else None)
+        ora.load_state_dict(w0)
+        ref = ora.run_training(osum.SUMMARIZERS[cfg['summarizer']](st.cpu(), ac.cpu()), th.cpu(),
+                               n_updates, batch, ids_table=ids)
+        g, r = got['test_loss'][-1], ref['test_loss'][-1]
+        return {'heldout_nll_hip': g, 'heldout_nll_oracle': r, 'rel_diff': abs(g - r) / max(abs(r), 1e-12),
+                'max_rel_diff_all_logs': float(max(
+                    abs(a - b) / max(abs(b), 1e-12)
+                    for key in ('train_loss', 'test_loss') for a, b in zip(got[key], ref[key]))),
+                'protocol': '%d pairs as one chunk, %d updates of minibatch %d teacher-forced, EPS_NOISE=0'
+                            % (n, n_updates, batch)}
+    finally:
+        pkg.MDNN.EPS_NOISE = old
 
 
 T0 = time.perf_counter()
@@ -482,6 +579,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-scaled-batch', action='store_true')
+    ap.add_argument('--only-scaled-batch', action='store_true',
+                    help='run the scaled-batch mode alone (for profiling) and print its JSON')
     ap.add_argument('--variants', action='store_true',
                     help='also time the fit with the persistent kernel / feature cache / RFF hoist off')
     ap.add_argument('--watchdog', type=int, default=int(os.environ.get('BENCH_WATCHDOG', 1700)),
@@ -543,6 +642,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.only_scaled_batch:
+        print(json.dumps(scaled_batch(pkg, cfg, theta, states, actions, device)), flush=True)
+        return
     np.random.seed(1234 + rank)
     note('warmup')
     for _ in range(args.warmup):
@@ -563,6 +665,8 @@ def main():
     final_test = float(np.mean([lg['test_loss'][-1] for lg in logs]))
 
     out = None
+    if dist is not None and int(pkg._lib.load().bsig_fit_is_persistent(bsim.model._plan)):
+        time_dp_loop(pkg, bsim)
     if rank == 0:
         out = {
             'metric': 'summary_vectors_per_sec_in_fit', 'value': value, 'unit': 'pairs/s',

@@ -7,7 +7,7 @@ OUT=bayes_sim_ig_amd/lib
 mkdir -p "$OUT" "$OUT/obj"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 pids=()
-for f in summarizers gemm_f32 gemm_tile_64 gemm_tile_128 gemm_tile_128x32 gemm_tile_128x64 mdn_head flat_ops estimator fit_persistent fit_persistent_mdnn; do
+for f in summarizers gemm_f32 gemm_tile_64 gemm_tile_128 gemm_tile_128x32 gemm_tile_128x64 gemm_tile_128x96 gemm_tile_96x128 mdn_head flat_ops estimator fit_persistent fit_persistent_mdnn; do
   if [ ! -f "$OUT/obj/$f.o" ] || [ "$SRC/$f.hip" -nt "$OUT/obj/$f.o" ] || [ -n "$(find "$SRC" -name '*.h' -newer "$OUT/obj/$f.o")" ] || [ include/bsig.h -nt "$OUT/obj/$f.o" ]; then
     hipcc $FLAGS -c "$SRC/$f.hip" -o "$OUT/obj/$f.o" &
     pids+=($!)

@@ -245,6 +245,13 @@ typedef struct bsig_fit_plan bsig_fit_plan;
  * rows of every evaluation are computed by bsig_fit_begin in one large GEMM). */
 int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t max_test_rows,
                     int64_t n_updates, bsig_fit_plan** plan);
+/* The same with a bound on the training rows the plan will be bound to (0 = none):
+ * MDRFF plans then size the hoisted feature block for min(n_updates*batch,
+ * max_train_rows) rows -- a call that visits every row many times (large minibatches
+ * over many epochs) keeps ONE feature row per distinct training row instead of
+ * projecting inside every update. */
+int bsig_fit_create_sized(const bsig_mdn_cfg* cfg, int64_t batch, int64_t max_train_rows,
+                          int64_t max_test_rows, int64_t n_updates, bsig_fit_plan** plan);
 void bsig_fit_destroy(bsig_fit_plan* plan);
 size_t bsig_fit_workspace_bytes(const bsig_fit_plan* plan);
 /* Bind buffers (re-captures graphs only if something changed).  flags:

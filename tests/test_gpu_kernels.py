@@ -145,6 +145,53 @@ def test_gemm_layouts(B, m, n, k, a_km, b_km):
     np.testing.assert_allclose(out, ref, atol=3e-6 * np.sqrt(k) * 4, rtol=1e-5)
 
 
+@pytest.mark.parametrize('tile', [3, 4, 5])           # 128x64, 128x96, 96x128
+@pytest.mark.parametrize('a_km,b_km', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('splits', [1, 3])
+def test_gemm_every_tile_shape(B, tile, a_km, b_km, splits):
+    """The tile shapes the planner only picks for large problems, forced on a small ragged
+    problem (edges in M, N and K) in every operand layout, unsplit and split-K."""
+    import os
+    m, n, k = 300, 260, 530
+    gen = torch.Generator().manual_seed(tile * 7 + a_km * 2 + b_km)
+    a_t = torch.randn(m, k, generator=gen)
+    b_t = torch.randn(n, k, generator=gen)
+    ref = (a_t.double() @ b_t.double().T).numpy()
+    a = (a_t.T if a_km else a_t).contiguous().to(DEV)
+    b = (b_t.T if b_km else b_t).contiguous().to(DEV)
+    os.environ['BSIG_GEMM_TILE'], os.environ['BSIG_GEMM_SPLITS'] = str(tile), str(splits)
+    try:
+        out = _gemm(B, a, b, m, n, k, a_km, b_km).cpu().numpy()
+    finally:
+        os.environ.pop('BSIG_GEMM_TILE'), os.environ.pop('BSIG_GEMM_SPLITS')
+    np.testing.assert_allclose(out, ref, atol=3e-6 * np.sqrt(k) * 4, rtol=1e-5)
+
+
+@pytest.mark.parametrize('shape', ['fwd', 'dw'])
+def test_gemm_large_minibatch_shapes(B, shape):
+    """The scaled-batch update's products as the planner runs them (least-padding tile,
+    split K): head forward 8192 x 260 x 4096 on gathered feature rows with bias, and
+    dW = dO^T F[ids] with the gather on the contraction index, vs fp64 on sampled outputs."""
+    L = B._lib
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    pool, bsz, nh, f = 20000, 8192, 260, 4096
+    feats = torch.randn(pool, f, device=DEV, generator=gen) * 0.02
+    ids = torch.randint(0, pool, (bsz,), device=DEV, generator=gen).to(torch.int32)
+    if shape == 'fwd':
+        w = torch.randn(nh, f, device=DEV, generator=gen)
+        bias = torch.randn(nh, device=DEV, generator=gen)
+        out = _gemm(B, feats, w, bsz, nh, f, 0, 0, epi=L.EPI_BIAS, bias=bias, a_rows=ids)
+        rows = torch.arange(0, bsz, 97, device=DEV)
+        ref = feats[ids.long()[rows]].double() @ w.double().T + bias.double()
+        torch.testing.assert_close(out[rows].double(), ref, rtol=1e-5, atol=2e-5)
+    else:
+        d_o = torch.randn(bsz, nh, device=DEV, generator=gen) * 0.01
+        out = _gemm(B, d_o, feats, nh, f, bsz, 1, 1, b_rows=ids)
+        cols = torch.arange(0, f, 61, device=DEV)
+        ref = d_o.double().T @ feats[ids.long()][:, cols].double()
+        torch.testing.assert_close(out[:, cols].double(), ref, rtol=1e-5, atol=2e-6)
+
+
 def test_gemm_gather_and_epilogues(B):
     L = B._lib
     gen = torch.Generator().manual_seed(5)
