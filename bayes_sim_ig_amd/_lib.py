@@ -17,6 +17,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_ACT, EPI_COS_SIN, EPI_COS_OFF, EPI_MUL_DACT = range
 ACT_TANH, ACT_RELU, ACT_LEAKY_RELU, ACT_SIGMOID, ACT_IDENTITY = range(5)
 MAX_HIDDEN = 8
 FIT_GRAPH, FIT_SPLIT_ADAM = 1, 2
+X_ROWS, X_CROSSCORR_FACTORS = 0, 1
 
 i64, i32, u64, f32, vp, sz = (C.c_int64, C.c_int32, C.c_uint64, C.c_float,
                               C.c_void_p, C.c_size_t)
@@ -44,7 +45,8 @@ class FitBuffers(C.Structure):
                 ('x_test', vp), ('ldx_test', i64), ('n_test', i64),
                 ('y_test', vp), ('ldy_test', i64),
                 ('ids_table', vp), ('train_loss', vp), ('test_loss', vp),
-                ('state', vp), ('workspace', vp), ('workspace_bytes', sz)]
+                ('state', vp), ('workspace', vp), ('workspace_bytes', sz),
+                ('x_kind', i32), ('x_s', i32), ('x_a', i32)]
 
 
 _PROTOS = {
@@ -54,6 +56,9 @@ _PROTOS = {
     'bsig_summary_dim': (i64, [C.c_int] * 5),
     'bsig_summary_start': (C.c_int, [vp, vp, vp, i64] + [C.c_int] * 5 + [i64, vp]),
     'bsig_crosscorr': (C.c_int, [vp, vp, vp, i64] + [C.c_int] * 5 + [i64, vp, vp]),
+    'bsig_crosscorr_factor_dims': (C.c_int, [C.c_int] * 3 + [C.POINTER(i32)] * 2),
+    'bsig_crosscorr_factors': (C.c_int, [vp, vp, vp, i64] + [C.c_int] * 5 + [i64, vp, vp]),
+    'bsig_crosscorr_expand': (C.c_int, [vp, i64, i64, C.c_int, C.c_int, vp, i64, vp]),
     'bsig_signature': (C.c_int, [vp, vp, vp, i64] + [C.c_int] * 4 + [i64, vp]),
     'bsig_gemm_workspace_bytes': (sz, [i64, i64, i64]),
     'bsig_gemm_f32': (C.c_int, [vp, i64, C.c_int, vp, vp, i64, C.c_int, vp, vp,
@@ -95,6 +100,7 @@ _PROTOS = {
     'bsig_fit_apply': (C.c_int, [vp, vp]),
     'bsig_fit_flush': (C.c_int, [vp, vp]),
     'bsig_fit_is_persistent': (C.c_int, [vp]),
+    'bsig_fit_accepts_factors': (C.c_int, [vp]),
     'bsig_fit_eval': (C.c_int, [vp, vp]),
     'bsig_fit_updates': (C.c_int, [vp, i64, vp]),
     'bsig_debug_persist_profile': (None, [vp]),
@@ -175,6 +181,8 @@ def on_device(device):
 
 def as_f32_rows(t, device=None):
     """fp32, last dim contiguous, on the GPU.  Returns (tensor, ld)."""
+    if hasattr(t, 'materialize'):      # a lazy summary handle (summarizers.CrossCorrFactors)
+        t = t.materialize()
     if t.dtype != torch.float32:
         t = t.float()
     if device is not None and t.device != torch.device(device):

@@ -89,26 +89,39 @@ class BayesSim(object):
             n = n_train_trajs - n_train_trajs_done
         return n
 
-    def _summarize(self, states, actions, finite_flag=None):
+    def _summarize(self, states, actions, finite_flag=None, lazy=False):
         if self.summarizer_name == 'summary_signatory' and self._sig_depth:
             return self.summarizer_fxn(states, actions, depth=self._sig_depth)
-        if finite_flag is not None and self.summarizer_name in ('summary_corr', 'summary_corrdiff'):
-            # the isfinite assert of summarizers.py:120, deferred with the chunk's logs
-            return self.summarizer_fxn(states, actions, check_finite=finite_flag)
+        if self.summarizer_name in ('summary_corr', 'summary_corrdiff'):
+            kw = {}
+            if finite_flag is not None:
+                # the isfinite assert of summarizers.py:120, deferred with the chunk's logs
+                kw['check_finite'] = finite_flag
+            # training never needs the outer product itself: the estimator's first layer forms
+            # it from the factor rows (summarizers.CrossCorrFactors)
+            if lazy and self._lazy_summaries():
+                kw['lazy'] = True
+            return self.summarizer_fxn(states, actions, **kw)
         return self.summarizer_fxn(states, actions)
+
+    def _lazy_summaries(self):
+        return (getattr(self.model, 'rff', None) is None and self.model._flat.is_cuda and
+                os.environ.get('BSIG_NO_FUSED_SUMMARY') != '1')
 
     def run_training(self, params, traj_states, traj_actions, _defer=False, _finite_flag=None,
                      _summaries=None, _feats=None):
         """One chunk: summarize, then NUM_GRAD_UPDATES Adam updates of
         MINIBATCH_SIZE (reference bayes_sim.py:91-114)."""
         traj_summaries = _summaries if _summaries is not None else \
-            self._summarize(traj_states, traj_actions, _finite_flag)
+            self._summarize(traj_states, traj_actions, _finite_flag, lazy=True)
         kw = {} if _feats is None else {'_feats': _feats}
         return self.model.run_training(
             x_data=traj_summaries, y_data=params,
             n_updates=BayesSim.NUM_GRAD_UPDATES,
             batch_size=BayesSim.MINIBATCH_SIZE,
             test_frac=BayesSim.TEST_FRACTION, _defer=_defer, **kw)
+
+    FIT_BLOCK_BYTES = 4 << 30        # (not in the reference) bound on a block's summaries in fit()
 
     def fit(self, params, traj_states, traj_actions):
         """The caller-side loop of bayes_sim_main.py:157-167 over
@@ -127,25 +140,29 @@ class BayesSim(object):
         flag = None
         if torch.is_tensor(traj_states) and traj_states.is_cuda:
             flag = torch.zeros(1, dtype=torch.int32, device=traj_states.device)
-        # MDRFF: the summaries and their RFF features are pure functions of the row
-        # (rff.py:128-132): both are computed for a block of chunks at once -- one
-        # summarizer launch and one large MFMA GEMM instead of one small one per chunk
+        # The summaries (and an MDRFF's RFF features, rff.py:128-132) are pure functions of the
+        # row: both are computed for a block of chunks at once -- one summarizer launch over
+        # up to 32000 trajectories (and one large MFMA GEMM) instead of one small one per chunk
         block = 0
-        if flag is not None and getattr(self.model, 'rff', None) is not None and \
-                os.environ.get('BSIG_NO_FIT_PREPROJECT') != '1':
-            block = BayesSim.FIT_BLOCK_CHUNKS * BayesSim.NUM_TRAIN_TRAJ_PER_BATCH
+        is_rff = getattr(self.model, 'rff', None) is not None
+        if flag is not None and os.environ.get('BSIG_NO_FIT_PREPROJECT') != '1':
+            row_bytes = 4 * (self.model.input_dim + (self.model.rff.n_feat if is_rff else 0))
+            chunks = max(min(BayesSim.FIT_BLOCK_CHUNKS,
+                             BayesSim.FIT_BLOCK_BYTES // (row_bytes * BayesSim.NUM_TRAIN_TRAJ_PER_BATCH)), 1)
+            block = chunks * BayesSim.NUM_TRAIN_TRAJ_PER_BATCH
         lo = hi = 0
         summ = feats = None
         while done < n:
             m = BayesSim.get_n_trajs_per_batch(n, done)
             if block and done + m > hi:
                 lo, hi = done, min(n, done + block)
-                summ = self._summarize(traj_states[lo:hi], traj_actions[lo:hi], flag)
-                feats = self.model.rff.to_features(summ)
+                summ = self._summarize(traj_states[lo:hi], traj_actions[lo:hi], flag, lazy=True)
+                feats = self.model.rff.to_features(summ) if is_rff else None
             if block:
-                pending.append(self.run_training(params[done:done + m], None, None, _defer=True,
-                                                 _summaries=summ[done - lo:done - lo + m],
-                                                 _feats=feats[done - lo:done - lo + m]))
+                pending.append(self.run_training(
+                    params[done:done + m], None, None, _defer=True,
+                    _summaries=summ[done - lo:done - lo + m],
+                    _feats=None if feats is None else feats[done - lo:done - lo + m]))
             else:
                 pending.append(self.run_training(params[done:done + m],
                                                  traj_states[done:done + m],

@@ -441,6 +441,7 @@ static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, int 
   const bsig_fit_buffers& b = p->buf;
   PersistMdnnBuffers pb;
   pb.x = b.x_train; pb.ldx = b.ldx_train; pb.ids = b.ids_table;
+  pb.x_kind = b.x_kind; pb.x_s = b.x_s; pb.x_a = b.x_a;
   pb.y = b.y_train; pb.ldy = b.ldy_train;
   pb.params = b.params; pb.exp_avg = b.exp_avg; pb.exp_avg_sq = b.exp_avg_sq;
   pb.w1_off = p->L.w_off[0]; pb.b1_off = p->L.b_off[0];
@@ -496,6 +497,7 @@ static Inputs eval_inputs(const bsig_fit_plan* p, const PlanMem& m) {
 
 // forward + NLL + finish (advances the step) [+ backward]
 static int enqueue_grad(bsig_fit_plan* p, hipStream_t st, bool fuse_adam) {
+  if (p->buf.x_kind != BSIG_X_ROWS) { set_error("per-phase update on factor rows"); return BSIG_EUNSUPPORTED; }
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
   const Inputs in = train_inputs(p, m);
@@ -711,6 +713,8 @@ extern "C" int bsig_fit_create_sized(const bsig_mdn_cfg* cfg, int64_t batch,
   // MDRFF feature block: one row per gathered minibatch row, or -- when the caller bounds the
   // training rows and they are fewer -- one per distinct training row (feature cache)
   p->max_train = max_train_rows;
+  const char* no_cache_env = getenv("BSIG_NO_FEAT_CACHE");   // diagnostics: every gathered row projected
+  if (no_cache_env && no_cache_env[0] == '1') max_train_rows = 0;
   p->feat_rows = (max_train_rows > 0 ? std::min(n_updates * batch, max_train_rows)
                                      : n_updates * batch) + max_test_rows;
   const size_t feats = (size_t)p->feat_rows * (size_t)std::max(cfg->rff_feats, 0) * sizeof(float);
@@ -763,7 +767,22 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
   BSIG_REQUIRE(b->n_train >= 1 && b->n_test >= 0 && b->n_test <= std::max<int64_t>(p->max_test, 0),
                "fit_bind: n_train=%lld n_test=%lld (max %lld)", (long long)b->n_train,
                (long long)b->n_test, (long long)p->max_test);
-  BSIG_REQUIRE(b->ldx_train >= p->cfg.input_dim && b->ldy_train >= p->cfg.head.out_dim,
+  const bool fac = b->x_kind == BSIG_X_CROSSCORR_FACTORS;
+  BSIG_REQUIRE(b->x_kind == BSIG_X_ROWS || fac, "fit_bind: unknown x_kind %d", b->x_kind);
+  if (fac) {
+    BSIG_REQUIRE(b->x_s >= 1 && b->x_a >= 1 && (int64_t)b->x_s * b->x_a + 2 == p->cfg.input_dim,
+                 "fit_bind: factor rows S=%d A=%d do not give the %d inputs of the first layer",
+                 b->x_s, b->x_a, p->cfg.input_dim);
+    BSIG_REQUIRE(b->ldx_train >= b->x_s + b->x_a + 3, "fit_bind: factor rows need a pitch >= S + A + 3");
+    BSIG_REQUIRE(b->n_test == 0 || b->ldx_test >= p->cfg.input_dim,
+                 "fit_bind: the held-out rows are summary rows (ldx_test >= input_dim)");
+    if (!bsig_fit_accepts_factors(p)) {
+      set_error("fit_bind: this plan runs kernels that read materialised summary rows "
+                "(bsig_fit_accepts_factors); expand the factors (bsig_crosscorr_expand)");
+      return BSIG_EUNSUPPORTED;
+    }
+  }
+  BSIG_REQUIRE((fac || b->ldx_train >= p->cfg.input_dim) && b->ldy_train >= p->cfg.head.out_dim,
                "fit_bind: leading dims too small");
   BSIG_REQUIRE(!(b->n_test > 0 && !(b->x_test && b->y_test)), "fit_bind: null test buffers");
   const bool graph = (flags & BSIG_FIT_GRAPH) != 0, split = (flags & BSIG_FIT_SPLIT_ADAM) != 0;
@@ -859,6 +878,12 @@ extern "C" int bsig_fit_apply(bsig_fit_plan* p, bsig_stream_t stream) {
   if (p->persistent || p->persistent_mdnn) { p->adam_pending = true; return BSIG_OK; }
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_apply, as_stream(stream))); return BSIG_OK; }
   return enqueue_apply(p, as_stream(stream));
+}
+
+extern "C" int bsig_fit_accepts_factors(const bsig_fit_plan* p) {
+  // every update runs in the persistent kernel of the two-layer MDNN, whose first-layer tile
+  // workgroups form the products; the evaluations read materialised held-out rows
+  return p && p->persistent_mdnn && p->n_updates >= 1 ? 1 : 0;
 }
 
 extern "C" int bsig_fit_is_persistent(const bsig_fit_plan* p) {

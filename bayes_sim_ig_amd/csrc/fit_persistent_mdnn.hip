@@ -55,6 +55,8 @@ struct MdnnArgs {
   int k_slices, G1, n_owner, n_small;
   int n_updates, x_floats;
   const float* x; int64_t ldx; const int32_t* ids;
+  int x_fac, xS, xA;   // x rows are cross-correlation factors [sf S | af A | mean | std | 1]
+                       // (x_test rows are always materialised summaries)
   const float* y; int64_t ldy;
   float* params; float* m1; float* m2;
   int64_t w1_off, b1_off, w2_off, b2_off, wh_off, bh_off;
@@ -111,6 +113,34 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// First-layer inputs from cross-correlation FACTOR rows (summarizers.py:106-119; layout in
+// bsig.h): x[i*A + j] = sf[i] * af[j] -- the one fp32 multiply the summarizer itself would
+// do --, x[S*A] = mean * 1, x[S*A + 1] = std * 1; columns beyond that come out as 1 * 1 and
+// are masked by the callers.  FacCols: where the two factors of the four consecutive inputs
+// x[col .. col+3] sit inside a factor row (the same for every row).
+struct FacCols { int oi[4], oj[4]; };
+__device__ __forceinline__ FacCols fac_cols(int col, int S, int A) {
+  const int SA = S * A, one = S + A + 2;
+  // col / A without an integer division: float estimate, two corrections (col < 2^24)
+  int i = (int)((float)col * __builtin_amdgcn_rcpf((float)A));
+  if (i * A > col) --i;
+  if ((i + 1) * A <= col) ++i;
+  int j = col - i * A;
+  FacCols c;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = col + e;
+    c.oi[e] = k < SA ? i : (k == SA ? S + A : (k == SA + 1 ? S + A + 1 : one));
+    c.oj[e] = k < SA ? S + j : one;
+    if (++j == A) { j = 0; ++i; }
+  }
+  return c;
+}
+__device__ __forceinline__ float4 fac_load4(const float* __restrict__ rowp, const FacCols& c) {
+  return make_float4(rowp[c.oi[0]] * rowp[c.oj[0]], rowp[c.oi[1]] * rowp[c.oj[1]],
+                     rowp[c.oi[2]] * rowp[c.oj[2]], rowp[c.oi[3]] * rowp[c.oj[3]]);
+}
+
 // one [<=104, 256] summary tile = 13 float4 per thread in named registers
 #define BSIG_MPF_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
 #define BSIG_MPF_DECL(u) float4 pf##u;
@@ -118,8 +148,12 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   {                                                                                         \
     const int idx = min((u) * kMT + tid, nvec - 1);                                         \
     const int64_t fr = (int64_t)p.ids[pf_row0 + (idx >> 6)];                                \
-    const int64_t col = min((int64_t)k0 + (idx & 63) * 4, p.ldx - 4);                       \
-    pf##u = *reinterpret_cast<const float4*>(p.x + fr * p.ldx + col);                       \
+    if constexpr (FAC) {                                                                    \
+      pf##u = fac_load4(p.x + fr * p.ldx, fcols);                                           \
+    } else {                                                                                \
+      const int64_t col = min((int64_t)k0 + (idx & 63) * 4, p.ldx - 4);                     \
+      pf##u = *reinterpret_cast<const float4*>(p.x + fr * p.ldx + col);                     \
+    }                                                                                       \
   }
 #define BSIG_MPF_ZERO(u) pf##u = make_float4(0.f, 0.f, 0.f, 0.f);
 // columns >= I (row padding, the tail of the last k-slice) enter as zeros
@@ -206,7 +240,7 @@ __device__ __forceinline__ void mdnn_tile_eval(const MdnnArgs& p, const float* W
 }
 
 // ---- tile workgroups: first-layer partial products, dW1, Adam -------------------
-template <bool DP>
+template <bool DP, bool FAC>
 __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* smem) {
   float* Fl = smem;                          // [FR][kMPitch] minibatch summaries (this k-slice)
   float* Wl = Fl + p.FR * kMPitch;           // [32][kMPitch] weight tile (authoritative copy)
@@ -273,6 +307,8 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   BSIG_MPF_LIST(BSIG_MPF_DECL)
   if (p.n_updates > 0) {
     const int64_t pf_row0 = (int64_t)step0 * B;
+    FacCols fcols{};
+    if constexpr (FAC) fcols = fac_cols(k0 + (tid & 63) * 4, p.xS, p.xA);
     BSIG_MPF_LIST(BSIG_MPF_LOAD)
   } else {
     BSIG_MPF_LIST(BSIG_MPF_ZERO)
@@ -339,12 +375,17 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
       mdnn_tile_eval(p, Wl, X, biasl, mdnn_evals_before(step, p.eval_every) - 1);
     if (t + 1 < p.n_updates) {
       const int64_t pf_row0 = (int64_t)(step + 1) * B;
+      FacCols fcols{};
+      if constexpr (FAC) fcols = fac_cols(k0 + (tid_l & 63) * 4, p.xS, p.xA);
       BSIG_MPF_LIST(BSIG_MPF_LOAD)
     }
     b1t *= p.beta1; b2t *= p.beta2;
     a0 = (float)(p.lr / (1.0 - b1t));
     a1 = (float)(1.0 / sqrt(1.0 - b2t));
 
+    if constexpr (FAC) {   // (diagnostics) the factor products of the next tile are in registers
+      if (p.prof) { asm volatile("" :: "v"(pf0.x), "v"(pf12.w)); BSIG_MSTAMP(8); }
+    }
     // ---- 3. dW1 = dz1^T X on this tile, Adam ---------------------------------------
     if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
     __syncthreads();
@@ -1151,11 +1192,12 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
 }
 
 // DP: data-parallel rank (gradients out, pending Adam step in; see MdnnArgs)
-template <bool DP>
+// FAC: the summary rows arrive as cross-correlation factor rows
+template <bool DP, bool FAC>
 __global__ __launch_bounds__(kMT) void mdnn_updates_kernel(MdnnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wg = blockIdx.x;
-  if (wg < p.G1) mdnn_tile_workgroup<DP>(p, smem);
+  if (wg < p.G1) mdnn_tile_workgroup<DP, FAC>(p, smem);
   else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP>(p, smem);
   else mdnn_small_workgroup<DP>(p, smem);
 }
@@ -1258,7 +1300,13 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
                    b.train_loss && b.workspace, "persistent MDNN updates: null buffer");
   BSIG_REQUIRE(b.workspace_bytes >= persist_mdnn_workspace_bytes(s),
                "persistent MDNN updates: workspace too small");
-  BSIG_REQUIRE(b.ldx % 4 == 0 && b.ldx >= s.input_dim && aligned(b.x, 16),
+  const bool fac = b.x_kind == BSIG_X_CROSSCORR_FACTORS;
+  BSIG_REQUIRE(b.x_kind == BSIG_X_ROWS || fac, "persistent MDNN updates: unknown x_kind");
+  BSIG_REQUIRE(!fac || (b.x_s >= 1 && b.x_a >= 1 && (int64_t)b.x_s * b.x_a + 2 == s.input_dim &&
+                        b.ldx >= b.x_s + b.x_a + 3),
+               "persistent MDNN updates: factor rows do not match the first layer (S=%d A=%d I=%d)",
+               b.x_s, b.x_a, s.input_dim);
+  BSIG_REQUIRE(fac || (b.ldx % 4 == 0 && b.ldx >= s.input_dim && aligned(b.x, 16)),
                "persistent MDNN updates: summaries must be 16-byte aligned rows");
   BSIG_REQUIRE(b.w2_off % 2 == 0 && b.wh_off % 2 == 0 && aligned(b.params, 16),
                "persistent MDNN updates: weight blocks must be 8-byte aligned");
@@ -1272,10 +1320,12 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   BSIG_HIP(hipGetDevice(&attr_dev));
   bool& attr_set = attr_set_dev[attr_dev & 63];
   if (!attr_set) {
-    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mdnn_updates_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit));
-    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mdnn_updates_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit));
+    const void* kernels[4] = {reinterpret_cast<const void*>(mdnn_updates_kernel<false, false>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, false>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<false, true>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, true>)};
+    for (const void* k : kernels)
+      BSIG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit));
     attr_set = true;
   }
   MdnnArgs p{};
@@ -1285,6 +1335,7 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.n_updates = std::max(n, 0); p.x_floats = g.x_floats;
   p.grads = b.grads; p.adam_pending = b.adam_pending;
   p.x = b.x; p.ldx = b.ldx; p.ids = b.ids; p.y = b.y; p.ldy = b.ldy;
+  p.x_fac = fac ? 1 : 0; p.xS = b.x_s; p.xA = b.x_a;
   p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq;
   p.w1_off = b.w1_off; p.b1_off = b.b1_off; p.w2_off = b.w2_off; p.b2_off = b.b2_off;
   p.wh_off = b.wh_off; p.bh_off = b.bh_off;
@@ -1324,10 +1375,11 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
     p.test_loss = b.test_loss;
   }
   p.prof = reinterpret_cast<long long*>(persist_profile_buffer());
-  if (b.grads)
-    hipLaunchKernelGGL(mdnn_updates_kernel<true>, dim3(g.G1 + g.n_owner + g.n_small), dim3(kMT), g.lds, st, p);
-  else
-    hipLaunchKernelGGL(mdnn_updates_kernel<false>, dim3(g.G1 + g.n_owner + g.n_small), dim3(kMT), g.lds, st, p);
+  const dim3 grid(g.G1 + g.n_owner + g.n_small);
+  if (b.grads && fac) hipLaunchKernelGGL((mdnn_updates_kernel<true, true>), grid, dim3(kMT), g.lds, st, p);
+  else if (b.grads) hipLaunchKernelGGL((mdnn_updates_kernel<true, false>), grid, dim3(kMT), g.lds, st, p);
+  else if (fac) hipLaunchKernelGGL((mdnn_updates_kernel<false, true>), grid, dim3(kMT), g.lds, st, p);
+  else hipLaunchKernelGGL((mdnn_updates_kernel<false, false>), grid, dim3(kMT), g.lds, st, p);
   BSIG_CHECK_LAUNCH("mdnn_updates");
   return BSIG_OK;
 }

@@ -13,7 +13,9 @@ struct PersistMdnnShape {
 };
 
 struct PersistMdnnBuffers {
-  const float* x; int64_t ldx;            // summary rows (training split of the chunk)
+  const float* x; int64_t ldx;            // summary rows (training split of the chunk), or
+  int x_kind = 0, x_s = 0, x_a = 0;       // ... cross-correlation factor rows (bsig.h: the tile
+                                          // workgroups form x[i*A + j] = sf[i] * af[j] themselves)
   const int32_t* ids;                     // [n_updates*batch] minibatch row ids (rows of x and y)
   const float* y; int64_t ldy;            // normalised targets
   float* params; float* exp_avg; float* exp_avg_sq;   // flat buffers

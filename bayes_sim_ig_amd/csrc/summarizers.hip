@@ -50,10 +50,14 @@ __global__ __launch_bounds__(256) void summary_start_kernel(
 //   out[i*A + j]   = sf[i]*af[j]      (bmm outer product, :112-113)
 //   out[S*A]       = mean(sf), out[S*A+1] = unbiased std(sf)   (:114-119)
 // Algorithmic bytes / trajectory: 4*(W*(sd+ad) + S*A + 2); write-bound.
+// `fac` (optional): the row's FACTORS [sf S | af A | mean | std | 1 | 0..] -- everything the
+// summary is made of, 1/35 of its size for Ant; `out` may then be null (no outer product):
+// the fit engine's first layer forms sf[i]*af[j] itself (bsig_crosscorr_factors).
 __global__ __launch_bounds__(256) void crosscorr_kernel(
     const float* __restrict__ states, const float* __restrict__ actions,
     float* __restrict__ out, int64_t n, int ts, int ta, int sd, int ad, int w,
-    int use_diff, int64_t ld_out, int vec4, int32_t* __restrict__ nonfinite) {
+    int use_diff, int64_t ld_out, int vec4, int32_t* __restrict__ nonfinite,
+    float* __restrict__ fac, int64_t ld_fac) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int sfeat = sd - 1;
   const int S = w * sfeat, A = w * ad;
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
   for (int64_t traj = blockIdx.x; traj < n; traj += gridDim.x) {
     const float* s = states + traj * (int64_t)ts * sd;
     const float* a = actions + traj * (int64_t)ta * ad;
-    float* o = out + traj * ld_out;
+    float* o = out ? out + traj * ld_out : nullptr;
     __syncthreads();
     // state features: iterate (t, c) without integer division
     for (int t = 0; t < w; ++t) {
@@ -101,6 +105,18 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
     ms = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     ma = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
     const bool check_each = !(ms < 1e18f && ma < 1e18f);
+    if (fac) {
+      float* f = fac + traj * ld_fac;
+      for (int i = tid; i < S; i += nt) f[i] = sf[i];
+      for (int i = tid; i < A; i += nt) f[S + i] = af[i];
+      for (int i = S + A + tid; i < ld_fac; i += nt)
+        f[i] = i == S + A ? mean : (i == S + A + 1 ? sdev : (i == S + A + 2 ? 1.0f : 0.f));
+    }
+    if (!o) {   // factors only: |sf[i] af[j]| <= max|sf| max|af|
+      if (nonfinite && (in_bad || (tid == 0 && !(isfinite(ms * ma) && isfinite(mean) && isfinite(sdev)))))
+        atomicOr(nonfinite, 1);
+      continue;
+    }
     // streaming outer product
     const int64_t total = (int64_t)S * A;
     bool bad = in_bad;
@@ -155,7 +171,8 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
 __global__ __launch_bounds__(256) void crosscorr_wave_kernel(
     const float* __restrict__ states, const float* __restrict__ actions,
     float* __restrict__ out, int64_t n, int ts, int ta, int sd, int ad, int w,
-    int use_diff, int64_t ld_out, int32_t* __restrict__ nonfinite) {
+    int use_diff, int64_t ld_out, int32_t* __restrict__ nonfinite,
+    float* __restrict__ fac, int64_t ld_fac) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int sfeat = sd - 1;
   const int S = w * sfeat, A = w * ad;
@@ -191,6 +208,22 @@ __global__ __launch_bounds__(256) void crosscorr_wave_kernel(
     }
     const float ss = wave_sum(part);
     const float sdev = (S < 2) ? 0.f : sqrtf(ss / (float)(S - 1));
+    if (fac) {
+      float* f = fac + traj * ld_fac;
+      for (int i = lane; i < S + A; i += 64) f[i] = sf[i];     // af follows sf in LDS
+      for (int i = S + A + lane; i < ld_fac; i += 64)
+        f[i] = i == S + A ? mean : (i == S + A + 1 ? sdev : (i == S + A + 2 ? 1.0f : 0.f));
+    }
+    if (!out) {   // factors only: a non-finite product needs a non-finite or overflowing pair
+      float ms = 0.f, ma = 0.f;
+      bool in_bad = false;
+      for (int i = lane; i < S; i += 64) { ms = fmaxf(ms, fabsf(sf[i])); in_bad |= !isfinite(sf[i]); }
+      for (int i = lane; i < A; i += 64) { ma = fmaxf(ma, fabsf(af[i])); in_bad |= !isfinite(af[i]); }
+      ms = wave_max(ms); ma = wave_max(ma);
+      if (nonfinite && (in_bad || !(isfinite(ms * ma) && isfinite(mean) && isfinite(sdev))))
+        atomicOr(nonfinite, 1);
+      continue;
+    }
     float* o = out + traj * ld_out;
     const int total = S * A;
     bool bad = false;
@@ -406,39 +439,107 @@ extern "C" int bsig_summary_start(const float* states, const float* actions, flo
   return BSIG_OK;
 }
 
-extern "C" int bsig_crosscorr(const float* states, const float* actions, float* out,
-                              int64_t n, int t_states, int t_actions, int sd, int ad,
-                              int use_state_diff, int64_t ld_out, int32_t* nonfinite,
-                              bsig_stream_t stream) {
+namespace bsig {
+static int crosscorr_window(int t_states, int sd) {
+  int w = sd > 50 ? 5 : 10;                       // summarizers.py:96-98
+  if (t_states <= w) w = t_states;                // :99 (only crop when longer)
+  return w;
+}
+
+// the materialised summary (`out`), its factors (`fac`), or both
+static int crosscorr_launch(const float* states, const float* actions, float* out, int64_t ld_out,
+                            float* fac, int64_t ld_fac, int64_t n, int t_states, int t_actions,
+                            int sd, int ad, int use_state_diff, int32_t* nonfinite,
+                            hipStream_t st) {
   if (n == 0) return BSIG_OK;
-  BSIG_REQUIRE(states && actions && out, "crosscorr: null pointer");
+  BSIG_REQUIRE(states && actions && (out || fac), "crosscorr: null pointer");
   BSIG_REQUIRE(n >= 0 && sd >= 2 && ad >= 1, "crosscorr: bad dims sd=%d ad=%d", sd, ad);
   BSIG_REQUIRE(t_states > 1, "crosscorr: traj_len must be > 1 (summarizers.py:94)");
   BSIG_REQUIRE(t_actions >= 1, "crosscorr: no actions");
-  int w = sd > 50 ? 5 : 10;                       // summarizers.py:96-98
-  if (t_states <= w) w = t_states;                // :99 (only crop when longer)
+  const int w = crosscorr_window(t_states, sd);
   const int64_t S = (int64_t)w * (sd - 1), A = (int64_t)w * ad;
-  BSIG_REQUIRE(ld_out >= S * A + 2, "crosscorr: ld_out too small");
+  BSIG_REQUIRE(!out || ld_out >= S * A + 2, "crosscorr: ld_out too small");
+  BSIG_REQUIRE(!fac || ld_fac >= S + A + 3, "crosscorr: ld_factors too small (need S + A + 3 = %lld)",
+               (long long)(S + A + 3));
   const size_t lds = (size_t)(S + A + 8) * sizeof(float);
   if (lds > 150 * 1024) {
     set_error("crosscorr: %zu B of LDS needed", lds);
     return BSIG_EUNSUPPORTED;
   }
-  if (n == 0) return BSIG_OK;
   if (S * A <= 2048 && (S + A) * 4 * sizeof(float) <= 32 * 1024) {
     const int64_t blocks = ceil_div<int64_t>(n, 4);
     hipLaunchKernelGGL(crosscorr_wave_kernel, dim3((int)std::min<int64_t>(blocks, 65536)),
-                       dim3(256), (size_t)(S + A) * 4 * sizeof(float), as_stream(stream), states,
+                       dim3(256), (size_t)(S + A) * 4 * sizeof(float), st, states,
                        actions, out, n, t_states, t_actions, sd, ad, w, use_state_diff, ld_out,
-                       nonfinite);
+                       nonfinite, fac, ld_fac);
     BSIG_CHECK_LAUNCH("crosscorr_wave");
     return BSIG_OK;
   }
-  const int vec4 = (ld_out % 4 == 0) && aligned(out, 16);
-  hipLaunchKernelGGL(crosscorr_kernel, dim3(grid_for(n)), dim3(256), lds, as_stream(stream),
+  const int vec4 = out && (ld_out % 4 == 0) && aligned(out, 16);
+  hipLaunchKernelGGL(crosscorr_kernel, dim3(grid_for(n)), dim3(256), lds, st,
                      states, actions, out, n, t_states, t_actions, sd, ad, w,
-                     use_state_diff, ld_out, vec4, nonfinite);
+                     use_state_diff, ld_out, vec4, nonfinite, fac, ld_fac);
   BSIG_CHECK_LAUNCH("crosscorr");
+  return BSIG_OK;
+}
+
+// out[r, i*A + j] = sf[i] * af[j], out[r, S*A] = mean, out[r, S*A + 1] = std  from factor rows
+__global__ __launch_bounds__(256) void crosscorr_expand_kernel(const float* __restrict__ fac,
+                                                               int64_t ld_fac, int64_t n, int S,
+                                                               int A, float* __restrict__ out,
+                                                               int64_t ld_out) {
+  const int total = S * A;
+  for (int64_t r = blockIdx.y; r < n; r += gridDim.y) {
+    const float* f = fac + r * ld_fac;
+    float* o = out + r * ld_out;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + 2; e += gridDim.x * blockDim.x) {
+      const int i = e / A, j = e - i * A;
+      o[e] = e < total ? f[i] * f[S + j] : f[S + A + (e - total)];
+    }
+  }
+}
+}  // namespace bsig
+
+extern "C" int bsig_crosscorr(const float* states, const float* actions, float* out,
+                              int64_t n, int t_states, int t_actions, int sd, int ad,
+                              int use_state_diff, int64_t ld_out, int32_t* nonfinite,
+                              bsig_stream_t stream) {
+  if (n == 0) return BSIG_OK;
+  BSIG_REQUIRE(out, "crosscorr: null pointer");
+  return crosscorr_launch(states, actions, out, ld_out, nullptr, 0, n, t_states, t_actions, sd, ad,
+                          use_state_diff, nonfinite, as_stream(stream));
+}
+
+extern "C" int bsig_crosscorr_factor_dims(int traj_len, int sd, int ad, int32_t* s_out,
+                                          int32_t* a_out) {
+  BSIG_REQUIRE(traj_len > 1 && sd >= 2 && ad >= 1 && s_out && a_out, "crosscorr_factor_dims: bad args");
+  const int w = crosscorr_window(traj_len, sd);
+  *s_out = w * (sd - 1);
+  *a_out = w * ad;
+  return BSIG_OK;
+}
+
+extern "C" int bsig_crosscorr_factors(const float* states, const float* actions, float* factors,
+                                      int64_t n, int t_states, int t_actions, int sd, int ad,
+                                      int use_state_diff, int64_t ld_factors, int32_t* nonfinite,
+                                      bsig_stream_t stream) {
+  if (n == 0) return BSIG_OK;
+  BSIG_REQUIRE(factors, "crosscorr_factors: null pointer");
+  return crosscorr_launch(states, actions, nullptr, 0, factors, ld_factors, n, t_states, t_actions,
+                          sd, ad, use_state_diff, nonfinite, as_stream(stream));
+}
+
+extern "C" int bsig_crosscorr_expand(const float* factors, int64_t ld_factors, int64_t n, int s_dim,
+                                     int a_dim, float* out, int64_t ld_out, bsig_stream_t stream) {
+  if (n == 0) return BSIG_OK;
+  BSIG_REQUIRE(factors && out && n >= 0 && s_dim >= 1 && a_dim >= 1, "crosscorr_expand: bad args");
+  BSIG_REQUIRE(ld_factors >= s_dim + a_dim + 3 && ld_out >= (int64_t)s_dim * a_dim + 2,
+               "crosscorr_expand: leading dims too small");
+  const int total = s_dim * a_dim + 2;
+  const dim3 grid(std::min(ceil_div(total, 256), 64), (unsigned)std::min<int64_t>(n, 16384));
+  hipLaunchKernelGGL(crosscorr_expand_kernel, grid, dim3(256), 0, as_stream(stream), factors,
+                     ld_factors, n, s_dim, a_dim, out, ld_out);
+  BSIG_CHECK_LAUNCH("crosscorr_expand");
   return BSIG_OK;
 }
 

@@ -19,6 +19,7 @@ import torch.nn as nn
 from . import _lib
 from . import pdf
 from . import dp as _dp
+from .summarizers import CrossCorrFactors
 
 _ACT_CODES = {nn.Tanh: _lib.ACT_TANH, nn.ReLU: _lib.ACT_RELU,
               nn.LeakyReLU: _lib.ACT_LEAKY_RELU, nn.Sigmoid: _lib.ACT_SIGMOID,
@@ -403,20 +404,46 @@ class MDNN(nn.Module):
         d, n_tot = self.output_dim, x_data.shape[0]
         n_train = max(int(n_tot * (1.0 - test_frac)), 1)
         n_test = n_tot - n_train
-        xs, ldx_src = _lib.as_f32_rows(x_data, dev)
-        ys, ldy_src = _lib.as_f32_rows(y_data, dev)
-        assert xs.shape[1] == self.input_dim and ys.shape[1] == d
         st = _lib.stream()
-        # chunk staging: fixed addresses (graph replay) and 16-B aligned rows
-        ldx, ldy = _lib.round_up(self.input_dim, 4), _lib.round_up(d, 4)
+        # plan (graphs, persistent-kernel geometry) keyed by everything baked into it
+        key = (batch_size, max(n_test, self._bufs.get('cap_test', 0)), n_updates,
+               cfg.head.eps_noise, cfg.lr, cfg.head.min_weight, cfg.head.ll_limit,
+               max(n_train, self._bufs.get('cap_train', 0)))
+        if self._plan is None or self._plan_key != key:
+            if self._plan:
+                lib.bsig_fit_destroy(self._plan)
+            handle = C.c_void_p()
+            _lib.check(lib.bsig_fit_create_sized(C.byref(cfg), batch_size, key[7], key[1],
+                                                 n_updates, C.byref(handle)))
+            self._plan, self._plan_key = handle, key
+            self._bufs['cap_test'], self._bufs['cap_train'] = key[1], key[7]
+        # a cross-correlation summary may arrive as factor rows (summarizers.CrossCorrFactors):
+        # plans whose first layer lives in the persistent kernel consume them as they are
+        factored = isinstance(x_data, CrossCorrFactors)
+        if factored and not lib.bsig_fit_accepts_factors(self._plan):
+            x_data, factored = x_data.materialize(), False
+        ldy = _lib.round_up(d, 4)
+        ys, ldy_src = _lib.as_f32_rows(y_data, dev)
+        assert x_data.shape[1] == self.input_dim and ys.shape[1] == d
         cap = self._bufs.get('cap_rows', 0)
         if n_tot > cap:
             self._bufs.pop('x_stage', None), self._bufs.pop('y_stage', None)
             self._bufs['cap_rows'] = n_tot
-        x_stage = self._buf('x_stage', self._bufs['cap_rows'] * ldx)
+        if factored:
+            # bound where they lie: 1.3 KB per Ant row instead of a 47 KB summary row
+            x_stage, _ = _lib.as_f32_rows(x_data.factors, dev)
+            ldx = x_stage.stride(0) if n_tot > 1 else x_stage.shape[1]
+            # the held-out rows, read once per evaluation, as summary rows
+            x_held = x_data[n_train:].materialize() if n_test > 0 else None
+            self._bufs['x_keepalive'] = (x_stage, x_held)
+        else:
+            # chunk staging: fixed addresses (graph replay) and 16-B aligned rows
+            xs, ldx_src = _lib.as_f32_rows(x_data, dev)
+            ldx = _lib.round_up(self.input_dim, 4)
+            x_stage = self._buf('x_stage', self._bufs['cap_rows'] * ldx)
+            _lib.check(lib.bsig_copy_rows(_lib.ptr(xs), ldx_src, None, _lib.ptr(x_stage), ldx,
+                                          n_tot, self.input_dim, st))
         y_stage = self._buf('y_stage', self._bufs['cap_rows'] * ldy)
-        _lib.check(lib.bsig_copy_rows(_lib.ptr(xs), ldx_src, None, _lib.ptr(x_stage), ldx,
-                                      n_tot, self.input_dim, st))
         if self.output_lows is not None:                       # mdnn.py:204-205
             _lib.check(lib.bsig_normalize_rows(
                 _lib.ptr(ys), ldy_src, _lib.ptr(self.output_lows),
@@ -452,18 +479,6 @@ class MDNN(nn.Module):
         train_loss = self._buf('train_loss', n_updates)
         test_loss = self._buf('test_loss', len(eval_its))
         state = self._buf('state', 16, torch.int32)
-        # plan (graphs) keyed by everything baked into the captured kernels
-        key = (batch_size, max(n_test, self._bufs.get('cap_test', 0)), n_updates,
-               cfg.head.eps_noise, cfg.lr, cfg.head.min_weight, cfg.head.ll_limit,
-               max(n_train, self._bufs.get('cap_train', 0)))
-        if self._plan is None or self._plan_key != key:
-            if self._plan:
-                lib.bsig_fit_destroy(self._plan)
-            handle = C.c_void_p()
-            _lib.check(lib.bsig_fit_create_sized(C.byref(cfg), batch_size, key[7], key[1],
-                                                 n_updates, C.byref(handle)))
-            self._plan, self._plan_key = handle, key
-            self._bufs['cap_test'], self._bufs['cap_train'] = key[1], key[7]
         ws = self._buf('fit_ws', int(lib.bsig_fit_workspace_bytes(self._plan)) // 4 + 1)
         coeff, ldc, off = self._rff_args()
         fb = _lib.FitBuffers()
@@ -475,11 +490,15 @@ class MDNN(nn.Module):
         fb.x_train, fb.ldx_train, fb.n_train = x_stage.data_ptr(), ldx, n_train
         fb.y_train, fb.ldy_train = y_stage.data_ptr(), ldy
         fb.x_test, fb.ldx_test, fb.n_test = x_stage.data_ptr() + 4 * n_train * ldx, ldx, n_test
+        if factored and n_test > 0:
+            fb.x_test, fb.ldx_test = x_held.data_ptr(), x_held.stride(0)
         fb.y_test, fb.ldy_test = y_stage.data_ptr() + 4 * n_train * ldy, ldy
         fb.ids_table = ids_dev.data_ptr()
         fb.train_loss, fb.test_loss = train_loss.data_ptr(), test_loss.data_ptr()
         fb.state = state.data_ptr()
         fb.workspace, fb.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        if factored:
+            fb.x_kind, fb.x_s, fb.x_a = _lib.X_CROSSCORR_FACTORS, x_data.s_dim, x_data.a_dim
         flags = (_lib.FIT_GRAPH if type(self).USE_GRAPH else 0) | \
             (_lib.FIT_SPLIT_ADAM if self._dp is not None else 0)
         _lib.check(lib.bsig_fit_bind(self._plan, C.byref(fb), flags))

@@ -65,6 +65,22 @@ int bsig_crosscorr(const float* states, const float* actions, float* out,
                    int use_state_diff, int64_t ld_out, int32_t* nonfinite,
                    bsig_stream_t stream);
 
+/* The cross-correlation summary in FACTORED form (no summary
+ * materialisation).  summarizers.py:106-119 builds out[i*A + j] = sf[i] * af[j]
+ * (S = W(sd-1) state features, A = W*ad action features; 47 KB per Ant row, 420 KB per
+ * ShadowHand row) plus mean(sf), std(sf).  A factor row holds what that is made of:
+ *   [ sf[0..S) | af[0..A) | mean | std | 1.0 | 0... ]   (ld_factors >= S + A + 3)
+ * and the fit engine's first layer forms the products itself, one fp32 multiply each,
+ * exactly as the summarizer would (bsig_fit_buffers.x_kind = BSIG_X_CROSSCORR_FACTORS).
+ * bsig_crosscorr_expand materialises the summary rows from factor rows. */
+int bsig_crosscorr_factor_dims(int traj_len, int sd, int ad, int32_t* s_out, int32_t* a_out);
+int bsig_crosscorr_factors(const float* states, const float* actions, float* factors,
+                           int64_t n, int t_states, int t_actions, int sd, int ad,
+                           int use_state_diff, int64_t ld_factors, int32_t* nonfinite,
+                           bsig_stream_t stream);
+int bsig_crosscorr_expand(const float* factors, int64_t ld_factors, int64_t n, int s_dim,
+                          int a_dim, float* out, int64_t ld_out, bsig_stream_t stream);
+
 /* summary_signatory, summarizers.py:144-168: truncated signature (levels
  * 1..depth, signatory layout) of the time-augmented path [l+1 | s_l | a_l].
  * depth 1..3; depth 3 needs 1+sd+ad <= 32, depth 2 needs <= 160. */
@@ -236,7 +252,16 @@ typedef struct bsig_fit_buffers {
   float* test_loss;              /* [n_evals]                              */
   int32_t* state;                /* [16] int32 engine state (reset by begin); word 2 = non-finite flag */
   void* workspace; size_t workspace_bytes;
+  /* what the x_train rows hold: the summary itself (BSIG_X_ROWS), or the factor rows of a
+   * cross-correlation summary (bsig_crosscorr_factors; cfg.input_dim = x_s*x_a + 2,
+   * ldx_train >= x_s + x_a + 3) -- accepted by plans for which bsig_fit_accepts_factors()
+   * != 0.  The training rows are the ones the updates gather over and over (12.5 visits per
+   * row and call); the held-out x_test rows, read once per evaluation, are always summary
+   * rows (bsig_crosscorr_expand of their factor rows). */
+  int32_t x_kind; int32_t x_s; int32_t x_a;
 } bsig_fit_buffers;
+#define BSIG_X_ROWS 0
+#define BSIG_X_CROSSCORR_FACTORS 1
 
 typedef struct bsig_fit_plan bsig_fit_plan;
 
@@ -297,6 +322,9 @@ int bsig_fit_pack_logs(bsig_fit_plan* plan, int64_t n_updates, float* out,
 int bsig_fit_grad(bsig_fit_plan* plan, bsig_stream_t stream);
 int bsig_fit_apply(bsig_fit_plan* plan, bsig_stream_t stream);
 int bsig_fit_flush(bsig_fit_plan* plan, bsig_stream_t stream);
+/* != 0: the plan's training rows may be cross-correlation factor rows (all its updates run
+ * in the persistent kernel of the two-layer MDNN, whose first-layer tiles form the products). */
+int bsig_fit_accepts_factors(const bsig_fit_plan* plan);
 /* 1: the plan's updates run in the persistent kernel for linear heads on cached
  * features (MDRFF), 2: in the one for the two-layer MDNN trunk (as bound), 0: as
  * per-phase kernels (diagnostics / tests). */

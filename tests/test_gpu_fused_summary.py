@@ -1,0 +1,196 @@
+"""the cross-correlation summary is never materialised for training.
+summarizers.py:106-119 builds out[i*A + j] = sf[i] * af[j] (+ mean, std); the factor rows
+[sf | af | mean | std | 1] carry the same information in S + A + 3 floats and the first-layer
+tiles of the persistent MDNN kernel form the products themselves -- one fp32 multiply each,
+so everything downstream is BITWISE what the materialised path computes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def B():
+    import bayes_sim_ig_amd as pkg
+    pkg._lib.require_gpu()
+    pkg.MDNN.VERBOSE = False
+    return pkg
+
+
+@pytest.fixture(autouse=True)
+def _guards():
+    import bayes_sim_ig_amd as pkg
+    old = pkg.MDNN.EPS_NOISE
+    yield
+    pkg.MDNN.EPS_NOISE = old
+    for k in ('BSIG_NO_FUSED_SUMMARY', 'BSIG_NO_PERSISTENT', 'BSIG_NO_INKERNEL_EVAL'):
+        os.environ.pop(k, None)
+
+
+# (n, T, sd, ad): the wavefront-per-trajectory kernel (small summaries), the workgroup one
+# (Ant: W = 5 because sd > 50), T < W (all steps), and a width with I % 4 == 2
+SHAPES = [(37, 21, 4, 1), (50, 51, 60, 8), (9, 6, 5, 2), (16, 12, 10, 8)]
+
+
+@pytest.mark.parametrize('n,t,sd,ad', SHAPES)
+@pytest.mark.parametrize('diff', [True, False])
+def test_factor_rows_expand_to_the_summary_bitwise(B, n, t, sd, ad, diff):
+    gen = torch.Generator().manual_seed(n + sd)
+    s = torch.randn(n, t, sd, generator=gen).to(DEV)
+    a = torch.rand(n, t, ad, generator=gen).to(DEV)
+    full = B.cross_correlation(s, a, use_state_diff=diff)
+    lazy = B.cross_correlation(s, a, use_state_diff=diff, lazy=True)
+    assert isinstance(lazy, B.summarizers.CrossCorrFactors)
+    assert tuple(lazy.shape) == tuple(full.shape) and len(lazy) == n
+    w = min(5 if sd > 50 else 10, t)
+    assert (lazy.s_dim, lazy.a_dim) == (w * (sd - 1), w * ad)
+    assert lazy.factors.shape[1] < full.shape[1] or full.shape[1] < 64
+    assert torch.equal(lazy.materialize(), full)          # products, mean and std: bit for bit
+    assert torch.equal(lazy[3:8].materialize(), full[3:8])
+    assert torch.equal(torch.as_tensor(lazy[:, -2:]), full[:, -2:])
+    f = lazy.factors
+    assert torch.equal(f[:, lazy.s_dim + lazy.a_dim + 2], torch.ones(n, device=DEV))
+
+
+def test_factor_rows_raise_the_finiteness_flag(B):
+    s = torch.randn(8, 12, 6)
+    a = torch.rand(8, 12, 2)
+    s[5, 3, 2] = float('inf')
+    with pytest.raises(AssertionError):
+        B.summary_corrdiff(s.to(DEV), a.to(DEV), lazy=True)      # summarizers.py:120
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    B.summary_corrdiff(s.to(DEV), a.to(DEV), lazy=True, check_finite=flag)
+    assert int(flag.item()) == 1
+    big = torch.full((2, 12, 6), 3e19)
+    big[:, :, ::2] = -3e19                                       # finite inputs, overflowing products
+    with pytest.raises(AssertionError):
+        B.summary_corrdiff(big.to(DEV), (a[:2] * 3e19).to(DEV), lazy=True)
+
+
+def _cfg(sd, ad, t, d=3, k=4, hidden=(128, 128)):
+    return dict(task='synthetic', model='MDNN', summarizer='summary_corrdiff', t=t, sd=sd, ad=ad,
+                d=d, k=k, hidden=list(hidden), n_feat=0, pairs=1000)
+
+
+def _chunk(B, cfg, lazy, n=1000, batch=100, n_updates=100, eps=1e-5, dp=False):
+    import bench
+    B.MDNN.EPS_NOISE = eps
+    theta, states, actions = bench.synth_pairs(cfg, n, 3, DEV)
+    torch.manual_seed(5)
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    if dp:
+        bs.model.enable_data_parallel()
+    ids = np.random.RandomState(5).randint(0, n - int(n * 0.2), (n_updates, batch))
+    summ = B.summary_corrdiff(states, actions, lazy=lazy)
+    torch.manual_seed(6)                                          # jitter seed
+    logs = bs.model.run_training(summ, theta, n_updates, batch, ids_table=ids)
+    return logs, bs.model._flat.clone(), bs
+
+
+# Ant (I = 11802, 47 k-slices), a Cartpole-like width with a ragged last k-slice (I = 302),
+# I = 722 (I % 4 == 2: the factor path has no alignment requirement at all)
+@pytest.mark.parametrize('sd,ad,t', [(60, 8, 51), (4, 1, 21), (10, 8, 12)])
+@pytest.mark.parametrize('eps', [0.0, 1e-5])
+def test_fused_first_layer_is_bitwise_the_materialised_fit(B, sd, ad, t, eps):
+    cfg = _cfg(sd, ad, t)
+    a = _chunk(B, cfg, lazy=False, eps=eps)
+    b = _chunk(B, cfg, lazy=True, eps=eps)
+    lib = B._lib.load()
+    assert lib.bsig_fit_is_persistent(b[2].model._plan) == 2
+    assert a[0] == b[0]                                           # 6 + 6 losses
+    assert torch.equal(a[1], b[1])                                # every weight
+    assert 'x_keepalive' in b[2].model._bufs and 'x_keepalive' not in a[2].model._bufs
+
+
+def test_fused_first_layer_ragged_minibatch_and_small_chunk(B):
+    cfg = _cfg(10, 8, 12)
+    for n, batch, nu in ((1000, 37, 23), (60, 100, 5), (400, 104, 11)):
+        a = _chunk(B, cfg, lazy=False, n=n, batch=batch, n_updates=nu)
+        b = _chunk(B, cfg, lazy=True, n=n, batch=batch, n_updates=nu)
+        assert a[0] == b[0] and torch.equal(a[1], b[1]), (n, batch, nu)
+
+
+def test_plans_that_read_summary_rows_get_them_materialised(B):
+    """A trunk the persistent kernel does not cover, and the per-phase kernels
+    (BSIG_NO_PERSISTENT=1): run_training expands the factor rows itself."""
+    cfg = _cfg(10, 8, 12, hidden=(24, 24))
+    a = _chunk(B, cfg, lazy=False)
+    b = _chunk(B, cfg, lazy=True)
+    assert B._lib.load().bsig_fit_is_persistent(b[2].model._plan) == 0
+    assert a[0] == b[0] and torch.equal(a[1], b[1])
+    os.environ['BSIG_NO_PERSISTENT'] = '1'
+    cfg = _cfg(10, 8, 12)
+    a = _chunk(B, cfg, lazy=False)
+    b = _chunk(B, cfg, lazy=True)
+    assert a[0] == b[0] and torch.equal(a[1], b[1])
+
+
+def test_bind_refuses_factor_rows_where_kernels_need_summaries(B):
+    """C ABI: bsig_fit_bind with x_kind = factors on a plan that is not covered answers
+    BSIG_EUNSUPPORTED (the Python mirror asks bsig_fit_accepts_factors first)."""
+    import ctypes as C
+    L, lib = B._lib, B._lib.load()
+    torch.manual_seed(0)
+    m = B.MDNN(input_dim=302, output_dim=2, output_lows=np.zeros(2), output_highs=np.ones(2),
+               n_gaussians=3, full_covariance=False, hidden_layers=(24, 24),
+               activation=torch.nn.Tanh, lr=1e-3, device=DEV)
+    x = torch.randn(100, 304, device=DEV)[:, :302]
+    m.run_training(x, torch.rand(100, 2, device=DEV), 5, 10)      # creates and binds a plan
+    assert lib.bsig_fit_accepts_factors(m._plan) == 0
+    fb = L.FitBuffers()
+    for name in ('params', 'grads', 'exp_avg', 'exp_avg_sq', 'x_train', 'y_train', 'ids_table',
+                 'train_loss', 'test_loss', 'state', 'workspace'):
+        setattr(fb, name, m._flat.data_ptr())
+    fb.workspace_bytes = 1 << 40
+    fb.ldx_train, fb.n_train, fb.ldy_train, fb.n_test = 64, 80, 4, 0
+    fb.x_kind, fb.x_s, fb.x_a = L.X_CROSSCORR_FACTORS, 30, 10
+    assert lib.bsig_fit_bind(m._plan, C.byref(fb), 0) == L.BSIG_EUNSUPPORTED
+    fb.x_s = 31                                                   # S*A + 2 != input_dim
+    assert lib.bsig_fit_bind(m._plan, C.byref(fb), 0) == L.BSIG_EINVAL
+    m._drop_plan()
+
+
+def test_bayessim_fit_trains_from_factor_rows(B):
+    """BayesSim.fit on an MDNN with summary_corrdiff: blocks of chunks are summarised as
+    factor rows (no [N, 11802] tensor), the result is bitwise the materialised fit."""
+    import bench
+    cfg = dict(bench.CONFIGS['cfg3'])
+    theta, states, actions = bench.synth_pairs(cfg, 3000, 7, DEV)
+    out = []
+    for env in ('1', None):
+        if env:
+            os.environ['BSIG_NO_FUSED_SUMMARY'] = env
+        else:
+            os.environ.pop('BSIG_NO_FUSED_SUMMARY', None)
+        torch.manual_seed(11)
+        bs = bench.build_gpu_model(B, cfg, DEV, 11)
+        np.random.seed(12)
+        logs = bs.fit(theta, states, actions)
+        out.append((logs, bs.model._flat.clone(), 'x_keepalive' in bs.model._bufs))
+    assert out[0][2] is False and out[1][2] is True
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+    # predict() takes the (materialised) summaries of the few real trajectories
+    mog = bs.predict(states[:1], actions[:1])
+    assert np.isfinite(mog.eval(theta[:1].cpu().numpy().astype(np.float64))).all()
+
+
+def test_data_parallel_rank_trains_from_factor_rows(B):
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29579')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        cfg = _cfg(10, 8, 12)
+        a = _chunk(B, cfg, lazy=False, dp=True)
+        b = _chunk(B, cfg, lazy=True, dp=True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert a[0] == b[0] and torch.equal(a[1], b[1])

@@ -21,7 +21,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
 cfg = dict(bench.CONFIGS[name])
 theta, states, actions = bench.synth_pairs(cfg, 1000, 3, dev)
 bs = bench.build_gpu_model(B, cfg, dev, 77)
-summ = bs._summarize(states, actions)
+summ = bs._summarize(states, actions, lazy=os.environ.get('LAZY') == '1')
 bs.model.run_training(summ, theta, 100, 100)          # warm-up (plan, graphs)
 assert lib.bsig_fit_is_persistent(bs.model._plan) == 2
 buf = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
@@ -39,6 +39,7 @@ print('%s: %d tile + %d owner + %d small-weight workgroups; mean over updates 2.
 rows = [('last tile wg has its summary tile in LDS', tiles, 1, np.max),
         ('last tile wg done with the forward MFMAs', tiles, 2, np.max),
         ('last forward flag raised', tiles, 3, np.max),
+        ('tiles: last has the next tile prefetched (factor rows only)', tiles, 8, np.max),
         ('owners: first / last start of the update', owners, 0, np.min),
         ('owners: last start of the update', owners, 0, np.max),
         ('owners: last has the small weights flags', owners, 4, np.max),
