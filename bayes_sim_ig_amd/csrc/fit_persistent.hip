@@ -179,7 +179,7 @@ __device__ __forceinline__ void tile_eval(const PersistArgs& p, const float* Wl,
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0)
-    __hip_atomic_store(p.flag_eval + wg, (unsigned)eidx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag_raise(p.flag_eval, wg, (unsigned)eidx + 1u);
 }
 
 // ---- tile workgroups: forward partial products, dW, Adam ----------------------
@@ -321,7 +321,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       if (tid_l == 0)
-        __hip_atomic_store(p.flag_fwd + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag_raise(p.flag_fwd, wg, epoch);
       BSIG_STAMP(3);
     }
 
@@ -343,7 +343,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     //   d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
     // is applied here, to this block's columns, while the tile is loaded
     if (w == 0) {
-      const float su = granule_gather(p.gran + kXwgMax, p.n_owner, epoch * 4u + 2u, lane, flagp);
+      const float su = granule_gather(p.gran + kGranArr, p.n_owner, epoch * 4u + 2u, lane, flagp);
       if (lane == 0) red[62] = p.eps_noise != 0.f ? p.eps_noise / ((float)B * (float)(p.D * p.K)) * su : 0.f;
     }
     __syncthreads();
@@ -522,7 +522,7 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
     if (tid == 0) {
       float sx = 0.f;
       for (int q = 0; q < kPT / 64; ++q) sx += red[q];
-      granule_publish(p.gran_eval + o, etag, sx);
+      granule_publish(p.gran_eval, o, etag, sx);
     }
     const int pass = w / p.R, r = w - pass * p.R;
     const int erow = pass * B + r0 + r;
@@ -552,10 +552,10 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
     if (tid == 0) {
       float sl = 0.f;
       for (int q = 0; q < kPT / 64; ++q) sl += red[16 + q];
-      granule_publish(p.gran_eval + kXwgMax + o, etag, sl);
+      granule_publish(p.gran_eval + kGranArr, o, etag, sl);
     }
     if (o == 0 && w == 0) {
-      const float sum = granule_gather(p.gran_eval + kXwgMax, p.n_owner, etag, lane, flagp);
+      const float sum = granule_gather(p.gran_eval + kGranArr, p.n_owner, etag, lane, flagp);
       if (lane == 0) {
         const float l = -sum / (float)p.n_test;
         p.test_loss[p.state[1]] = l;
@@ -603,7 +603,7 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
     if (tid == 0) {
       float sx = 0.f;
       for (int q = 0; q < kPT / 64; ++q) sx += red[q];
-      granule_publish(p.gran + o, tag + 1, sx);
+      granule_publish(p.gran, o, tag + 1, sx);
     }
     BSIG_STAMP(5);
     RowOut ro;
@@ -647,12 +647,12 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
     if (tid == 0) {
       float sl = 0.f, su = 0.f;
       for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
-      granule_publish(p.gran + kXwgMax + o, tag + 2, su);
-      granule_publish(p.gran + 2 * kXwgMax + o, tag + 3, sl);
+      granule_publish(p.gran + kGranArr, o, tag + 2, su);
+      granule_publish(p.gran + 2 * kGranArr, o, tag + 3, sl);
     }
     BSIG_STAMP(9);
     if (o == 0 && w == 0) {
-      const float s = granule_gather(p.gran + 2 * kXwgMax, p.n_owner, tag + 3, lane, flagp);
+      const float s = granule_gather(p.gran + 2 * kGranArr, p.n_owner, tag + 3, lane, flagp);
       if (lane == 0) {
         const float l = -s / (float)B;
         p.train_loss[step] = l;
@@ -748,7 +748,7 @@ bool persist_eval_supported(const PersistShape& s) {
 static size_t data_bytes(const PersistGeom& g) {
   return round_up<size_t>((g.slab_floats + 2 * g.dout_floats + g.eval_floats) * sizeof(float), 256);
 }
-static size_t sync_bytes() { return 2 * kXwgMax * sizeof(unsigned) + 5 * kXwgMax * 8; }
+static size_t sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
 
 size_t persist_workspace_bytes(const PersistShape& s) {
   PersistGeom g;
@@ -818,9 +818,9 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.eval_slabs = p.e_out + g.dout_floats;
   char* sync = base + data_bytes(g);
   p.flag_fwd = reinterpret_cast<unsigned*>(sync);
-  p.flag_eval = p.flag_fwd + kXwgMax;
-  p.gran = reinterpret_cast<unsigned long long*>(sync + 2 * kXwgMax * sizeof(unsigned));
-  p.gran_eval = p.gran + 3 * kXwgMax;
+  p.flag_eval = p.flag_fwd + kFlagArr;
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 2 * kFlagArr * sizeof(unsigned));
+  p.gran_eval = p.gran + 3 * kGranArr;
   if (b.do_eval) {
     BSIG_REQUIRE(g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
                      b.y_test && b.test_loss && b.eval_every >= 1 && b.n_total >= 1,

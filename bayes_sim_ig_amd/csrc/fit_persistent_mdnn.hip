@@ -236,7 +236,7 @@ __device__ __forceinline__ void mdnn_tile_eval(const MdnnArgs& p, const float* W
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0)
-    __hip_atomic_store(p.flag_eval + wg, (unsigned)eidx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag_raise(p.flag_eval, wg, (unsigned)eidx + 1u);
 }
 
 // ---- tile workgroups: first-layer partial products, dW1, Adam -------------------
@@ -365,7 +365,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       if (tid_l == 0)
-        __hip_atomic_store(p.flag_fwd + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag_raise(p.flag_fwd, wg, epoch);
       BSIG_MSTAMP(3);
     }
 
@@ -562,7 +562,7 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0)
-    __hip_atomic_store(p.flag_pack + sb, p.launch_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag_raise(p.flag_pack, sb, p.launch_tag);
   for (int idx = tid; idx < (p.FR - B) * kMHP; idx += kMT) Hs[B * kMHP + idx] = 0.f;
   __syncthreads();
 
@@ -651,7 +651,7 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       if (tid == 0)
-        __hip_atomic_store(p.flag_small + sb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag_raise(p.flag_small, sb, epoch);
     }
     BSIG_MSTAMP(6);
   }
@@ -836,7 +836,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     if (tid == 0) {
       float sx = 0.f;
       for (int q = 0; q < kMT / 64; ++q) sx += red[q];
-      granule_publish(p.gran_eval + o, etag, sx);
+      granule_publish(p.gran_eval, o, etag, sx);
     }
     HeadArgs ae = a;
     ae.d_out = nullptr;                      // forward only
@@ -878,10 +878,10 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     if (tid == 0) {
       float sl = 0.f;
       for (int q = 0; q < kMR; ++q) sl += red[16 + q];
-      granule_publish(p.gran_eval + kXwgMax + o, etag, sl);
+      granule_publish(p.gran_eval + kGranArr, o, etag, sl);
     }
     if (o == 0 && w == 0) {
-      const float sum = granule_gather(p.gran_eval + kXwgMax, p.n_owner, etag, lane, flagp);
+      const float sum = granule_gather(p.gran_eval + kGranArr, p.n_owner, etag, lane, flagp);
       if (lane == 0) {
         const float l = -sum / (float)p.n_test;
         p.test_loss[p.state[1]] = l;
@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     if (tid == 0) {
       float sx = 0.f;
       for (int q = 0; q < kMT / 64; ++q) sx += red[q];
-      granule_publish(p.gran + o, tag + 1, sx);
+      granule_publish(p.gran, o, tag + 1, sx);
     }
     BSIG_MSTAMP(9);
     // ---- row-wise NLL forward / backward (one wavefront per row) -----------------------
@@ -1075,8 +1075,8 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     if (tid == 0) {
       float sl = 0.f, su = 0.f;
       for (int q = 0; q < kMR; ++q) { sl += red[16 + q]; su += red[32 + q]; }
-      granule_publish(p.gran + kXwgMax + o, tag + 2, su);
-      granule_publish(p.gran + 2 * kXwgMax + o, tag + 3, sl);
+      granule_publish(p.gran + kGranArr, o, tag + 2, su);
+      granule_publish(p.gran + 2 * kGranArr, o, tag + 3, sl);
     }
     BSIG_MSTAMP(13);
     float w2b[32];
@@ -1091,7 +1091,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     {
       float c = 0.f;
       if (p.eps_noise != 0.f)
-        c = p.eps_noise / norm * granule_gather(p.gran + kXwgMax, p.n_owner, tag + 2, lane, flagp);
+        c = p.eps_noise / norm * granule_gather(p.gran + kGranArr, p.n_owner, tag + 2, lane, flagp);
       if (active) {
         const int groups = 64 / K, TPR = groups * K;
         const int k = lane % K, d0 = lane / K;
@@ -1166,10 +1166,10 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (tid == 0)
-      __hip_atomic_store(p.flag_own + o, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag_raise(p.flag_own, o, epoch);
     BSIG_MSTAMP(15);
     if (o == 0 && w == 0) {
-      const float s = granule_gather(p.gran + 2 * kXwgMax, p.n_owner, tag + 3, lane, flagp);
+      const float s = granule_gather(p.gran + 2 * kGranArr, p.n_owner, tag + 3, lane, flagp);
       if (lane == 0) {
         const float l = -s / (float)B;
         p.train_loss[step] = l;
@@ -1270,7 +1270,7 @@ static size_t mdnn_data_bytes(const MdnnGeom& g) {
   return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats + 2 * kPackFloats +
                            g.eval_floats) * sizeof(float), 256);
 }
-static size_t mdnn_sync_bytes() { return 5 * kXwgMax * sizeof(unsigned) + 5 * kXwgMax * 8; }
+static size_t mdnn_sync_bytes() { return 5 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
 
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
   MdnnGeom g;
@@ -1356,14 +1356,14 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.eval_out = p.eval_slabs + (size_t)2 * g.eval_passes * g.slab_floats;
   char* sync = base + mdnn_data_bytes(g);
   p.flag_fwd = reinterpret_cast<unsigned*>(sync);
-  p.flag_own = p.flag_fwd + kXwgMax;
-  p.flag_small = p.flag_own + kXwgMax;
-  p.flag_pack = p.flag_small + kXwgMax;
-  p.flag_eval = p.flag_pack + kXwgMax;
+  p.flag_own = p.flag_fwd + kFlagArr;
+  p.flag_small = p.flag_own + kFlagArr;
+  p.flag_pack = p.flag_small + kFlagArr;
+  p.flag_eval = p.flag_pack + kFlagArr;
   static unsigned launch_tag = 0;
   p.launch_tag = ++launch_tag;
-  p.gran = reinterpret_cast<unsigned long long*>(sync + 5 * kXwgMax * sizeof(unsigned));
-  p.gran_eval = p.gran + 3 * kXwgMax;
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 5 * kFlagArr * sizeof(unsigned));
+  p.gran_eval = p.gran + 3 * kGranArr;
   if (b.do_eval) {
     BSIG_REQUIRE(g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
                      b.x_test && b.y_test && b.test_loss && b.eval_every >= 1 && b.n_total >= 1 &&

@@ -10,6 +10,14 @@ constexpr int kSigMax = 4096;       // capacity of the exp(pre) partial-sum arra
 constexpr int kSigBlocks = 512;     // blocks of the stand-alone sigma0_sum kernel
 constexpr int kElemsPerLane = 8;    // wave kernel: register-cached elements per lane
 constexpr int kXwgMax = 256;        // persistent kernel: at most this many workgroups
+// Cross-workgroup flags / granules sit one per 64-byte block: a fan-in of 144 flags polled by
+// 100 workgroups costs 2.75 us when the flags are consecutive dwords (every poller hammers the
+// same few lines of one memory channel) and 1.4 us at this spacing
+// (tools/micro/fanin_bench.hip, profiles/r02_fanin_bench.txt).
+constexpr int kFlagStride = 16;                       // dwords between two flags
+constexpr int kGranStride = 8;                        // 8-byte granules between two granules
+constexpr int kFlagArr = kXwgMax * kFlagStride;       // dwords of one flag array
+constexpr int kGranArr = kXwgMax * kGranStride;       // granule slots of one granule array
 
 struct HeadArgs {
   const float* seg_w; int64_t ld_w;    // logits (fused) or weights (tuple), K / row
@@ -181,8 +189,9 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
 // inside a kernel), polled by lane g (+64, +128, +192) of every consuming wave
 // and summed in granule order (bitwise reproducible).  The poll is bounded and
 // raises bit 1 of `flag` instead of hanging.
-__device__ inline void granule_publish(unsigned long long* g, uint32_t tag, float v) {
-  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
+// (array `g`, slot `slot`)
+__device__ inline void granule_publish(unsigned long long* g, int slot, uint32_t tag, float v) {
+  __hip_atomic_store(g + slot * kGranStride, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ inline float granule_gather(unsigned long long* g, int G, uint32_t tag, int lane,
@@ -196,7 +205,7 @@ __device__ inline float granule_gather(unsigned long long* g, int G, uint32_t ta
     for (int u = 0; u < 4; ++u) {
       if (!ok[u]) {
         const unsigned long long x =
-            __hip_atomic_load(g + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_load(g + (lane + 64 * u) * kGranStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(x >> 32) == tag) { ok[u] = true; v[u] = __uint_as_float((uint32_t)x); }
       }
     }
@@ -210,6 +219,9 @@ __device__ inline float granule_gather(unsigned long long* g, int G, uint32_t ta
   return (wave_sum_dpp(v[0]) + wave_sum_dpp(v[1])) + (wave_sum_dpp(v[2]) + wave_sum_dpp(v[3]));
 }
 
+__device__ inline void flag_raise(unsigned* flags, int slot, unsigned epoch) {
+  __hip_atomic_store(flags + slot * kFlagStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // wait until flags[0..G) >= epoch (G <= 256; one wavefront polls)
 __device__ inline void flags_wait(unsigned* flags, int G, unsigned epoch, int lane, int32_t* flag) {
   bool ok[4];
@@ -219,7 +231,7 @@ __device__ inline void flags_wait(unsigned* flags, int G, unsigned epoch, int la
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (!ok[u])
-        ok[u] = __hip_atomic_load(flags + lane + 64 * u, __ATOMIC_RELAXED,
+        ok[u] = __hip_atomic_load(flags + (lane + 64 * u) * kFlagStride, __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_AGENT) >= epoch;
     if (__all(ok[0] && ok[1] && ok[2] && ok[3])) break;
     if (spin > (1u << 18)) {
