@@ -259,6 +259,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     biasl[64 + n] = bv;
   };
 
+  if (tid == 0) red[63] = 0.f;
   // feature tile of the first update (later ones are fetched during the waits)
   BSIG_PF_LIST(BSIG_PF_DECL)
   if (p.n_updates > 0) {
@@ -276,7 +277,7 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     asm volatile("" : "+v"(tid_l), "+v"(l31_l), "+v"(h_l), "+v"(kcol_l));
     const int step = step0 + t;
     const unsigned epoch = (unsigned)step + 1u;
-    if (run_aborted(flagp, red, tid_l)) break;
+    if (red[63] != 0.f) break;   // time-out bit as sampled during the previous update's wait
     BSIG_STAMP(0);
     // ---- 1. feature tile -> LDS ---------------------------------------------
     BSIG_PF_LIST(BSIG_PF_STORE)
@@ -329,6 +330,10 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     //      (this tile still holds those weights), next feature tile, Adam scalars ------
     if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
       tile_eval(p, Wl, X, biasl, evals_before(step, p.eval_every) - 1);
+    // the time-out bit (set by any bounded poll on the chip), sampled off the critical path:
+    // tested at the top of the next update
+    if (tid_l == 0)
+      red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
     if (t + 1 < p.n_updates) {
       const int64_t pf_row0 = (int64_t)(step + 1) * B;
       BSIG_PF_LIST(BSIG_PF_LOAD)

@@ -304,6 +304,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     biasl[64 + n] = bv;
   };
 
+  if (tid == 0) red[63] = 0.f;
   BSIG_MPF_LIST(BSIG_MPF_DECL)
   if (p.n_updates > 0) {
     const int64_t pf_row0 = (int64_t)step0 * B;
@@ -320,7 +321,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     asm volatile("" : "+v"(tid_l), "+v"(l31_l), "+v"(h_l), "+v"(kcol_l));
     const int step = step0 + t;
     const unsigned epoch = (unsigned)step + 1u;
-    if (run_aborted(flagp, red, tid_l)) break;
+    if (red[63] != 0.f) break;   // time-out bit as sampled during the previous update's wait
     BSIG_MSTAMP(0);
     // ---- 1. summary tile -> LDS ------------------------------------------------
     BSIG_MPF_LIST(BSIG_MPF_STORE)
@@ -373,6 +374,10 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     //      still holds those weights), next summary tile, Adam scalars -------------------
     if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
       mdnn_tile_eval(p, Wl, X, biasl, mdnn_evals_before(step, p.eval_every) - 1);
+    // the time-out bit (set by any bounded poll on the chip), sampled off the critical path:
+    // tested at the top of the next update
+    if (tid_l == 0)
+      red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
     if (t + 1 < p.n_updates) {
       const int64_t pf_row0 = (int64_t)(step + 1) * B;
       FacCols fcols{};

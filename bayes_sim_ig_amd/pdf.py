@@ -16,7 +16,7 @@ Deviations from the reference, on purpose:
     (the reference reads a non-existent ``x.sigma``, pdf.py:549-554);
   * ``MoG.__mul__`` / ``__truediv__`` use the correct product/quotient
     normaliser (the reference's transcription flips one sign, pdf.py:511,533);
-  * Halton sampling uses the plain Halton sequence of rff.halton_points
+  * Halton sampling uses the scrambled Halton sequence of rff.halton_points
     (``ghalton`` is not available).
 """
 import numpy as np

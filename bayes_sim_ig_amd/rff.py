@@ -16,31 +16,26 @@ from . import _lib
 _STUDENT_NU = {'Laplace': 1, 'Matern12': 1, 'Matern32': 3, 'Matern52': 5}
 
 
-def _first_primes(n):
-    primes, cand = [], 2
-    while len(primes) < n:
-        if all(cand % p for p in primes if p * p <= cand):
-            primes.append(cand)
-        cand += 1
-    return primes
+HALTON_SEED = 20231002   # fixed: the reference's sequence is deterministic too
 
 
 def halton_points(m, d):
-    """Plain Halton sequence, points 1..m, in (0,1)^d.  The reference uses
-    ``ghalton.GeneralizedHalton(EA_PERMS)`` (rff.py:113-116) — a third-party
-    module whose permutation tables are not available here; this is a
-    documented stand-in (PARITY UNPINNED for input_dim <= 100; pass ``freqs=``
-    to inject the reference's frequencies)."""
-    out = np.empty((m, d))
-    for j, base in enumerate(_first_primes(d)):
-        for i in range(1, m + 1):
-            f, r, k = 1.0, 0.0, i
-            while k > 0:
-                f /= base
-                r += f * (k % base)
-                k //= base
-            out[i - 1, j] = r
-    return out
+    """m low-discrepancy points in (0,1)^d for the quasi-random frequency draw.
+
+    The reference uses ``ghalton.GeneralizedHalton(ghalton.EA_PERMS[:d])`` (rff.py:113-116):
+    a Halton sequence whose digits are permuted per dimension -- a third-party module whose
+    permutation tables are not available here (PARITY UNPINNED for input_dim <= 100; pass
+    ``freqs=`` to inject the reference's frequencies).  The stand-in is scipy's Owen-scrambled
+    Halton sequence with a fixed seed: like the generalized sequence it breaks the
+    dimension-to-dimension correlation of the plain one, whose coordinates with a prime
+    base above m are all the same ramp i/p (for m = 100, d = 40, the pendulum MDRFF of
+    regression_tests.py:104-128, 16 % of the coordinate pairs of the PLAIN sequence
+    correlate above 0.5 and 14 coordinates are one-sided; tests/test_host_logic.py bounds
+    both here)."""
+    from scipy.stats import qmc
+    pts = qmc.Halton(d=int(d), scramble=True, seed=HALTON_SEED).random(int(m))
+    tiny = 2.0 ** -24
+    return np.clip(pts, tiny, 1.0 - tiny)
 
 
 def _inv_cdf(kernel, u):

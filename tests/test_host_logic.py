@@ -159,3 +159,24 @@ def test_pdf_matches_reference():
     back = (mog * prior) / prior
     np.testing.assert_allclose(back.a, mog.a, rtol=1e-9)
     np.testing.assert_allclose(back.xs[0].m, mog.xs[0].m, rtol=1e-8, atol=1e-10)
+
+
+def test_quasi_random_frequencies_are_not_collinear():
+    """RFF with input_dim <= 100 draws its frequencies from a low-discrepancy sequence
+    (reference rff.py:113-117 via mdrff.py:23).  A PLAIN Halton sequence would make every
+    coordinate with a prime base above m the same ramp (for m = 100, I = 40: 14 collinear,
+    one-sided columns); the stand-in for ghalton's generalized sequence must not."""
+    import numpy as np
+    from bayes_sim_ig_amd import rff
+    m, d = 100, 40                          # BayesSim's default nFeat = 200 on pendulum summary_start
+    pts = rff.halton_points(m, d)
+    assert pts.shape == (m, d) and pts.min() > 0.0 and pts.max() < 1.0
+    assert np.array_equal(pts, rff.halton_points(m, d))          # deterministic
+    f = rff.draw_freqs('RBF', m, d, quasi_random=True)
+    c = np.corrcoef(f.T)
+    np.fill_diagonal(c, 0.0)
+    assert np.abs(c).max() < 0.5                                 # iid normal columns: ~0.3
+    assert np.abs(f.mean(0)).max() < 0.3 and 0.8 < f.std(0).min() and f.std(0).max() < 1.2
+    # low discrepancy survives the scrambling: every coordinate fills its 10 deciles evenly
+    counts = np.stack([np.histogram(pts[:, j], bins=10, range=(0, 1))[0] for j in range(d)])
+    assert counts.min() >= 5 and counts.max() <= 15           # iid uniform: 2..20
