@@ -314,15 +314,27 @@ enum { ST_STEP = 0, ST_EVAL = 1, ST_NONFINITE = 2, ST_ADAM0 = 4, ST_ADAM1 = 5,
        ST_RNG = 8 /* 4 words: seed, counter (uint64 x2) */,
        ST_BETA_POW = 12 /* 4 words: beta1^t, beta2^t (double x2) */, ST_WORDS = 16 };
 
-__global__ void fit_begin_kernel(int32_t* state, uint64_t seed) {
-  if (threadIdx.x < ST_WORDS) state[threadIdx.x] = 0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    reinterpret_cast<uint64_t*>(state + ST_RNG)[0] = seed;
-    reinterpret_cast<uint64_t*>(state + ST_RNG)[1] = 1;
-    reinterpret_cast<double*>(state + ST_BETA_POW)[0] = 1.0;   // beta1^0, beta2^0
-    reinterpret_cast<double*>(state + ST_BETA_POW)[1] = 1.0;
+// Start of a run_training call: reset the state block and clear what the call needs cleared
+// (a fresh optimizer's moments, mdnn.py:203, unless the persistent kernels start them in
+// registers; the persistent kernels' flags / granules) -- ONE launch, no runtime memsets.
+struct BeginZero { float4* ptr[4]; int64_t n4[4]; };
+__global__ __launch_bounds__(256) void fit_begin_kernel(int32_t* state, uint64_t seed, BeginZero z) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < ST_WORDS) state[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      reinterpret_cast<uint64_t*>(state + ST_RNG)[0] = seed;
+      reinterpret_cast<uint64_t*>(state + ST_RNG)[1] = 1;
+      reinterpret_cast<double*>(state + ST_BETA_POW)[0] = 1.0;   // beta1^0, beta2^0
+      reinterpret_cast<double*>(state + ST_BETA_POW)[1] = 1.0;
+    }
   }
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.n4[r];
+         i += (int64_t)gridDim.x * blockDim.x)
+      z.ptr[r][i] = zero;
 }
 
 __global__ void iota_mod_kernel(int32_t* out, int n, int mod) {
@@ -349,6 +361,7 @@ struct bsig_fit_plan {
   bool hoist;                  // RFF projection once per run_training call
   bool feat_unique;            // ... of the distinct training rows (else of every gathered minibatch row)
   bool feats_preloaded;        // ... already handed over by the caller (bsig_fit_set_features)
+  const float* ext_feats;      // ... and read where they lie (this call only) instead of copied
   int64_t feat_rows;           // rows of the hoisted feature block (+ max_test)
   int64_t max_train;           // caller's bound on n_train (0: none)
   bsig_fit_buffers buf;
@@ -381,7 +394,8 @@ static void plan_mem(const bsig_fit_plan* p, PlanMem* m) {
   base += p->train_ws_bytes;
   carve(&p->cfg, p->L, std::max<int64_t>(p->max_test, 1), base, &m->te);
   base += p->test_ws_bytes;
-  m->feats = reinterpret_cast<float*>(base); base += p->feats_bytes;
+  m->feats = p->ext_feats ? const_cast<float*>(p->ext_feats) : reinterpret_cast<float*>(base);
+  base += p->feats_bytes;
   m->big_ws = reinterpret_cast<float*>(base); base += p->big_gemm_ws_bytes;
   m->iota = reinterpret_cast<int32_t*>(base); base += p->iota_bytes;
   m->persist_ws = base;
@@ -816,10 +830,17 @@ extern "C" int bsig_fit_set_features(bsig_fit_plan* p, const float* feats, int64
   BSIG_REQUIRE(rows == p->buf.n_train + p->buf.n_test && ld_feats >= p->cfg.rff_feats,
                "fit_set_features: need the %lld training + %lld held-out rows",
                (long long)p->buf.n_train, (long long)p->buf.n_test);
-  PlanMem m; plan_mem(p, &m);
-  const size_t w = (size_t)p->cfg.rff_feats * sizeof(float);
-  BSIG_HIP(hipMemcpy2DAsync(m.feats, w, feats, (size_t)ld_feats * sizeof(float), w, (size_t)rows,
-                            hipMemcpyDeviceToDevice, as_stream(stream)));
+  p->ext_feats = nullptr;
+  if (ld_feats == p->cfg.rff_feats && aligned(feats, 16)) {
+    // a dense block of feature rows: the kernels read it in place (the caller keeps it alive
+    // until the call's work has been enqueued and run)
+    p->ext_feats = feats;
+  } else {
+    PlanMem m; plan_mem(p, &m);
+    const size_t w = (size_t)p->cfg.rff_feats * sizeof(float);
+    BSIG_HIP(hipMemcpy2DAsync(m.feats, w, feats, (size_t)ld_feats * sizeof(float), w, (size_t)rows,
+                              hipMemcpyDeviceToDevice, as_stream(stream)));
+  }
   p->feats_preloaded = true;
   return BSIG_OK;
 }
@@ -830,24 +851,41 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
   BSIG_REQUIRE(norm_batch >= 1, "fit_begin: norm_batch must be >= 1");
   if (norm_batch != p->norm_batch) { drop_graphs(p); p->norm_batch = norm_batch; }
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(fit_begin_kernel, dim3(1), dim3(64), 0, st, p->buf.state, seed);
-  BSIG_CHECK_LAUNCH("fit_begin");
   p->adam_pending = false;
   p->dp_evals_done = 0;
-  if (p->persistent) {
+  BeginZero bz{};
+  int nz = 0;
+  int64_t total4 = 0;
+  auto add_zero = [&](void* ptr, size_t bytes) {
+    bz.ptr[nz] = reinterpret_cast<float4*>(ptr);
+    bz.n4[nz] = (int64_t)(bytes / 16);
+    total4 += bz.n4[nz];
+    ++nz;
+  };
+  if (p->persistent || p->persistent_mdnn) {
     PlanMem m; plan_mem(p, &m);
-    BSIG_TRY(persist_reset(persist_shape(p), m.persist_ws, p->persist_bytes, st));
+    ZeroRegion zr[2];
+    if (p->persistent) BSIG_TRY(persist_reset_regions(persist_shape(p), m.persist_ws, p->persist_bytes, zr));
+    else BSIG_TRY(persist_mdnn_reset_regions(persist_mdnn_shape(p), m.persist_ws, p->persist_bytes, zr));
+    BSIG_REQUIRE(aligned(zr[0].ptr, 16) && aligned(zr[1].ptr, 16) && zr[0].bytes % 16 == 0 &&
+                 zr[1].bytes % 16 == 0, "fit_begin: persistent workspace regions must be 16-byte multiples");
+    add_zero(zr[0].ptr, zr[0].bytes);
+    add_zero(zr[1].ptr, zr[1].bytes);
   }
-  if (p->persistent_mdnn) {
-    PlanMem m; plan_mem(p, &m);
-    BSIG_TRY(persist_mdnn_reset(persist_mdnn_shape(p), m.persist_ws, p->persist_bytes, st));
+  // fresh optimizer state for every run_training call (mdnn.py:203); a single-rank plan in a
+  // persistent kernel starts the moments at zero in its registers instead
+  if (!((p->persistent || p->persistent_mdnn) && !p->split_adam)) {
+    BSIG_REQUIRE(aligned(p->buf.exp_avg, 16) && aligned(p->buf.exp_avg_sq, 16),
+                 "fit_begin: the Adam moment buffers must be 16-byte aligned");
+    add_zero(p->buf.exp_avg, (size_t)p->L.total * sizeof(float));
+    add_zero(p->buf.exp_avg_sq, (size_t)p->L.total * sizeof(float));
   }
-  // fresh optimizer state for every run_training call (mdnn.py:203)
-  BSIG_HIP(hipMemsetAsync(p->buf.exp_avg, 0, (size_t)p->L.total * sizeof(float), st));
-  BSIG_HIP(hipMemsetAsync(p->buf.exp_avg_sq, 0, (size_t)p->L.total * sizeof(float), st));
+  const int blocks = (int)std::min<int64_t>(std::max<int64_t>(ceil_div<int64_t>(total4, 256 * 4), 1), 1024);
+  hipLaunchKernelGGL(fit_begin_kernel, dim3(blocks), dim3(256), 0, st, p->buf.state, seed, bz);
+  BSIG_CHECK_LAUNCH("fit_begin");
   if (p->hoist) {
     if (p->feats_preloaded) p->feats_preloaded = false;   // handed over for this call
-    else BSIG_TRY(enqueue_hoisted_rff(p, st));
+    else { p->ext_feats = nullptr; BSIG_TRY(enqueue_hoisted_rff(p, st)); }
   }
   return ensure_graphs(p);
 }

@@ -211,6 +211,9 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
   const bool col_ok = k0 + kcol < p.Fdim;
   constexpr bool dp = DP;
   const bool pend = DP && p.adam_pending != 0;
+  // first launch of a run_training call: a fresh optimizer (mdnn.py:203) -- the moments start
+  // at zero in the registers, nobody has to clear (or read) the 2 x 4.3 MB in memory
+  const bool fresh = !DP && step0 == 0;
   // data-parallel: Adam scalars of the update whose reduced gradients are pending
   const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
   const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
@@ -221,7 +224,8 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     Mr[i] = 0.f; Vr[i] = 0.f;
     if (n < Nh && col_ok) {
       const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + kcol;
-      wv = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+      wv = p.params[off];
+      if (!fresh) { Mr[i] = p.m1[off]; Vr[i] = p.m2[off]; }
       if (pend) {
         // (a data-parallel launch changes the tile only here: written back at once,
         // the stores drain under the forward product)
@@ -234,8 +238,8 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
   if (ks == 0 && tid < kNB) {
     const int n = n0 + tid;
     float bw = n < Nh ? p.params[p.b_off + n] : 0.f;
-    float bm = n < Nh ? p.m1[p.b_off + n] : 0.f;
-    float bv = n < Nh ? p.m2[p.b_off + n] : 0.f;
+    float bm = n < Nh && !fresh ? p.m1[p.b_off + n] : 0.f;
+    float bv = n < Nh && !fresh ? p.m2[p.b_off + n] : 0.f;
     if (pend && n < Nh) {
       bw = adam_bias(p.grads[p.b_off + n], bm, bv, bw, pa0, pa1, ak);
       p.params[p.b_off + n] = bw; p.m1[p.b_off + n] = bm; p.m2[p.b_off + n] = bv;
@@ -761,7 +765,8 @@ size_t persist_workspace_bytes(const PersistShape& s) {
   return data_bytes(g) + sync_bytes();
 }
 
-int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes, hipStream_t st) {
+int persist_reset_regions(const PersistShape& s, void* workspace, size_t workspace_bytes,
+                          ZeroRegion* regions) {
   PersistGeom g;
   BSIG_REQUIRE(persist_geom(s, &g), "persistent updates: shape not covered");
   BSIG_REQUIRE(workspace && workspace_bytes >= persist_workspace_bytes(s),
@@ -769,8 +774,8 @@ int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes
   char* base = reinterpret_cast<char*>(workspace);
   const size_t slab_bytes = g.slab_floats * sizeof(float);
   // d_out / exp(pre) rows (their padding columns stay zero), flags and granules
-  BSIG_HIP(hipMemsetAsync(base + slab_bytes, 0, 2 * g.dout_floats * sizeof(float), st));
-  BSIG_HIP(hipMemsetAsync(base + data_bytes(g), 0, sync_bytes(), st));
+  regions[0] = ZeroRegion{base + slab_bytes, 2 * g.dout_floats * sizeof(float)};
+  regions[1] = ZeroRegion{base + data_bytes(g), sync_bytes()};
   return BSIG_OK;
 }
 

@@ -264,6 +264,9 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   const int kcol = 32 * w + l31;
   const bool col_ok = k0 + kcol < p.I;
   const bool pend = DP && p.adam_pending != 0;
+  // first launch of a run_training call: a fresh optimizer (mdnn.py:203) -- the moments start
+  // at zero in the registers, nobody has to clear (or read) them in memory
+  const bool fresh = !DP && step0 == 0;
   const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
   const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
 #pragma unroll
@@ -273,7 +276,8 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     Mr[i] = 0.f; Vr[i] = 0.f;
     if (col_ok) {
       const int64_t off = p.w1_off + (int64_t)n * p.I + k0 + kcol;
-      wv = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+      wv = p.params[off];
+      if (!fresh) { Mr[i] = p.m1[off]; Vr[i] = p.m2[off]; }
       if (pend) {   // written back at once: a data-parallel launch changes the tile only here
         wv = adam_weight(p.grads[off], Mr[i], Vr[i], wv, pa0, pa1, ak);
         p.params[off] = wv; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
@@ -283,7 +287,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   }
   if (ks == 0 && tid < kMNB) {
     const int64_t off = p.b1_off + n0 + tid;
-    float bw = p.params[off], bm = p.m1[off], bv = p.m2[off];
+    float bw = p.params[off], bm = fresh ? 0.f : p.m1[off], bv = fresh ? 0.f : p.m2[off];
     if (pend) {
       bw = adam_bias(p.grads[off], bm, bv, bw, pa0, pa1, ak);
       p.params[off] = bw; p.m1[off] = bm; p.m2[off] = bv;
@@ -522,6 +526,7 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
   const AdamK ak{1.0f - (float)p.beta1, (float)p.beta2, 1.0f - (float)p.beta2, p.adam_eps};
 
   const bool pend = DP && p.adam_pending != 0;
+  const bool fresh = !DP && step0 == 0;      // fresh optimizer: the moments start at zero
   const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
   const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
   // waves 0-3: element i of lane (h, l31) of wave w <-> W[n0 + acc_row(i, h)][32w + l31]
@@ -533,7 +538,8 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
     Wr[i] = 0.f; Mr[i] = 0.f; Vr[i] = 0.f;
     if (w < 4 && n < nrows) {
       const int64_t off = w_off + (int64_t)n * kMH + kcol;
-      Wr[i] = p.params[off]; Mr[i] = p.m1[off]; Vr[i] = p.m2[off];
+      Wr[i] = p.params[off];
+      if (!fresh) { Mr[i] = p.m1[off]; Vr[i] = p.m2[off]; }
       if (pend) {
         Wr[i] = adam_weight(p.grads[off], Mr[i], Vr[i], Wr[i], pa0, pa1, ak);
         xwg_store(p.params + off, Wr[i]); p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
@@ -557,7 +563,8 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
   float bw = 0.f, bm = 0.f, bv = 0.f;
   if (bias_lane) {
     const int64_t off = b_off + n0 + lane;
-    bw = p.params[off]; bm = p.m1[off]; bv = p.m2[off];
+    bw = p.params[off];
+    if (!fresh) { bm = p.m1[off]; bv = p.m2[off]; }
     if (pend) {
       bw = adam_bias(p.grads[off], bm, bv, bw, pa0, pa1, ak);
       xwg_store(p.params + off, bw); p.m1[off] = bm; p.m2[off] = bv;
@@ -1283,8 +1290,8 @@ size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
   return mdnn_data_bytes(g) + mdnn_sync_bytes();
 }
 
-int persist_mdnn_reset(const PersistMdnnShape& s, void* workspace, size_t workspace_bytes,
-                       hipStream_t st) {
+int persist_mdnn_reset_regions(const PersistMdnnShape& s, void* workspace, size_t workspace_bytes,
+                               ZeroRegion* regions) {
   MdnnGeom g;
   BSIG_REQUIRE(mdnn_geom(s, &g), "persistent MDNN updates: shape not covered");
   BSIG_REQUIRE(workspace && workspace_bytes >= persist_mdnn_workspace_bytes(s),
@@ -1292,8 +1299,8 @@ int persist_mdnn_reset(const PersistMdnnShape& s, void* workspace, size_t worksp
   char* base = reinterpret_cast<char*>(workspace);
   const size_t slab_bytes = g.slab_floats * sizeof(float);
   // activations / gradients (padding columns of d_out stay zero), flags and granules
-  BSIG_HIP(hipMemsetAsync(base + slab_bytes, 0, (4 * g.act_floats + g.dout_floats) * sizeof(float), st));
-  BSIG_HIP(hipMemsetAsync(base + mdnn_data_bytes(g), 0, mdnn_sync_bytes(), st));
+  regions[0] = ZeroRegion{base + slab_bytes, (4 * g.act_floats + g.dout_floats) * sizeof(float)};
+  regions[1] = ZeroRegion{base + mdnn_data_bytes(g), mdnn_sync_bytes()};
   return BSIG_OK;
 }
 

@@ -46,8 +46,11 @@ bool persist_supported(const PersistShape& s);
 // ... and the held-out evaluations of up to s.max_test rows can run inside the launches
 bool persist_eval_supported(const PersistShape& s);
 size_t persist_workspace_bytes(const PersistShape& s);
-// zero the cross-workgroup flags / gradient staging (once per fit call)
-int persist_reset(const PersistShape& s, void* workspace, size_t workspace_bytes, hipStream_t st);
+// what must be zero at the start of a fit call (cross-workgroup flags, granules, the padding of
+// the d_out rows): two regions of the workspace, cleared by the engine's begin kernel
+struct ZeroRegion { void* ptr; size_t bytes; };
+int persist_reset_regions(const PersistShape& s, void* workspace, size_t workspace_bytes,
+                          ZeroRegion* regions);
 // n consecutive updates starting at the state block's step counter; advances
 // the counter, the jitter RNG stream and the Adam bias-correction powers
 int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyper& h, int n,

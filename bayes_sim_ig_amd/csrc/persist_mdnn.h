@@ -43,8 +43,9 @@ bool persist_mdnn_supported(const PersistMdnnShape& s);
 // ... and the held-out evaluations of up to s.max_test rows can run inside the launches
 bool persist_mdnn_eval_supported(const PersistMdnnShape& s);
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s);
-int persist_mdnn_reset(const PersistMdnnShape& s, void* workspace, size_t workspace_bytes,
-                       hipStream_t st);
+struct ZeroRegion;   // persist.h
+int persist_mdnn_reset_regions(const PersistMdnnShape& s, void* workspace, size_t workspace_bytes,
+                               ZeroRegion* regions);
 // n consecutive updates starting at the state block's step counter; advances the
 // counter, the jitter RNG stream and the Adam bias-correction powers
 int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,

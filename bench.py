@@ -549,6 +549,38 @@ def scaled_nll_check(pkg, cfg, theta, states, actions, device, batch, n=20000, n
         pkg.MDNN.EPS_NOISE = old
 
 
+def per_config_numbers(pkg, device, skip):
+    """The other BASELINE-shaped configs under the same clock (short fits: 10 chunks each):
+    pairs/s of BayesSim.fit, time per update of the persistent kernel (HIP events through the
+    C ABI), teacher-forced held-out NLL vs the oracle."""
+    out = {}
+    for name in ('cfg2', 'cfg3', 'cfg4', 'cfg4b', 'cfg5'):
+        if name == skip:
+            continue
+        cfg = dict(CONFIGS[name])
+        n = 10_000
+        theta, states, actions = synth_pairs(cfg, n, 1234, device)
+        bs = build_gpu_model(pkg, cfg, device, 1234)
+        np.random.seed(1234)
+        bs.fit(theta, states, actions)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            bs.fit(theta, states, actions)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        roof = time_dominant_kernel(pkg, cfg, bs, device)
+        nll = nll_check(pkg, cfg, theta, states, actions, device)
+        out[name] = {'workload': '%s %s %s (I=%d), %d pairs' % (cfg['task'], cfg['model'], cfg['summarizer'],
+                                                               bs.model.input_dim, n),
+                     'pairs_per_s': n / dt, 'us_per_update': roof.get('us_per_update'),
+                     'roofline_frac': roof.get('frac'), 'kernel': roof['kernel'].split(':')[0],
+                     'nll_rel_diff': nll['rel_diff']}
+        del bs, theta, states, actions
+        torch.cuda.empty_cache()
+    return out
+
+
 T0 = time.perf_counter()
 
 
@@ -581,6 +613,8 @@ def main():
     ap.add_argument('--no-scaled-batch', action='store_true')
     ap.add_argument('--only-scaled-batch', action='store_true',
                     help='run the scaled-batch mode alone (for profiling) and print its JSON')
+    ap.add_argument('--no-per-config', action='store_true',
+                    help='skip the short fits of the other BASELINE-shaped configs')
     ap.add_argument('--variants', action='store_true',
                     help='also time the fit with the persistent kernel / feature cache / RFF hoist off')
     ap.add_argument('--watchdog', type=int, default=int(os.environ.get('BENCH_WATCHDOG', 1700)),
@@ -726,6 +760,9 @@ def main():
                         for k in env:
                             del os.environ[k]
                 note('variants done')
+            if not args.no_per_config:
+                out['per_config'] = per_config_numbers(pkg, device, args.config)
+                note('per-config numbers done')
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(cfg, theta[:12000], states[:12000],
                                                    actions[:12000])
