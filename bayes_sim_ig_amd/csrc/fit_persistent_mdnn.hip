@@ -78,6 +78,15 @@ struct MdnnArgs {
   float* w2f_pack;   // [2][8 waves][8 tt][2][64 lanes][2]: W2[16w + c16][16tt + 4g + 2half + e]
   float* w2b_pack;   // [2][8 waves][8 tt][2][64 lanes][2]: W2[16tt + 4g + 2half + e][16w + c16]
   unsigned* flag_fwd; unsigned* flag_own; unsigned* flag_small; unsigned* flag_pack;
+  // WIDE heads (Nh > 272: the head matrix no longer fits the row owners' LDS next to their
+  // activations -- the reference YAMLs' 10 components with D > 13, cfg/ant.yaml:69-70): the
+  // head-block workgroups, which hold 32 rows of the head matrix anyway, form the head outputs
+  // and their share of d_out Wh for ALL minibatch rows; per update owners -> (h2) -> head blocks
+  // -> (o_wide) -> owners -> (d_out) -> head blocks -> (dz2_part) -> owners
+  int wide, n_hb;
+  float* o_wide;     // [B][NhP]        raw head outputs, bias included
+  float* dz2_part;   // [n_hb][B][128]  partial d_out Wh of each head block
+  unsigned* flag_h2; unsigned* flag_o; unsigned* flag_dout; unsigned* flag_dz2;
   unsigned launch_tag;   // flag_pack value of THIS launch: the small weights (and the W2 packs)
                          // as of its start are out, one flag per small-weight workgroup
   unsigned long long* gran;
@@ -503,11 +512,14 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
 }
 
 // ---- small-weight workgroups: 32 rows of W2 or of the head matrix ----------------
-template <bool DP>
+template <bool DP, bool WIDE>
 __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* smem) {
   float* Hs = smem;                          // [FR][kMHP] input activations of the layer
   float* X = Hs + p.FR * kMHP;               // [32][FR + 4] output gradients, transposed
   float* red = X + kMNB * (p.FR + 4);        // [64]
+  float* Wb = red + 64;                      // wide heads: [32][kMHP] this block's weights, operand order
+  float* Xo = Wb + kMNB * kMHP;              // ... [128][33] k-half exchange of the head-output product
+  float* bsh = Xo + 128 * kMPbuf;            // ... [32] this block's biases
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int sb = blockIdx.x - p.G1 - p.n_owner;
@@ -519,6 +531,8 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
   const int dpitch = is_w2 ? kMH : p.NhP;
   const float* hsrc = is_w2 ? p.h1 : p.h2;
   const int B = p.B, DOP = p.FR + 4;
+  const bool whead = WIDE && !is_w2;         // forms head outputs / d_out Wh for all rows (MdnnArgs)
+  const int hb = sb - kMH / kMNB;
   int32_t* flagp = p.state + 2;
   const int step0 = p.state[0];
   double b1t = reinterpret_cast<const double*>(p.state + 12)[0];
@@ -570,6 +584,15 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
       xwg_store(p.params + off, bw); p.m1[off] = bm; p.m2[off] = bv;
     }
   }
+#define BSIG_REFRESH_OPERAND_COPY()                                                        \
+  if constexpr (WIDE) {                                                                     \
+    if (whead && w < 4) {                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) Wb[acc_row(i, h) * kMHP + kcol] = Wr[i]; \
+    } else if (whead && w == 4 && lane < kMNB) {                                            \
+      bsh[lane] = bw;                                                                       \
+    }                                                                                       \
+  }
+  BSIG_REFRESH_OPERAND_COPY()
   // the weights as of the start of this launch are out (owners wait for every block)
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
@@ -586,37 +609,112 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
     const float a0 = (float)(p.lr / (1.0 - b1t));
     const float a1 = (float)(1.0 / sqrt(1.0 - b2t));
     BSIG_MSTAMP(0);
-    if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
-    __syncthreads();
-    BSIG_MSTAMP(4);
-    // activations [B, 128] (8-byte loads) and this block's gradient columns [B, 32]
-    for (int base = 0; base < B * (kMH / 2); base += kMT * 8) {
-      float2 q[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = min(base + u * kMT + tid, B * (kMH / 2) - 1);
-        q[u] = xwg_load2(hsrc + (int64_t)(idx >> 6) * kMH + (idx & 63) * 2);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * kMT + tid;
-        if (idx < B * (kMH / 2))
-          *reinterpret_cast<float2*>(Hs + (idx >> 6) * kMHP + (idx & 63) * 2) = q[u];
-      }
+#define BSIG_LOAD_ACTIVATIONS() /* [B, 128], 8-byte loads */                                   \
+    for (int base = 0; base < B * (kMH / 2); base += kMT * 8) {                                 \
+      float2 q[8];                                                                              \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
+        const int idx = min(base + u * kMT + tid, B * (kMH / 2) - 1);                           \
+        q[u] = xwg_load2(hsrc + (int64_t)(idx >> 6) * kMH + (idx & 63) * 2);                    \
+      }                                                                                         \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
+        const int idx = base + u * kMT + tid;                                                   \
+        if (idx < B * (kMH / 2))                                                                \
+          *reinterpret_cast<float2*>(Hs + (idx >> 6) * kMHP + (idx & 63) * 2) = q[u];           \
+      }                                                                                         \
     }
-    for (int base = 0; base < p.FR * kMNB; base += kMT * 8) {
-      float q[8];
+#define BSIG_LOAD_GRADIENT_BLOCK() /* this block's gradient columns [B, 32], transposed */      \
+    for (int base = 0; base < p.FR * kMNB; base += kMT * 8) {                                   \
+      float q[8];                                                                               \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
+        const int idx = base + u * kMT + tid;                                                   \
+        const int b = idx >> 5, n = n0 + (idx & 31);                                            \
+        q[u] = (idx < p.FR * kMNB && b < B && n < nrows) ? xwg_load(dsrc + (int64_t)b * dpitch + n) : 0.f; \
+      }                                                                                         \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
+        const int idx = base + u * kMT + tid;                                                   \
+        if (idx < p.FR * kMNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u];                         \
+      }                                                                                         \
+    }
+    if (WIDE && whead) {
+      // ---- wide heads: head outputs of ALL minibatch rows for this block's 32 columns ------
+      if (w == 0) flags_wait(p.flag_h2, p.n_owner, epoch, lane, flagp);
+      __syncthreads();
+      BSIG_LOAD_ACTIVATIONS()
+      __syncthreads();
+      {
+        const int mt = w & 3, kh = w >> 2;
+        f32x16 acc;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * kMT + tid;
-        const int b = idx >> 5, n = n0 + (idx & 31);
-        q[u] = (idx < p.FR * kMNB && b < B && n < nrows) ? xwg_load(dsrc + (int64_t)b * dpitch + n) : 0.f;
-      }
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* ap = Hs + (mt * 32 + l31) * kMHP + kh * 64 + 4 * h;
+        const float* bp = Wb + l31 * kMHP + kh * 64 + 4 * h;
+#pragma unroll 4
+        for (int kk = 0; kk < 64; kk += 8) {
+          const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
+          const float4 b4 = *reinterpret_cast<const float4*>(bp + kk);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        if (kh == 1) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * kMT + tid;
-        if (idx < p.FR * kMNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u];
+          for (int i = 0; i < 16; ++i) Xo[(mt * 32 + acc_row(i, h)) * kMPbuf + l31] = acc[i];
+        }
+        __syncthreads();
+        if (kh == 0) {
+          const float bias = bsh[l31];
+          float* dst = p.o_wide + n0 + l31;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = mt * 32 + acc_row(i, h);
+            if (row < B) xwg_store(dst + (int64_t)row * p.NhP, acc[i] + Xo[row * kMPbuf + l31] + bias);
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) flag_raise(p.flag_o, hb, epoch);
       }
+      // ---- ... and this block's share of d_out Wh (with the weights of this update's forward)
+      if (w == 0) flags_wait(p.flag_dout, p.n_owner, epoch, lane, flagp);
+      __syncthreads();
+      BSIG_MSTAMP(4);
+      BSIG_LOAD_GRADIENT_BLOCK()
+      __syncthreads();
+      {
+        const int mt = w & 3, ih = w >> 2;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const int col = (2 * ih + jt) * 32 + l31;
+          f32x16 acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+          for (int g8 = 0; g8 < 4; ++g8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = 8 * g8 + 4 * h + e;
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[k * DOP + mt * 32 + l31], Wb[k * kMHP + col],
+                                                         acc, 0, 0, 0);
+            }
+          }
+          float* dst = p.dz2_part + (int64_t)hb * B * kMH + col;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = mt * 32 + acc_row(i, h);
+            if (row < B) xwg_store(dst + (int64_t)row * kMH, acc[i]);
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) flag_raise(p.flag_dz2, hb, epoch);
+      }
+    } else {
+      if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
+      __syncthreads();
+      BSIG_MSTAMP(4);
+      BSIG_LOAD_ACTIVATIONS()
+      BSIG_LOAD_GRADIENT_BLOCK()
     }
     __syncthreads();
     BSIG_MSTAMP(5);
@@ -660,6 +758,7 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
       }
     }
     if (!DP) {
+      BSIG_REFRESH_OPERAND_COPY()   // (all reads of the old copy are behind the barrier above)
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       if (tid == 0)
@@ -681,13 +780,13 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
 }
 
 // ---- row-owner workgroups: layers 2.., NLL forward / backward ---------------------
-template <bool DP>
+template <bool DP, bool WIDE>
 __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
   const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
   const int po = Nh16 + 4;                   // pitch of a head-output row
   const int per_wave = D + 3 * K;
   float* Whs = smem;                         // [Nh16][128], element (n, i) at n*128 + (i ^ 4(n & 15))
-  float* H1s = Whs + Nh16 * kMH;             // [kMR][kMHP]
+  float* H1s = Whs + (WIDE ? 0 : Nh16 * kMH);   // [kMR][kMHP]  (wide heads: no head matrix here)
   float* H2s = H1s + kMR * kMHP;             // [kMR][kMHP]  h2, later dz2 in place
   float* Os = H2s + kMR * kMHP;              // [kMR][po]    head outputs, later d_out in place
   float* b2s = Os + kMR * po;                // [128]
@@ -929,10 +1028,12 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     BSIG_MSTAMP(0);
     // ---- weights of this update (written by the small-weight workgroups) ---------
     // (first update of a launch, and the only one of a data-parallel launch: flag_pack above)
-    if (!DP && t > 0 && w == 0) flags_wait(p.flag_small, p.n_small, epoch - 1u, lane, flagp);
+    // (wide heads: the owners only need W2 / b2 -- the first four small-weight workgroups)
+    if (!DP && t > 0 && w == 0)
+      flags_wait(p.flag_small, WIDE ? kMH / kMNB : p.n_small, epoch - 1u, lane, flagp);
     __syncthreads();
     BSIG_MSTAMP(4);
-    for (int base = 0; base < Nh16 * (kMH / 2); base += kMT * 8) {
+    for (int base = 0; base < (WIDE ? 0 : Nh16 * (kMH / 2)); base += kMT * 8) {
       float2 q[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1025,11 +1126,25 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         }
       }
     }
+    if constexpr (WIDE) __builtin_amdgcn_s_waitcnt(0);   // h2 rows are out before the flag
     __syncthreads();
     BSIG_MSTAMP(8);
-    // ---- head outputs = h2 Wh^T + bh: column blocks w, w+8, w+16 -----------------------
     float eacc = 0.f;
-    for (int cb = w; cb * 16 < Nh16; cb += 8) {
+    if constexpr (WIDE) {
+      // ---- wide heads: the head-block workgroups form h2 Wh^T + bh for all rows ------------
+      if (tid == 0) flag_raise(p.flag_h2, o, epoch);
+      if (w == 0) flags_wait(p.flag_o, p.n_hb, epoch, lane, flagp);
+      __syncthreads();
+      for (int idx = tid; idx < kMR * Nh16; idx += kMT) {
+        const int r = idx / Nh16, j = idx - r * Nh16;
+        const bool ok = j < Nh && r0 + r < B;
+        const float v = ok ? xwg_load(p.o_wide + (int64_t)(r0 + r) * p.NhP + j) : 0.f;
+        Os[r * po + j] = v;
+        if (ok && j >= K + DK && j < K + 2 * DK) eacc += expf(v);
+      }
+    }
+    // ---- head outputs = h2 Wh^T + bh: column blocks w, w+8, w+16 -----------------------
+    for (int cb = w; !WIDE && cb * 16 < Nh16; cb += 8) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const int n = 16 * cb + c16;
       const float* ap = H2s + rowA * kMHP + 4 * g;
@@ -1121,10 +1236,37 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       }
     }
     if (ro.bad) atomicOr(flagp, 1);
+    if constexpr (WIDE) __builtin_amdgcn_s_waitcnt(0);   // d_out rows are out before the flag
     __syncthreads();
     BSIG_MSTAMP(14);
+    if constexpr (WIDE) {
+      // ---- wide heads: dz2 = (sum of the head blocks' shares of d_out Wh) * (1 - h2^2) -------
+      if (tid == 0) flag_raise(p.flag_dout, o, epoch);
+      if (w == 0) flags_wait(p.flag_dz2, p.n_hb, epoch, lane, flagp);
+      __syncthreads();
+      if (tid < kMR * 64) {
+        const int r = tid >> 6, c2 = (tid & 63) * 2;
+        const float* src = p.dz2_part + (int64_t)min(r0 + r, B - 1) * kMH + c2;
+        float vx = 0.f, vy = 0.f;
+        for (int z = 0; z < p.n_hb; z += 8) {
+          float2 q[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) q[u] = xwg_load2(src + (int64_t)min(z + u, p.n_hb - 1) * zs);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (z + u < p.n_hb) { vx += q[u].x; vy += q[u].y; }
+        }
+        const float hx = H2s[r * kMHP + c2], hy = H2s[r * kMHP + c2 + 1];
+        vx *= 1.0f - hx * hx; vy *= 1.0f - hy * hy;
+        H2s[r * kMHP + c2] = vx; H2s[r * kMHP + c2 + 1] = vy;
+        if (r0 + r < B) {
+          xwg_store(p.dz2 + (int64_t)(r0 + r) * kMH + c2, vx);
+          xwg_store(p.dz2 + (int64_t)(r0 + r) * kMH + c2 + 1, vy);
+        }
+      }
+    }
     // ---- dz2 = (d_out Wh) * (1 - h2^2): wave w -> columns 16w .. 16w+15 ----------------
-    {
+    if constexpr (!WIDE) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const int i = 16 * w + c16;
       const float* ap = Os + rowA * po + 4 * g;
@@ -1190,13 +1332,13 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     }
     // the evaluation due after the previous update: the tile workgroups formed its
     // first-layer products while this update's rows were being finished
-    if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
+    if (!WIDE && __builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
       __syncthreads();
       owner_eval(mdnn_evals_before(step, p.eval_every) - 1,
                  rng_ctr0 + (uint64_t)t + (uint64_t)(mdnn_evals_before(step, p.eval_every) - ev0) - 1u, step, false);
     }
   }
-  if (p.do_eval && step0 + p.n_updates == p.n_total && (!DP || p.n_updates == 0) &&
+  if (!WIDE && p.do_eval && step0 + p.n_updates == p.n_total && (!DP || p.n_updates == 0) &&
       !run_aborted(flagp, red, tid_0))
     owner_eval(mdnn_evals_before(p.n_total - 1, p.eval_every),
                rng_ctr0 + (uint64_t)p.n_updates +
@@ -1205,18 +1347,20 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
 
 // DP: data-parallel rank (gradients out, pending Adam step in; see MdnnArgs)
 // FAC: the summary rows arrive as cross-correlation factor rows
-template <bool DP, bool FAC>
+// WIDE: heads wider than the owners' LDS: head outputs formed by the head-block workgroups
+template <bool DP, bool FAC, bool WIDE>
 __global__ __launch_bounds__(kMT) void mdnn_updates_kernel(MdnnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wg = blockIdx.x;
   if (wg < p.G1) mdnn_tile_workgroup<DP, FAC>(p, smem);
-  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP>(p, smem);
-  else mdnn_small_workgroup<DP>(p, smem);
+  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP, WIDE>(p, smem);
+  else mdnn_small_workgroup<DP, WIDE>(p, smem);
 }
 
 // ---------------------------------------------------------------- host side
 struct MdnnGeom {
   int FR, Nh, Nh16, NhP, k_slices, G1, n_owner, n_small, x_floats;
+  int wide;                     // head outputs formed by the head-block workgroups (see MdnnArgs)
   int eval_passes;              // 0: evaluations stay outside the launches
   size_t lds;
   size_t slab_floats, act_floats, dout_floats, eval_floats;
@@ -1242,9 +1386,17 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   g->x_floats = (int)round_up(std::max(128 * kMPbuf, kMNB * (g->FR + 4)), 4);
   const size_t tile_lds = ((size_t)g->FR * kMPitch + (size_t)kMNB * kMPitch + g->x_floats + 64 + 96 +
                            (kMT / 32) * 32) * sizeof(float);
-  const size_t owner_lds = ((size_t)g->Nh16 * kMH + 2 * kMR * kMHP + (size_t)kMR * (g->Nh16 + 4) + kMH +
-                            g->Nh16 + (size_t)kMR * (s.out_dim + 3 * s.n_comp) + 64) * sizeof(float);
-  const size_t small_lds = ((size_t)g->FR * kMHP + (size_t)kMNB * (g->FR + 4) + 64) * sizeof(float);
+  size_t owner_lds = ((size_t)g->Nh16 * kMH + 2 * kMR * kMHP + (size_t)kMR * (g->Nh16 + 4) + kMH +
+                      g->Nh16 + (size_t)kMR * (s.out_dim + 3 * s.n_comp) + 64) * sizeof(float);
+  size_t small_lds = ((size_t)g->FR * kMHP + (size_t)kMNB * (g->FR + 4) + 64) * sizeof(float);
+  g->wide = owner_lds > (size_t)kMLdsLimit ? 1 : 0;
+  const char* force_wide = getenv("BSIG_MDNN_WIDE_HEADS");     // tests: the wide path on small heads
+  if (force_wide && force_wide[0] == '1') g->wide = 1;
+  if (g->wide) {
+    owner_lds -= (size_t)g->Nh16 * kMH * sizeof(float);         // no head matrix in the owners
+    // + the block's weights in operand order [32][kMHP] and the k-half exchange [128][33]
+    small_lds += ((size_t)kMNB * kMHP + 128 * kMPbuf + kMNB) * sizeof(float);
+  }
   // the forward of the tile workgroups reads summary rows up to 127
   g->lds = std::max(std::max(tile_lds, (size_t)128 * kMPitch * sizeof(float)),
                     std::max(owner_lds, small_lds));
@@ -1254,7 +1406,7 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   g->dout_floats = (size_t)s.batch * g->NhP;
   // in-launch evaluations: slabs of both parities and the parked head outputs
   g->eval_passes = s.max_test > 0 ? ceil_div(s.max_test, s.batch) : 0;
-  if (g->eval_passes > 8) g->eval_passes = 0;
+  if (g->eval_passes > 8 || g->wide) g->eval_passes = 0;   // wide heads: evaluation graphs between launches
   g->eval_floats = (size_t)2 * g->eval_passes * g->slab_floats +
                    (size_t)g->eval_passes * s.batch * g->NhP;
   return true;
@@ -1278,11 +1430,14 @@ bool persist_mdnn_eval_supported(const PersistMdnnShape& s) {
 }
 
 constexpr size_t kPackFloats = (size_t)2 * kMH * kMH;   // both parities
+static size_t mdnn_wide_floats(const MdnnGeom& g) {
+  return g.wide ? g.dout_floats + (size_t)(g.NhP / kMNB) * g.act_floats : 0;
+}
 static size_t mdnn_data_bytes(const MdnnGeom& g) {
   return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats + 2 * kPackFloats +
-                           g.eval_floats) * sizeof(float), 256);
+                           g.eval_floats + mdnn_wide_floats(g)) * sizeof(float), 256);
 }
-static size_t mdnn_sync_bytes() { return 5 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
+static size_t mdnn_sync_bytes() { return 9 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
 
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
   MdnnGeom g;
@@ -1332,10 +1487,14 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   BSIG_HIP(hipGetDevice(&attr_dev));
   bool& attr_set = attr_set_dev[attr_dev & 63];
   if (!attr_set) {
-    const void* kernels[4] = {reinterpret_cast<const void*>(mdnn_updates_kernel<false, false>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, false>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<false, true>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, true>)};
+    const void* kernels[8] = {reinterpret_cast<const void*>(mdnn_updates_kernel<false, false, false>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, false, false>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<false, true, false>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, true, false>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<false, false, true>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, false, true>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<false, true, true>),
+                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, true, true>)};
     for (const void* k : kernels)
       BSIG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit));
     attr_set = true;
@@ -1366,15 +1525,22 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.w2b_pack = p.w2f_pack + kPackFloats;
   p.eval_slabs = p.w2b_pack + kPackFloats;
   p.eval_out = p.eval_slabs + (size_t)2 * g.eval_passes * g.slab_floats;
+  p.wide = g.wide; p.n_hb = g.NhP / kMNB;
+  p.o_wide = p.eval_out + (size_t)g.eval_passes * s.batch * g.NhP;
+  p.dz2_part = p.o_wide + g.dout_floats;
   char* sync = base + mdnn_data_bytes(g);
   p.flag_fwd = reinterpret_cast<unsigned*>(sync);
   p.flag_own = p.flag_fwd + kFlagArr;
   p.flag_small = p.flag_own + kFlagArr;
   p.flag_pack = p.flag_small + kFlagArr;
   p.flag_eval = p.flag_pack + kFlagArr;
+  p.flag_h2 = p.flag_eval + kFlagArr;
+  p.flag_o = p.flag_h2 + kFlagArr;
+  p.flag_dout = p.flag_o + kFlagArr;
+  p.flag_dz2 = p.flag_dout + kFlagArr;
   static unsigned launch_tag = 0;
   p.launch_tag = ++launch_tag;
-  p.gran = reinterpret_cast<unsigned long long*>(sync + 5 * kFlagArr * sizeof(unsigned));
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 9 * kFlagArr * sizeof(unsigned));
   p.gran_eval = p.gran + 3 * kGranArr;
   if (b.do_eval) {
     BSIG_REQUIRE(g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
@@ -1388,10 +1554,21 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   }
   p.prof = reinterpret_cast<long long*>(persist_profile_buffer());
   const dim3 grid(g.G1 + g.n_owner + g.n_small);
-  if (b.grads && fac) hipLaunchKernelGGL((mdnn_updates_kernel<true, true>), grid, dim3(kMT), g.lds, st, p);
-  else if (b.grads) hipLaunchKernelGGL((mdnn_updates_kernel<true, false>), grid, dim3(kMT), g.lds, st, p);
-  else if (fac) hipLaunchKernelGGL((mdnn_updates_kernel<false, true>), grid, dim3(kMT), g.lds, st, p);
-  else hipLaunchKernelGGL((mdnn_updates_kernel<false, false>), grid, dim3(kMT), g.lds, st, p);
+#define BSIG_MDNN_LAUNCH(DP_, FAC_, WIDE_) \
+  hipLaunchKernelGGL((mdnn_updates_kernel<DP_, FAC_, WIDE_>), grid, dim3(kMT), g.lds, st, p)
+  const bool dp = b.grads != nullptr;
+  if (g.wide) {
+    if (dp && fac) BSIG_MDNN_LAUNCH(true, true, true);
+    else if (dp) BSIG_MDNN_LAUNCH(true, false, true);
+    else if (fac) BSIG_MDNN_LAUNCH(false, true, true);
+    else BSIG_MDNN_LAUNCH(false, false, true);
+  } else {
+    if (dp && fac) BSIG_MDNN_LAUNCH(true, true, false);
+    else if (dp) BSIG_MDNN_LAUNCH(true, false, false);
+    else if (fac) BSIG_MDNN_LAUNCH(false, true, false);
+    else BSIG_MDNN_LAUNCH(false, false, false);
+  }
+#undef BSIG_MDNN_LAUNCH
   BSIG_CHECK_LAUNCH("mdnn_updates");
   return BSIG_OK;
 }

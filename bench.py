@@ -37,6 +37,10 @@ CONFIGS = {
     # (time + 19 observations + 2 actions) -> the reference's depth rule gives 3, I = 11154
     'cfg4b': dict(task='ShadowHand-22ch', model='MDNN', summarizer='summary_signatory', t=11,
                   sd=19, ad=2, d=32, k=4, hidden=[128, 128], n_feat=0, pairs=25_000),
+    # the reference's own cfg/ant.yaml:65-70 (10 components: a 350-wide head, the persistent
+    # MDNN kernel's wide-head path) -- a side case, not a BASELINE config
+    'ant_yaml': dict(task='Ant (cfg/ant.yaml)', model='MDNN', summarizer='summary_corrdiff', t=51,
+                     sd=60, ad=8, d=17, k=10, hidden=[128, 128], n_feat=0, pairs=20_000),
     'cfg5': dict(task='ShadowHand', model='MDRFF', summarizer='summary_start', t=11, sd=211,
                  ad=20, d=32, k=4, hidden=[], n_feat=4096, pairs=100_000),
 }

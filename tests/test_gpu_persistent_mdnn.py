@@ -203,3 +203,87 @@ def test_in_launch_evaluations_equal_the_evaluation_graphs(B, eps, n, batch, n_u
     assert len(a[0]['test_loss']) == len(b[0]['test_loss'])
     assert np.allclose(a[0]['test_loss'], b[0]['test_loss'], rtol=2e-6, atol=2e-6), (a[0], b[0])
     assert torch.equal(a[1], b[1])
+
+
+# ---- wide heads (Nh > 272): the head-block workgroups form the head outputs -----------------
+def _oracle_chunk(B, cfg, bs, theta, states, actions, ids, n_updates=100, batch=100):
+    import bench
+    from oracle import summarize as osum
+    ora = bench.build_oracle(cfg, bs.model.input_dim, 77, 0.0)
+    bs0 = bench.build_gpu_model(B, cfg, DEV, 77)
+    ora.load_state_dict({kk: v.cpu() for kk, v in bs0.model.state_dict().items()})
+    return ora.run_training(osum.SUMMARIZERS[cfg['summarizer']](states.cpu(), actions.cpu()),
+                            theta.cpu(), n_updates, batch, ids_table=ids), ora
+
+
+# the reference YAMLs' 10 components (cfg/ant.yaml:69-70: D = 17 -> Nh = 350; a ShadowHand-sized
+# theta, D = 32 -> Nh = 650, 21 head blocks) and a head that is not a multiple of 32 or 16
+@pytest.mark.parametrize('d,k,summarizer,sd,ad,t', [(17, 10, 'summary_corrdiff', 10, 8, 12),
+                                                    (32, 10, 'summary_start', 97, 20, 11),
+                                                    (25, 7, 'summary_start', 5, 2, 11)])
+def test_wide_heads_chunk_matches_oracle(B, d, k, summarizer, sd, ad, t):
+    cfg = _cfg(d, k, summarizer, t, sd, ad)
+    torch.set_num_threads(8)
+    logs, flat, bs, (theta, states, actions, ids) = _chunk(B, cfg, eps=0.0)
+    assert k * (1 + 2 * d) > 272
+    assert B._lib.load().bsig_fit_is_persistent(bs.model._plan) == 2
+    ref, ora = _oracle_chunk(B, cfg, bs, theta, states, actions, ids)
+    for key in ('train_loss', 'test_loss'):
+        got, exp = np.array(logs[key]), np.array(ref[key])
+        assert got.shape == exp.shape == (6,)
+        assert np.all(np.abs(got - exp) <= 1e-4 * np.maximum(np.abs(exp), 1.0)), (key, got, exp)
+    sd_ = bs.model.state_dict()
+    for name, v in ora.state_dict().items():
+        diff = (sd_[name].cpu() - v).abs()
+        assert int((diff > 2e-4 + 1e-3 * v.abs()).sum()) <= 3 and float(diff.max()) < 2e-3, name
+
+
+@pytest.mark.parametrize('eps', [0.0, 1e-5])
+@pytest.mark.parametrize('n,batch,n_updates', [(1000, 100, 100), (1000, 37, 11), (60, 100, 5)])
+def test_wide_heads_equal_the_owner_resident_heads(B, eps, n, batch, n_updates):
+    """The wide path forced onto a head that also fits the owners (BSIG_MDNN_WIDE_HEADS=1):
+    the same update, head products summed in another order; and against the per-phase
+    kernels.  Reruns are bitwise."""
+    cfg = _cfg(4, 6, 'summary_corrdiff', 12, 7, 3)
+    a = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=eps)
+    os.environ['BSIG_MDNN_WIDE_HEADS'] = '1'
+    try:
+        b = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=eps)
+        b2 = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates, eps=eps)
+        assert B._lib.load().bsig_fit_is_persistent(b[2].model._plan) == 2
+    finally:
+        os.environ.pop('BSIG_MDNN_WIDE_HEADS', None)
+    # (two summation orders of the head products; the jitter noise amplifies the 1e-7 differences
+    # of the early updates to a few 1e-5 by update 100 -- the weights stay within 1e-5)
+    for key in ('train_loss', 'test_loss'):
+        assert len(a[0][key]) == len(b[0][key])
+        assert np.allclose(a[0][key], b[0][key], rtol=1e-4, atol=1e-4), (key, a[0], b[0])
+    assert torch.allclose(a[1], b[1], atol=1e-4, rtol=1e-3)
+    assert b[0] == b2[0] and torch.equal(b[1], b2[1])
+
+
+def test_wide_heads_data_parallel_rank_is_bitwise(B):
+    import bench
+    import torch.distributed as dist
+    cfg = _cfg(17, 10, 'summary_corrdiff', 12, 10, 8)
+    logs_p, flat_p, bs_p, _ = _chunk(B, cfg, eps=1e-5)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29579')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        B.MDNN.EPS_NOISE = 1e-5
+        theta, states, actions = bench.synth_pairs(cfg, 1000, 3, DEV)
+        bs = bench.build_gpu_model(B, cfg, DEV, 77)
+        bs.model.enable_data_parallel()
+        ids = np.random.RandomState(5).randint(0, 800, (100, 100))
+        logs_d = bs.model.run_training(bs._summarize(states, actions), theta, 100, 100, ids_table=ids)
+        flat_d = bs.model._flat.clone()
+        assert B._lib.load().bsig_fit_is_persistent(bs.model._plan) == 2
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert logs_d['train_loss'] == logs_p['train_loss']
+    assert np.allclose(logs_d['test_loss'], logs_p['test_loss'], rtol=1e-6, atol=1e-6)
+    assert torch.equal(flat_d, flat_p)
