@@ -1033,16 +1033,19 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       flags_wait(p.flag_small, WIDE ? kMH / kMNB : p.n_small, epoch - 1u, lane, flagp);
     __syncthreads();
     BSIG_MSTAMP(4);
-    for (int base = 0; base < (WIDE ? 0 : Nh16 * (kMH / 2)); base += kMT * 8) {
-      float2 q[8];
+    // (kWhFlight 8-byte loads in flight per thread: the 139 KB of a 260-row head matrix arrive in
+    // two round trips around the L2 instead of five -- this refresh sits on the owners' critical path)
+    constexpr int kWhFlight = 17;
+    for (int base = 0; base < (WIDE ? 0 : Nh16 * (kMH / 2)); base += kMT * kWhFlight) {
+      float2 q[kWhFlight];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kWhFlight; ++u) {
         const int idx = base + u * kMT + tid;
         const int n = idx >> 6;
         q[u] = n < Nh ? xwg_load2(Wh + (int64_t)n * kMH + (idx & 63) * 2) : make_float2(0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kWhFlight; ++u) {
         const int idx = base + u * kMT + tid;
         const int n = idx >> 6, c2 = (idx & 63) * 2;
         if (n < Nh16) *reinterpret_cast<float2*>(Whs + n * kMH + (c2 ^ (4 * (n & 15)))) = q[u];

@@ -70,3 +70,13 @@ for u in range(2, 7):
 print('update period %.2f us' % np.mean(per))
 for label, _, _, _ in rows:
     print('    %-52s %6.2f' % (label, np.mean(acc[label])))
+if os.environ.get('DETAIL') == '1':
+    u = 4
+    t0 = min(st[g, u, 0] for g in tiles)
+    print('update %d: small-weight workgroups: released / inputs / published (us after t0), then into update %d' % (u, u + 1))
+    for g in small:
+        print('   wg %3d: %6.2f %6.2f %6.2f' % (g, st[g, u, 4] - t0, st[g, u, 5] - t0, st[g, u, 6] - t0))
+    t1 = min(st[g, u + 1, 0] for g in tiles)
+    print('update %d starts at %.2f; owners: start / small flags / Wh in LDS / fwd flags' % (u + 1, t1 - t0))
+    for g in owners:
+        print('   wg %3d: %6.2f %6.2f %6.2f %6.2f' % (g, st[g, u + 1, 0] - t1, st[g, u + 1, 4] - t1, st[g, u + 1, 5] - t1, st[g, u + 1, 6] - t1))

@@ -1,33 +1,43 @@
 #!/usr/bin/env bash
-# Collect the per-round evidence on a GPU box: kernel stats of the default bench
-# (cfg5) and of cfg3 (MDNN), PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs),
-# chunk timelines.  Usage: tools/round_profiles.sh <tag>   (writes gpurun_out/<tag>_*)
+# Collect the per-round evidence on a GPU box (writes gpurun_out/<tag>_*; copy what is to be
+# judged into profiles/):
+#   - kernel stats (rocprofv3 --kernel-trace --stats) + chunk timeline of the default bench (cfg5)
+#     and of cfg3 (MDNN on cross-correlation factor rows), and of the scaled-batch mode alone
+#   - PMC passes FETCH_SIZE / WRITE_SIZE (separate runs, --kernel-trace only) for cfg5 and cfg3
+#   - kernel stats + PMC of the summarizers at 50k / 100k trajectories (tools/summarizer_bench.py)
+# Usage: tools/round_profiles.sh <tag>
 set -uo pipefail
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-run_stats() {   # name, bench args...
-  local name=$1; shift
+run_stats() {   # name, program, args...
+  local name=$1 prog=$2; shift 2
   rm -rf /tmp/p_$name
-  rocprofv3 --kernel-trace --stats -d /tmp/p_$name -o k -- python3 $R/bench.py "$@" > $OUT/${TAG}_${name}_bench.log 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/p_$name -o k -- python3 $R/$prog "$@" > $OUT/${TAG}_${name}_run.log 2>&1
   local db=$(find /tmp/p_$name -name "*.db" | head -1)
   python3 $R/tools/rocprof_summary.py "$db" $OUT/${TAG}_${name}_kernel_stats.txt \
-    "$TAG: rocprofv3 --kernel-trace --stats -- python bench.py $*"
-  python3 $R/tools/chunk_timeline.py "$db" $OUT/${TAG}_${name}_chunk_timeline.txt
+    "$TAG: rocprofv3 --kernel-trace --stats -- python $prog $*"
+  if [ "$prog" = bench.py ]; then
+    python3 $R/tools/chunk_timeline.py "$db" $OUT/${TAG}_${name}_chunk_timeline.txt > /dev/null 2>&1 || true
+  fi
 }
-run_pmc() {     # name, counter, bench args...
-  local name=$1 ctr=$2; shift 2
+run_pmc() {     # name, counter, program, args...
+  local name=$1 ctr=$2 prog=$3; shift 3
   rm -rf /tmp/c_${name}_$ctr
-  rocprofv3 --pmc $ctr --kernel-trace -d /tmp/c_${name}_$ctr -o c -- python3 $R/bench.py "$@" > /dev/null 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace -d /tmp/c_${name}_$ctr -o c -- python3 $R/$prog "$@" > /dev/null 2>&1
   local db=$(find /tmp/c_${name}_$ctr -name "*.db" | head -1)
   python3 $R/tools/pmc_dump.py "$db" $OUT/${TAG}_${name}_pmc_$ctr.txt \
-    "rocprofv3 --pmc $ctr --kernel-trace -- python bench.py $*"
+    "rocprofv3 --pmc $ctr --kernel-trace -- python $prog $*"
 }
-run_stats cfg5 --steps 1 --warmup 1 --no-cpu-baseline --no-scaled-batch
-run_stats cfg3 --config cfg3 --pairs 20000 --steps 1 --warmup 1 --no-cpu-baseline --no-scaled-batch
+B5="--steps 1 --warmup 1 --no-cpu-baseline --no-scaled-batch --no-per-config"
+run_stats cfg5 bench.py $B5
+run_stats cfg3 bench.py --config cfg3 --pairs 20000 $B5
+run_stats scaled bench.py --only-scaled-batch
+run_stats summarizers tools/summarizer_bench.py
 for c in FETCH_SIZE WRITE_SIZE; do
-  run_pmc cfg5 $c --pairs 5000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch
-  run_pmc cfg3 $c --config cfg3 --pairs 5000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch
+  run_pmc cfg5 $c bench.py --pairs 5000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch --no-per-config
+  run_pmc cfg3 $c bench.py --config cfg3 --pairs 5000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch --no-per-config
+  run_pmc summarizers $c tools/summarizer_bench.py
 done
