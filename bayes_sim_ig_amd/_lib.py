@@ -101,6 +101,7 @@ _PROTOS = {
     'bsig_fit_flush': (C.c_int, [vp, vp]),
     'bsig_fit_is_persistent': (C.c_int, [vp]),
     'bsig_fit_accepts_factors': (C.c_int, [vp]),
+    'bsig_fit_takes_features': (C.c_int, [vp, i64]),
     'bsig_fit_eval': (C.c_int, [vp, vp]),
     'bsig_fit_updates': (C.c_int, [vp, i64, vp]),
     'bsig_debug_persist_profile': (None, [vp]),

@@ -918,6 +918,15 @@ extern "C" int bsig_fit_apply(bsig_fit_plan* p, bsig_stream_t stream) {
   return enqueue_apply(p, as_stream(stream));
 }
 
+extern "C" int bsig_fit_takes_features(const bsig_fit_plan* p, int64_t n_train) {
+  // a hoisted MDRFF plan keeps one feature row per training row when the call visits its rows
+  // more than once: bsig_fit_set_features then replaces the projection and nothing reads
+  // x_train / x_test afterwards (same condition as feat_unique in bsig_fit_bind)
+  const char* no_cache = getenv("BSIG_NO_FEAT_CACHE");
+  return p && p->hoist && n_train >= 1 && n_train <= p->n_updates * p->batch &&
+                 !(no_cache && no_cache[0] == '1') ? 1 : 0;
+}
+
 extern "C" int bsig_fit_accepts_factors(const bsig_fit_plan* p) {
   // every update runs in the persistent kernel of the two-layer MDNN, whose first-layer tile
   // workgroups form the products; the evaluations read materialised held-out rows

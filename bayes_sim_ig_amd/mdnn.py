@@ -441,8 +441,10 @@ class MDNN(nn.Module):
             xs, ldx_src = _lib.as_f32_rows(x_data, dev)
             ldx = _lib.round_up(self.input_dim, 4)
             x_stage = self._buf('x_stage', self._bufs['cap_rows'] * ldx)
-            _lib.check(lib.bsig_copy_rows(_lib.ptr(xs), ldx_src, None, _lib.ptr(x_stage), ldx,
-                                          n_tot, self.input_dim, st))
+            # (an MDRFF whose rows' features are handed over never reads the summaries themselves)
+            if _feats is None or not lib.bsig_fit_takes_features(self._plan, n_train):
+                _lib.check(lib.bsig_copy_rows(_lib.ptr(xs), ldx_src, None, _lib.ptr(x_stage), ldx,
+                                              n_tot, self.input_dim, st))
         y_stage = self._buf('y_stage', self._bufs['cap_rows'] * ldy)
         if self.output_lows is not None:                       # mdnn.py:204-205
             _lib.check(lib.bsig_normalize_rows(

@@ -294,6 +294,10 @@ int bsig_fit_bind(bsig_fit_plan* plan, const bsig_fit_buffers* buffers, int flag
  * bsig_fit_begin only. */
 int bsig_fit_set_features(bsig_fit_plan* plan, const float* feats, int64_t ld_feats,
                           int64_t rows, bsig_stream_t stream);
+/* != 0: bound to n_train training rows the plan keeps one feature row per row (MDRFF whose
+ * call visits its rows more than once): after bsig_fit_set_features nothing reads x_train /
+ * x_test -- the caller need not stage the summaries. */
+int bsig_fit_takes_features(const bsig_fit_plan* plan, int64_t n_train);
 /* Reset step counter / Adam state (fresh optimizer per call, mdnn.py:203). */
 int bsig_fit_begin(bsig_fit_plan* plan, uint64_t seed, int64_t norm_batch,
                    bsig_stream_t stream);
