@@ -780,11 +780,12 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
 }
 
 // ---- row-owner workgroups: layers 2.., NLL forward / backward ---------------------
-template <bool DP, bool WIDE>
+// FULL: full covariance (one lane per component runs the triangular solves: full_row)
+template <bool DP, bool WIDE, bool FULL>
 __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
   const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
   const int po = Nh16 + 4;                   // pitch of a head-output row
-  const int per_wave = D + 3 * K;
+  const int per_wave = D + 3 * K + (FULL ? 3 * DK : 0);
   float* Whs = smem;                         // [Nh16][128], element (n, i) at n*128 + (i ^ 4(n & 15))
   float* H1s = Whs + (WIDE ? 0 : Nh16 * kMH);   // [kMR][kMHP]  (wide heads: no head matrix here)
   float* H2s = H1s + kMR * kMHP;             // [kMR][kMHP]  h2, later dz2 in place
@@ -803,6 +804,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   const uint64_t rng_ctr0 = reinterpret_cast<const uint64_t*>(p.state + 8)[1];
   HeadArgs a{};
   a.D = D; a.K = K; a.Nh = Nh; a.batch = B; a.from_tuple = 0;
+  a.Ls = FULL ? D * (D - 1) / 2 : 0;
   a.min_w = p.min_w; a.ll_limit = p.ll_limit; a.inv_norm = p.inv_norm;
   a.eps_noise = p.eps_noise; a.seed = rng_seed; a.d_out = p.d_out;
   const float norm = (float)B * (float)DK;
@@ -971,14 +973,14 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
 #pragma unroll
         for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
-        diag_row(ae, erow, act, lane, tile, yv, rk, lpk, dlg,
-                 [&] {
-                   return p.eps_noise != 0.f
-                              ? p.eps_noise * (granule_gather(p.gran_eval, p.n_owner, etag, lane, flagp) /
-                                               ((float)p.n_test * (float)DK))
-                              : 0.f;
-                 },
-                 ro);
+        auto eval_eps = [&] {
+          return p.eps_noise != 0.f
+                     ? p.eps_noise * (granule_gather(p.gran_eval, p.n_owner, etag, lane, flagp) /
+                                      ((float)p.n_test * (float)DK))
+                     : 0.f;
+        };
+        if constexpr (FULL) full_row(ae, erow, act, lane, tile, yv, rk, dlg, dlg + K, eval_eps, ro);
+        else diag_row(ae, erow, act, lane, tile, yv, rk, lpk, dlg, eval_eps, ro);
         if (act) lse_acc += ro.lse;
         bad |= ro.bad;
       }
@@ -1190,13 +1192,15 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     // one jitter stream per update and per evaluation, in program order
     a.stream_id = rng_ctr0 + (uint64_t)t +
                   (uint64_t)(p.do_eval ? mdnn_evals_before(step, p.eval_every) - ev0 : 0);
-    diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg,
-             [&] {
-               return p.eps_noise != 0.f
-                          ? p.eps_noise * (granule_gather(p.gran, p.n_owner, tag + 1, lane, flagp) / norm)
-                          : 0.f;
-             },
-             ro);
+    {
+      auto row_eps = [&] {
+        return p.eps_noise != 0.f
+                   ? p.eps_noise * (granule_gather(p.gran, p.n_owner, tag + 1, lane, flagp) / norm)
+                   : 0.f;
+      };
+      if constexpr (FULL) full_row(a, row, active, lane, tile, yv, rk, dlg, dlg + K, row_eps, ro);
+      else diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, row_eps, ro);
+    }
     {
       const float uds_w = wave_sum_dpp(ro.uds);
       if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
@@ -1223,15 +1227,23 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       if (p.eps_noise != 0.f)
         c = p.eps_noise / norm * granule_gather(p.gran + kGranArr, p.n_owner, tag + 2, lane, flagp);
       if (active) {
-        const int groups = 64 / K, TPR = groups * K;
-        const int k = lane % K, d0 = lane / K;
-        if (c != 0.f && lane < TPR) {
+        if constexpr (FULL) {
+          // exp(pre) of the row: third block of full_row's scratch, [d][k] like the head outputs
+          const float* sg0 = dlg + K + 2 * DK;
+          if (c != 0.f)
+            for (int j = lane; j < DK; j += 64) tile[K + DK + j] += c * sg0[j];
+        } else {
+          const int groups = 64 / K, TPR = groups * K;
+          const int k = lane % K, d0 = lane / K;
+          if (c != 0.f && lane < TPR) {
 #pragma unroll
-          for (int q = 0; q < kElemsPerLane; ++q) {
-            const int d = d0 + q * groups;
-            if (d < D) tile[K + DK + d * K + k] += c * ro.esg0[q];
+            for (int q = 0; q < kElemsPerLane; ++q) {
+              const int d = d0 + q * groups;
+              if (d < D) tile[K + DK + d * K + k] += c * ro.esg0[q];
+            }
           }
         }
+        __builtin_amdgcn_wave_barrier();
         for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
         __builtin_amdgcn_wave_barrier();
         float* dst = p.d_out + (int64_t)row * p.NhP;
@@ -1351,12 +1363,12 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
 // DP: data-parallel rank (gradients out, pending Adam step in; see MdnnArgs)
 // FAC: the summary rows arrive as cross-correlation factor rows
 // WIDE: heads wider than the owners' LDS: head outputs formed by the head-block workgroups
-template <bool DP, bool FAC, bool WIDE>
+template <bool DP, bool FAC, bool WIDE, bool FULL>
 __global__ __launch_bounds__(kMT) void mdnn_updates_kernel(MdnnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wg = blockIdx.x;
   if (wg < p.G1) mdnn_tile_workgroup<DP, FAC>(p, smem);
-  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP, WIDE>(p, smem);
+  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP, WIDE, FULL>(p, smem);
   else mdnn_small_workgroup<DP, WIDE>(p, smem);
 }
 
@@ -1371,14 +1383,16 @@ struct MdnnGeom {
 
 static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   if (s.batch < 1 || s.input_dim < 1 || s.h1 != kMH || s.h2 != kMH ||
-      s.activation != BSIG_ACT_TANH || s.full_cov != 0 || s.out_dim < 1 || s.n_comp < 1 ||
-      s.n_comp > 64)
+      s.activation != BSIG_ACT_TANH || s.out_dim < 1 || s.n_comp < 1 || s.n_comp > 64)
     return false;
   const int groups = 64 / s.n_comp;
-  if (ceil_div(s.out_dim, groups) > kElemsPerLane) return false;
+  const bool full = s.full_cov != 0 && s.out_dim >= 2;
+  // (full covariance: one lane per component runs D sequential solves -- small theta only)
+  if (full ? s.out_dim > 16 : ceil_div(s.out_dim, groups) > kElemsPerLane) return false;
+  const int ls = full ? s.out_dim * (s.out_dim - 1) / 2 : 0;
   g->FR = (int)round_up(s.batch, 8);
   if (g->FR > 104) return false;               // 13 float4 of the summary tile per thread
-  g->Nh = s.n_comp + 2 * s.out_dim * s.n_comp;
+  g->Nh = s.n_comp * (1 + 2 * s.out_dim + ls);
   g->Nh16 = (int)round_up(g->Nh, 16);
   g->NhP = (int)round_up(g->Nh, kMNB);
   g->k_slices = ceil_div(s.input_dim, kMC);
@@ -1390,7 +1404,8 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   const size_t tile_lds = ((size_t)g->FR * kMPitch + (size_t)kMNB * kMPitch + g->x_floats + 64 + 96 +
                            (kMT / 32) * 32) * sizeof(float);
   size_t owner_lds = ((size_t)g->Nh16 * kMH + 2 * kMR * kMHP + (size_t)kMR * (g->Nh16 + 4) + kMH +
-                      g->Nh16 + (size_t)kMR * (s.out_dim + 3 * s.n_comp) + 64) * sizeof(float);
+                      g->Nh16 + (size_t)kMR * (s.out_dim + 3 * s.n_comp + (full ? 3 * s.out_dim * s.n_comp : 0)) +
+                      64) * sizeof(float);
   size_t small_lds = ((size_t)g->FR * kMHP + (size_t)kMNB * (g->FR + 4) + 64) * sizeof(float);
   g->wide = owner_lds > (size_t)kMLdsLimit ? 1 : 0;
   const char* force_wide = getenv("BSIG_MDNN_WIDE_HEADS");     // tests: the wide path on small heads
@@ -1490,14 +1505,15 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   BSIG_HIP(hipGetDevice(&attr_dev));
   bool& attr_set = attr_set_dev[attr_dev & 63];
   if (!attr_set) {
-    const void* kernels[8] = {reinterpret_cast<const void*>(mdnn_updates_kernel<false, false, false>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, false, false>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<false, true, false>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, true, false>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<false, false, true>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, false, true>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<false, true, true>),
-                              reinterpret_cast<const void*>(mdnn_updates_kernel<true, true, true>)};
+    const void* kernels[16] = {
+#define BSIG_K(a, b, c, d) reinterpret_cast<const void*>(mdnn_updates_kernel<a, b, c, d>)
+        BSIG_K(false, false, false, false), BSIG_K(true, false, false, false), BSIG_K(false, true, false, false),
+        BSIG_K(true, true, false, false),   BSIG_K(false, false, true, false), BSIG_K(true, false, true, false),
+        BSIG_K(false, true, true, false),   BSIG_K(true, true, true, false),   BSIG_K(false, false, false, true),
+        BSIG_K(true, false, false, true),   BSIG_K(false, true, false, true),  BSIG_K(true, true, false, true),
+        BSIG_K(false, false, true, true),   BSIG_K(true, false, true, true),   BSIG_K(false, true, true, true),
+        BSIG_K(true, true, true, true)};
+#undef BSIG_K
     for (const void* k : kernels)
       BSIG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit));
     attr_set = true;
@@ -1557,20 +1573,21 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   }
   p.prof = reinterpret_cast<long long*>(persist_profile_buffer());
   const dim3 grid(g.G1 + g.n_owner + g.n_small);
-#define BSIG_MDNN_LAUNCH(DP_, FAC_, WIDE_) \
-  hipLaunchKernelGGL((mdnn_updates_kernel<DP_, FAC_, WIDE_>), grid, dim3(kMT), g.lds, st, p)
-  const bool dp = b.grads != nullptr;
-  if (g.wide) {
-    if (dp && fac) BSIG_MDNN_LAUNCH(true, true, true);
-    else if (dp) BSIG_MDNN_LAUNCH(true, false, true);
-    else if (fac) BSIG_MDNN_LAUNCH(false, true, true);
-    else BSIG_MDNN_LAUNCH(false, false, true);
-  } else {
-    if (dp && fac) BSIG_MDNN_LAUNCH(true, true, false);
-    else if (dp) BSIG_MDNN_LAUNCH(true, false, false);
-    else if (fac) BSIG_MDNN_LAUNCH(false, true, false);
-    else BSIG_MDNN_LAUNCH(false, false, false);
-  }
+#define BSIG_MDNN_LAUNCH(DP_, FAC_, WIDE_, FULL_) \
+  hipLaunchKernelGGL((mdnn_updates_kernel<DP_, FAC_, WIDE_, FULL_>), grid, dim3(kMT), g.lds, st, p)
+#define BSIG_MDNN_LAUNCH_WF(DP_, FAC_)                                      \
+  do {                                                                       \
+    if (g.wide && full) BSIG_MDNN_LAUNCH(DP_, FAC_, true, true);             \
+    else if (g.wide) BSIG_MDNN_LAUNCH(DP_, FAC_, true, false);               \
+    else if (full) BSIG_MDNN_LAUNCH(DP_, FAC_, false, true);                 \
+    else BSIG_MDNN_LAUNCH(DP_, FAC_, false, false);                          \
+  } while (0)
+  const bool dp = b.grads != nullptr, full = s.full_cov != 0;
+  if (dp && fac) BSIG_MDNN_LAUNCH_WF(true, true);
+  else if (dp) BSIG_MDNN_LAUNCH_WF(true, false);
+  else if (fac) BSIG_MDNN_LAUNCH_WF(false, true);
+  else BSIG_MDNN_LAUNCH_WF(false, false);
+#undef BSIG_MDNN_LAUNCH_WF
 #undef BSIG_MDNN_LAUNCH
   BSIG_CHECK_LAUNCH("mdnn_updates");
   return BSIG_OK;

@@ -183,6 +183,137 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
   out.lse = lse; out.uds = uds; out.bad = bad;
 }
 
+// jitter draw of element (row, d, k) for the thread-per-component kernels (full covariance)
+__device__ inline float jitter_u(const HeadArgs& a, int row, int d, int k) {
+  const int64_t e = ((int64_t)row * a.D + d) * a.K + k;
+  if (a.noise) return a.noise[e];
+  const uint64_t seed = a.dyn_rng ? a.dyn_rng[0] : a.seed;
+  const uint64_t sid = a.dyn_rng ? a.dyn_rng[1] : a.stream_id;
+  return u01(philox4x32_10(seed, sid, (uint64_t)e).v[0]);
+}
+
+// ---- full covariance, one wavefront per row (the persistent MDNN kernel's owners) ---------
+// Lane k < K runs component k: forward substitution with T_k = diag(sigma_k) + strict lower
+// (mdnn.py:152-158), back substitution for the gradients -- the same
+// operations in the same order as mdn_nll_kernel<true> (mdn_head.hip), which the per-phase
+// path runs with one thread per (row, component).  In: tile[Nh] raw head outputs, yv[D].  Out:
+// gradients in tile[K..Nh) and dlg[K] (without the jitter-scale term), the row's logsumexp,
+// the lane's sum(u * dL/dsigma); vq [3][D][K] scratch: v, q, and exp(pre) (left for the caller's
+// jitter-scale correction).  `eps_fn()` as in diag_row.
+template <typename EpsFn>
+__device__ __forceinline__ void full_row(const HeadArgs& a, int row, bool active, int lane,
+                                         float* T, const float* yv, float* rk, float* dlg,
+                                         float* vq, EpsFn&& eps_fn, RowOut& out) {
+  const int D = a.D, K = a.K, DK = D * K;
+  const int k = lane < K ? lane : 0;
+  const bool comp = active && lane < K;
+  float* v_ = vq + k;              // v_[i * K]
+  float* q_ = vq + DK + k;         // q_[i * K]
+  float* s0 = vq + 2 * DK + k;     // exp(pre)[i * K]
+  float logp = 0.f, w_k = 0.f, s_k = 0.f, csum = 1.f, mx = 0.f, den = 1.f;
+  bool bad = false;
+  if (comp) {   // softmax -> clamp -> renormalise, mdnn.py:109-111
+    mx = T[0];
+    for (int j = 1; j < K; ++j) mx = fmaxf(mx, T[j]);
+    den = 0.f;
+    for (int j = 0; j < K; ++j) den += expf(T[j] - mx);
+    csum = 0.f;
+    for (int j = 0; j < K; ++j) csum += fminf(fmaxf(expf(T[j] - mx) / den, a.min_w), 1.0f);
+    s_k = expf(T[k] - mx) / den;
+    w_k = fminf(fmaxf(s_k, a.min_w), 1.0f) / csum;
+    bad |= !isfinite(w_k);
+  }
+  const float eps = eps_fn();
+  if (comp) {
+    float quad = 0.f, logdet = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float mu = T[K + d * K + k];
+      const float sg0 = expf(T[K + DK + d * K + k]);
+      s0[d * K] = sg0;
+      float sg = sg0;
+      if (eps != 0.f) sg += jitter_u(a, row, d, k) * eps;
+      bad |= !(isfinite(mu) && isfinite(sg));
+      float res = yv[d] - mu;
+      const int base = K + 2 * DK + (d * (d - 1) / 2) * K + k;
+      for (int j = 0; j < d; ++j) {
+        const float lij = T[base + j * K];
+        bad |= !isfinite(lij);
+        res -= lij * v_[j * K];
+      }
+      const float vi = res / sg;
+      v_[d * K] = vi;
+      quad += vi * vi;
+      logdet += logf(sg);
+    }
+    logp = -0.5f * quad - logdet - (float)D * kHalfLog2Pi;
+    const float lp = fminf(fmaxf(logp, -a.ll_limit), a.ll_limit);   // mdnn.py:159
+    const float wc = fminf(fmaxf(w_k, a.min_w), 1.0f);              // mdnn.py:160
+    const float rv = lp + logf(wc);
+    bad |= !(isfinite(logp) && isfinite(rv));
+    rk[k] = rv;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float lse = 0.f;
+  if (active) {
+    float m2 = rk[0];
+    for (int j = 1; j < K; ++j) m2 = fmaxf(m2, rk[j]);
+    float se = 0.f;
+    for (int j = 0; j < K; ++j) se += expf(rk[j] - m2);
+    lse = m2 + logf(se);
+  }
+  float uds = 0.f, dlogit = 0.f;
+  if (a.d_out != nullptr && comp) {
+    const float sc = -expf(rk[k] - lse) * a.inv_norm;
+    const float g_lp = (logp >= -a.ll_limit && logp <= a.ll_limit) ? sc : 0.f;
+    for (int i = D - 1; i >= 0; --i) {   // q = T^{-T} v by back substitution
+      float acc = v_[i * K];
+      for (int j = i + 1; j < D; ++j) acc -= T[K + 2 * DK + (j * (j - 1) / 2 + i) * K + k] * q_[j * K];
+      float sg = s0[i * K];
+      if (eps != 0.f) sg += jitter_u(a, row, i, k) * eps;
+      q_[i * K] = acc / sg;
+    }
+    for (int d = 0; d < D; ++d) {
+      const float sg0 = s0[d * K];
+      float sg = sg0, u = 0.f;
+      if (eps != 0.f) { u = jitter_u(a, row, d, k); sg += u * eps; }
+      const float qi = q_[d * K], vi = v_[d * K];
+      const float dsg = g_lp * (qi * vi - 1.0f / sg);
+      const int base = K + 2 * DK + (d * (d - 1) / 2) * K + k;
+      for (int j = 0; j < d; ++j) T[base + j * K] = g_lp * qi * v_[j * K];
+      uds += u * dsg;
+      T[K + d * K + k] = g_lp * qi;
+      T[K + DK + d * K + k] = dsg * sg0;
+    }
+    // mixture-weight path: second clamp, renormalisation, first clamp, softmax
+    float s1 = 0.f;
+    for (int j = 0; j < K; ++j) {
+      const float sj = expf(T[j] - mx) / den;
+      const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
+      const float wcj = fminf(fmaxf(wj, a.min_w), 1.0f);
+      const float scj = -expf(rk[j] - lse) * a.inv_norm;
+      const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / wcj : 0.f;
+      s1 += gwj * wj;
+    }
+    float s2 = 0.f, gs_k = 0.f;
+    for (int j = 0; j < K; ++j) {
+      const float sj = expf(T[j] - mx) / den;
+      const float wj = fminf(fmaxf(sj, a.min_w), 1.0f) / csum;
+      const float wcj = fminf(fmaxf(wj, a.min_w), 1.0f);
+      const float scj = -expf(rk[j] - lse) * a.inv_norm;
+      const float gwj = (wj >= a.min_w && wj <= 1.0f) ? scj / wcj : 0.f;
+      const float gcj = (gwj - s1) / csum;
+      const float gsj = (sj >= a.min_w && sj <= 1.0f) ? gcj : 0.f;
+      s2 += gsj * sj;
+      if (j == k) gs_k = gsj;
+    }
+    dlogit = s_k * (gs_k - s2);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (a.d_out != nullptr && comp) dlg[k] = dlogit;   // separate slot: the logits stay readable
+  __builtin_amdgcn_wave_barrier();
+  out.lse = lse; out.uds = uds; out.bad = bad;
+}
+
 // ---- cross-workgroup sums inside one launch -----------------------------------
 // 8-byte {tag, value} granules: one relaxed agent-scope atomic store each
 // (written through to memory: the per-XCD L2s are not coherent with each other

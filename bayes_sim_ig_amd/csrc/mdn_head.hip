@@ -23,14 +23,6 @@
 
 namespace bsig {
 
-__device__ inline float jitter_u(const HeadArgs& a, int row, int d, int k) {
-  const int64_t e = ((int64_t)row * a.D + d) * a.K + k;
-  if (a.noise) return a.noise[e];
-  const uint64_t seed = a.dyn_rng ? a.dyn_rng[0] : a.seed;
-  const uint64_t sid = a.dyn_rng ? a.dyn_rng[1] : a.stream_id;
-  return u01(philox4x32_10(seed, sid, (uint64_t)e).v[0]);
-}
-
 // eps = EPS_NOISE * mean(exp(pre)) from the partial sums (every workgroup
 // adds the same values in the same order)
 __device__ inline float jitter_eps(const HeadArgs& a, float* red) {

@@ -73,7 +73,8 @@ def synth_pairs(cfg, n, seed, device):
 def model_cfg(cfg):
     return {'modelClass': cfg['model'], 'summarizerFxn': cfg['summarizer'],
             'trainTrajLen': cfg['t'], 'components': cfg['k'],
-            'hiddenLayers': cfg['hidden'], 'lr': 1e-3, 'nFeat': cfg['n_feat']}
+            'hiddenLayers': cfg['hidden'], 'lr': 1e-3, 'nFeat': cfg['n_feat'],
+            'fullCovariance': bool(cfg.get('full', False))}
 
 
 def build_gpu_model(pkg, cfg, device, seed):
@@ -90,7 +91,8 @@ def build_oracle(cfg, in_dim, seed, eps_noise, freqs=None):
     torch.manual_seed(seed)
     np.random.seed(seed)
     kw = dict(input_dim=in_dim, output_dim=cfg['d'], output_lows=np.zeros(cfg['d']),
-              output_highs=np.ones(cfg['d']), n_gaussians=cfg['k'], full_covariance=False,
+              output_highs=np.ones(cfg['d']), n_gaussians=cfg['k'],
+              full_covariance=bool(cfg.get('full', False)),
               lr=1e-3, activation=torch.nn.Tanh, eps_noise=eps_noise)
     if cfg['model'] == 'MDRFF':
         if freqs is None:

@@ -387,6 +387,8 @@ def test_data_parallel_path_single_rank_equals_fused(B):
     dict(n=40, i=9, d=3, k=4, hidden=(128, 128), full=False, nu=7, bs=100, tf=0.5),
     dict(n=30, i=6, d=2, k=3, hidden=(128, 128), full=False, nu=5, bs=8, tf=0.0),
     dict(n=33, i=301, d=6, k=2, hidden=(128, 128), full=False, nu=4, bs=10, tf=0.2),
+    dict(n=33, i=5, d=6, k=2, hidden=(128, 128), full=True, nu=4, bs=10, tf=0.2),
+    dict(n=5, i=4, d=2, k=2, hidden=(128, 128), full=True, nu=1, bs=3, tf=0.2),
     # the unconditional refit of BayesSim.predict: one constant input (bayes_sim.py:160-176)
     dict(n=200, i=1, d=2, k=3, hidden=(128, 128), full=False, nu=6, bs=20, tf=0.2),
 ])
