@@ -10,6 +10,7 @@ Adam runs over the flat buffer, and ``run_training`` replays the whole update
 from a HIP graph (csrc/estimator.hip).  There is no CPU fallback.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -92,7 +93,8 @@ class _FusedNLL(torch.autograd.Function):
         m = ctx.model
         tmp = torch.empty_like(m._flat_grad)
         m.loss_and_grad(ctx.x, ctx.y, noise=ctx.noise, seed=ctx.seed, grads_out=tmp)
-        grads = [tmp[o:o + n].view(shape) * grad_out for o, n, shape in m._param_slices]
+        grads = [tmp[o:o + int(np.prod(full))].view(full)[tuple(slice(0, d) for d in shape)] * grad_out
+                 for o, full, shape in m._param_slices]
         return (None, None, None, None, None, None, *grads)
 
 
@@ -102,6 +104,7 @@ class MDNN(nn.Module):
     EPS_NOISE = 1.e-5    # small noise e.g. for numerical stability
     VERBOSE = True       # print the 6 train/test losses per call like the reference
     USE_GRAPH = True     # replay the update from a HIP graph
+    PAD_TRUNK_TO = 128   # hidden width the persistent update kernel is built for
 
     def __init__(self, input_dim, output_dim, output_lows, output_highs,
                  n_gaussians, full_covariance, hidden_layers, activation, lr,
@@ -140,6 +143,17 @@ class MDNN(nn.Module):
         if self.L_size > 0 and full_covariance:
             self.Lower = nn.Linear(width, self.L_size * n_gaussians)
         self._hidden = [int(h) for h in hidden_layers]
+        # A two-layer tanh trunk narrower than 128 is STORED zero-padded to [128, 128] (the
+        # parameters are views of the leading blocks): the padding units see zero weights, put
+        # out tanh(0) = 0 and receive exactly zero gradients, so Adam leaves them at zero and
+        # the network is the reference's bit for bit -- and the persistent update kernel, which
+        # is built for the reference's default [128, 128] trunk, covers it (the reference's own
+        # tests/regression_tests.py:59 uses (24, 24)).
+        self._hidden_stored = list(self._hidden)
+        if (len(self._hidden) == 2 and max(self._hidden) <= self.PAD_TRUNK_TO and
+                min(self._hidden) >= 1 and self._hidden != [self.PAD_TRUNK_TO] * 2 and
+                activation is nn.Tanh and os.environ.get('BSIG_NO_TRUNK_PAD') != '1'):
+            self._hidden_stored = [self.PAD_TRUNK_TO] * 2
         self._rff_feats = int(kwargs.get('_rff_feats', 0))
         self._rff_scale = float(kwargs.get('_rff_scale', 0.0))
         self._plan = None
@@ -153,7 +167,7 @@ class MDNN(nn.Module):
         cfg = _lib.MdnCfg()
         cfg.input_dim = int(self.input_dim)
         cfg.n_hidden = len(self._hidden)
-        for i, h in enumerate(self._hidden):
+        for i, h in enumerate(self._hidden_stored):
             cfg.hidden[i] = h
         cfg.activation = _ACT_CODES[self.activation]
         cfg.rff_feats = self._rff_feats
@@ -188,15 +202,22 @@ class MDNN(nn.Module):
         flat = torch.zeros(total, dtype=torch.float32, device=device)
         grads = torch.zeros(total, dtype=torch.float32, device=device)
         self._param_slices = []
+        # stored input width of every Linear: the (possibly padded) width of the layer below
+        widths = [self.input_dim if self._rff_feats == 0 else self._rff_feats] + self._hidden_stored
         with torch.no_grad():
             for i, mod in enumerate(self._linears()):
+                l = min(i, len(self._hidden))            # trunk layer l, or the heads (on the last width)
+                rows = self._hidden_stored[i] if i < len(self._hidden) else mod.weight.shape[0]
                 for j, prm in enumerate((mod.weight, mod.bias)):
                     o = int(offs[2 * i + j])
-                    self._param_slices.append((o, prm.numel(), tuple(prm.shape)))
-                    view = flat[o:o + prm.numel()].view(prm.shape)
+                    full = (rows, widths[l]) if j == 0 else (rows,)
+                    real = tuple(prm.shape)
+                    sub = tuple(slice(0, d) for d in real)
+                    self._param_slices.append((o, full, real))
+                    view = flat[o:o + int(np.prod(full))].view(full)[sub]
                     view.copy_(prm.detach().to(dtype=torch.float32))
                     prm.data = view
-                    prm.grad = grads[o:o + prm.numel()].view(prm.shape)
+                    prm.grad = grads[o:o + int(np.prod(full))].view(full)[sub]
         self._flat, self._flat_grad = flat, grads
         self._exp_avg = torch.zeros_like(flat)
         self._exp_avg_sq = torch.zeros_like(flat)

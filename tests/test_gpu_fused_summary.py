@@ -117,7 +117,7 @@ def test_fused_first_layer_ragged_minibatch_and_small_chunk(B):
 def test_plans_that_read_summary_rows_get_them_materialised(B):
     """A trunk the persistent kernel does not cover, and the per-phase kernels
     (BSIG_NO_PERSISTENT=1): run_training expands the factor rows itself."""
-    cfg = _cfg(10, 8, 12, hidden=(24, 24))
+    cfg = _cfg(10, 8, 12, hidden=(24, 24, 24))
     a = _chunk(B, cfg, lazy=False)
     b = _chunk(B, cfg, lazy=True)
     assert B._lib.load().bsig_fit_is_persistent(b[2].model._plan) == 0
@@ -136,7 +136,7 @@ def test_bind_refuses_factor_rows_where_kernels_need_summaries(B):
     L, lib = B._lib, B._lib.load()
     torch.manual_seed(0)
     m = B.MDNN(input_dim=302, output_dim=2, output_lows=np.zeros(2), output_highs=np.ones(2),
-               n_gaussians=3, full_covariance=False, hidden_layers=(24, 24),
+               n_gaussians=3, full_covariance=False, hidden_layers=(24, 24, 24),
                activation=torch.nn.Tanh, lr=1e-3, device=DEV)
     x = torch.randn(100, 304, device=DEV)[:, :302]
     m.run_training(x, torch.rand(100, 2, device=DEV), 5, 10)      # creates and binds a plan

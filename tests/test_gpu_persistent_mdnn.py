@@ -130,11 +130,49 @@ def test_persistent_mdnn_ragged_shapes_match_phase_kernels(B, n, batch, n_update
     assert torch.allclose(a[1], b[1], atol=1e-4, rtol=1e-3)
 
 
+def test_narrower_two_layer_trunks_run_zero_padded_in_the_persistent_kernel(B):
+    """A (24, 24) tanh trunk (the reference's tests/regression_tests.py:59) is stored zero-padded
+    to [128, 128]: the persistent kernel covers it, the padding stays exactly zero, and the fit
+    matches the per-phase kernels on the unpadded network and the oracle."""
+    import bench
+    from oracle import summarize as osum
+    cfg = _cfg(2, 10, 'summary_start', 21, 3, 1, hidden=(24, 24))
+    torch.set_num_threads(8)
+    logs, flat, bs, (theta, states, actions, ids) = _chunk(B, cfg, eps=0.0)
+    m = bs.model
+    assert B._lib.load().bsig_fit_is_persistent(m._plan) == 2
+    assert m.net[0].weight.shape == (24, 40) and m.net[2].weight.shape == (24, 24)
+    assert m.pi.weight.shape == (10, 24) and m.state_dict()['mu.weight'].shape == (20, 24)
+    # every stored element outside the parameters' views is still exactly zero
+    mask = torch.ones_like(m._flat, dtype=torch.bool)
+    for o, full, real in m._param_slices:
+        blk = mask[o:o + int(np.prod(full))].view(full)
+        blk[tuple(slice(0, d) for d in real)] = False
+    assert float(m._flat[mask].abs().max()) == 0.0
+    assert float(m._exp_avg[mask].abs().max()) == 0.0
+    ref, ora = _oracle_chunk(B, cfg, bs, theta, states, actions, ids)
+    for key in ('train_loss', 'test_loss'):
+        got, exp = np.array(logs[key]), np.array(ref[key])
+        assert np.all(np.abs(got - exp) <= 1e-4 * np.maximum(np.abs(exp), 1.0)), (key, got, exp)
+    os.environ['BSIG_NO_TRUNK_PAD'] = '1'
+    try:
+        logs_u, flat_u, bs_u, _ = _chunk(B, cfg, eps=0.0)
+    finally:
+        os.environ.pop('BSIG_NO_TRUNK_PAD', None)
+    assert B._lib.load().bsig_fit_is_persistent(bs_u.model._plan) == 0
+    assert bs_u.model._flat.numel() < m._flat.numel()
+    for key in ('train_loss', 'test_loss'):
+        assert np.allclose(logs[key], logs_u[key], rtol=3e-5, atol=3e-5)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), bs_u.model.state_dict().items()):
+        assert k1 == k2 and torch.allclose(v1, v2, atol=1e-4, rtol=1e-3), k1
+
+
 def test_other_trunks_keep_the_phase_kernels(B):
-    """Only the reference's default trunk [128, 128] is covered."""
-    cfg = _cfg(3, 5, hidden=(64, 64))
-    _, _, bs, _ = _chunk(B, cfg, n_updates=5, eps=0.0)
-    assert B._lib.load().bsig_fit_is_persistent(bs.model._plan) == 0
+    """Three hidden layers, a trunk wider than 128: per-phase kernels."""
+    for hidden in ((64, 64, 64), (256, 128)):
+        cfg = _cfg(3, 5, hidden=hidden)
+        _, _, bs, _ = _chunk(B, cfg, n_updates=5, eps=0.0)
+        assert B._lib.load().bsig_fit_is_persistent(bs.model._plan) == 0
 
 
 def test_nonfinite_summary_raises_through_persistent_mdnn(B):

@@ -180,3 +180,40 @@ def test_quasi_random_frequencies_are_not_collinear():
     # low discrepancy survives the scrambling: every coordinate fills its 10 deciles evenly
     counts = np.stack([np.histogram(pts[:, j], bins=10, range=(0, 1))[0] for j in range(d)])
     assert counts.min() >= 5 and counts.max() <= 15           # iid uniform: 2..20
+
+
+def test_narrow_two_layer_trunk_is_stored_zero_padded():
+    """A two-layer tanh trunk narrower than 128 lives zero-padded to [128, 128] in the flat
+    buffer (so that the persistent update kernel covers it); the module surface -- parameter
+    shapes, state_dict keys, load_state_dict -- is the reference's."""
+    import numpy as np
+    import torch
+    from bayes_sim_ig_amd import MDNN
+    kw = dict(input_dim=40, output_dim=2, output_lows=np.zeros(2), output_highs=np.ones(2),
+              n_gaussians=10, full_covariance=True, activation=torch.nn.Tanh, lr=1e-3)
+    torch.manual_seed(3)
+    m = MDNN(hidden_layers=(24, 24), **kw)
+    torch.manual_seed(3)
+    ref = MDNN(hidden_layers=(128, 128), **kw)
+    assert m._hidden == [24, 24] and m._hidden_stored == [128, 128]
+    assert m._flat.numel() == ref._flat.numel()
+    sd = m.state_dict()
+    assert list(sd) == list(ref.state_dict())
+    assert sd['net.fcon0.weight'].shape == (24, 40) and sd['net.fcon1.weight'].shape == (24, 24)
+    assert sd['pi.weight'].shape == (10, 24) and sd['Lower.weight'].shape == (10, 24)
+    total_real = sum(v.numel() for v in sd.values())
+    assert int((m._flat != 0).sum()) <= total_real
+    # the same torch-RNG stream as an unpadded (24, 24) reference-shaped model
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(40, 24)
+    assert torch.equal(sd['net.fcon0.weight'], lin.weight.detach())
+    # load_state_dict writes through the views into the flat buffer
+    new = {k: torch.full_like(v, 0.5) for k, v in sd.items()}
+    m.load_state_dict(new)
+    assert float(m._flat.sum()) == 0.5 * total_real
+    m.net[0].weight.grad.fill_(1.0)
+    assert float(m._flat_grad.sum()) == 24 * 40
+    # three layers, relu, wide trunks: stored as they are
+    assert MDNN(hidden_layers=(24, 24, 24), **kw)._hidden_stored == [24, 24, 24]
+    assert MDNN(hidden_layers=(24, 24), **dict(kw, activation=torch.nn.ReLU))._hidden_stored == [24, 24]
+    assert MDNN(hidden_layers=(256, 64), **kw)._hidden_stored == [256, 64]
