@@ -64,9 +64,11 @@ class PendingLogs:
         else:
             train_list, test_list, bad = host[:n_e], host[n_e:2 * n_e], host[2 * n_e]
         if int(bad) & 2:      # a bounded cross-workgroup poll of the persistent kernel gave up
-            raise RuntimeError('persistent update kernel timed out waiting for another workgroup '
-                               '(GPU shared or partitioned?); set BSIG_NO_PERSISTENT=1 to use the '
-                               'per-phase kernels')
+            raise RuntimeError('persistent update kernel timed out waiting for another workgroup: its '
+                               'workgroups (one per CU) were not all resident -- is the GPU shared with '
+                               'another process or partitioned?  The parameters and Adam moments of this '
+                               'call are partially updated (reload them before training on); set '
+                               'BSIG_NO_PERSISTENT=1 to use the per-phase kernels')
         assert bad == 0, 'non-finite value in forward / loss (mdnn.py:120-124,162-174)'
         if self.n_test == 0:
             test_list = [float('nan')] * n_e   # mean over an empty test split
