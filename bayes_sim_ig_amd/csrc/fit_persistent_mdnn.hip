@@ -278,21 +278,34 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   const bool fresh = !DP && step0 == 0;
   const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
   const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
+  // (three passes: every load is issued before the first store of a data-parallel launch's
+  // pending Adam step -- interleaved, the possibly aliasing stores serialise the loads)
+  {
+    float Wv[16], Gq[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int n = n0 + acc_row(i, h);
-    float wv = 0.f;
-    Mr[i] = 0.f; Vr[i] = 0.f;
-    if (col_ok) {
-      const int64_t off = p.w1_off + (int64_t)n * p.I + k0 + kcol;
-      wv = p.params[off];
-      if (!fresh) { Mr[i] = p.m1[off]; Vr[i] = p.m2[off]; }
-      if (pend) {   // written back at once: a data-parallel launch changes the tile only here
-        wv = adam_weight(p.grads[off], Mr[i], Vr[i], wv, pa0, pa1, ak);
-        p.params[off] = wv; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + acc_row(i, h);
+      Wv[i] = 0.f; Gq[i] = 0.f; Mr[i] = 0.f; Vr[i] = 0.f;
+      if (col_ok) {
+        const int64_t off = p.w1_off + (int64_t)n * p.I + k0 + kcol;
+        Wv[i] = p.params[off];
+        if (!fresh) { Mr[i] = p.m1[off]; Vr[i] = p.m2[off]; }
+        if (pend) Gq[i] = p.grads[off];
       }
     }
-    Wl[acc_row(i, h) * kMPitch + kcol] = wv;
+    if (pend) {   // written back at once: a data-parallel launch changes the tile only here
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Wv[i] = adam_weight(Gq[i], Mr[i], Vr[i], Wv[i], pa0, pa1, ak);
+      if (col_ok) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t off = p.w1_off + (int64_t)(n0 + acc_row(i, h)) * p.I + k0 + kcol;
+          p.params[off] = Wv[i]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Wl[acc_row(i, h) * kMPitch + kcol] = Wv[i];
   }
   if (ks == 0 && tid < kMNB) {
     const int64_t off = p.b1_off + n0 + tid;
@@ -546,17 +559,28 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
   // waves 0-3: element i of lane (h, l31) of wave w <-> W[n0 + acc_row(i, h)][32w + l31]
   float Wr[16], Mr[16], Vr[16];
   const int kcol = 32 * (w & 3) + l31;
+  {
+    float Gq[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int n = n0 + acc_row(i, h);
-    Wr[i] = 0.f; Mr[i] = 0.f; Vr[i] = 0.f;
-    if (w < 4 && n < nrows) {
-      const int64_t off = w_off + (int64_t)n * kMH + kcol;
-      Wr[i] = p.params[off];
-      if (!fresh) { Mr[i] = p.m1[off]; Vr[i] = p.m2[off]; }
-      if (pend) {
-        Wr[i] = adam_weight(p.grads[off], Mr[i], Vr[i], Wr[i], pa0, pa1, ak);
-        xwg_store(p.params + off, Wr[i]); p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + acc_row(i, h);
+      Wr[i] = 0.f; Mr[i] = 0.f; Vr[i] = 0.f; Gq[i] = 0.f;
+      if (w < 4 && n < nrows) {
+        const int64_t off = w_off + (int64_t)n * kMH + kcol;
+        Wr[i] = p.params[off];
+        if (!fresh) { Mr[i] = p.m1[off]; Vr[i] = p.m2[off]; }
+        if (pend) Gq[i] = p.grads[off];
+      }
+    }
+    if (pend) {   // (all loads before the first store: see the tile workgroups)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + acc_row(i, h);
+        if (w < 4 && n < nrows) {
+          const int64_t off = w_off + (int64_t)n * kMH + kcol;
+          Wr[i] = adam_weight(Gq[i], Mr[i], Vr[i], Wr[i], pa0, pa1, ak);
+          xwg_store(p.params + off, Wr[i]); p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+        }
       }
     }
   }
