@@ -41,6 +41,12 @@ CONFIGS = {
     # MDNN kernel's wide-head path) -- a side case, not a BASELINE config
     'ant_yaml': dict(task='Ant (cfg/ant.yaml)', model='MDNN', summarizer='summary_corrdiff', t=51,
                      sd=60, ad=8, d=17, k=10, hidden=[128, 128], n_feat=0, pairs=20_000),
+    # cfg/shadow_hand_more.yaml:73-81 as shipped: the widest summary of the reference's YAMLs
+    # (I = 105002, a 13.4 M-parameter first layer: 161 MB of weights + Adam moments -- more than
+    # the chip's LDS and registers hold, so no persistent kernel: per-phase kernels, HBM bound)
+    'shadow_more': dict(task='ShadowHand (cfg/shadow_hand_more.yaml)', model='MDNN',
+                        summarizer='summary_corrdiff', t=51, sd=211, ad=20, d=32, k=10,
+                        hidden=[128, 128], n_feat=0, pairs=5_000),
     'cfg5': dict(task='ShadowHand', model='MDRFF', summarizer='summary_start', t=11, sd=211,
                  ad=20, d=32, k=4, hidden=[], n_feat=4096, pairs=100_000),
 }
