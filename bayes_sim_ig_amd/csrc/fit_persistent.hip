@@ -78,6 +78,43 @@ struct PersistArgs {
   long long* prof;   // diagnostics: [G][kProfUpdates][16] wall-clock stamps, or null
 };
 
+// The 32-column tile of summed partial products a tile workgroup holds in X (pitch kPbufPitch) to
+// its slab rows: every lane stores 16 bytes (8 lanes per 128-byte row segment), all wavefronts.
+__device__ __forceinline__ void slab_tile_store(const float* X, float* dst, int rows, int ld, int tid) {
+  const __amdgpu_buffer_rsrc_t sr = xwg_buffer(dst);
+  for (int idx = tid; idx < rows * (kNB / 4); idx += kPT) {
+    const int row = idx >> 3, c4 = (idx & 7) * 4;
+    const float* x = X + row * kPbufPitch + c4;
+    xwg_store4(sr, row * ld + c4, x[0], x[1], x[2], x[3]);
+  }
+}
+
+// A row owner's sum over the k-slices of its rows' partial products: slabs [k_slices][B][ld], rows
+// r0.., `nrows` of them -> out[r * out_pitch + col] (col < n_cols), slices added in order, 16 loads
+// in flight per lane.  One dword per lane: measured faster here than 16-byte loads on a quarter of
+// the lanes (1.4 us against 1.6 us for 16 slices of 260 columns) -- the loads are latency-bound and
+// more wavefronts issue them.  `fn(col, v)` sees every finished element.
+template <typename F>
+__device__ __forceinline__ void slab_rows_sum(const float* slabs, int k_slices, int B, int ld, int nrows,
+                                              int n_cols, float* out, int out_pitch, int tid, F&& fn) {
+  const int64_t zs = (int64_t)B * ld;
+  for (int idx = tid; idx < nrows * n_cols; idx += kPT) {
+    const int r = idx / n_cols, col = idx - r * n_cols;
+    const float* src = slabs + (int64_t)r * ld + col;
+    float v = 0.f;
+    for (int z = 0; z < k_slices; z += 16) {
+      float q[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) q[u] = xwg_load(src + (int64_t)min(z + u, k_slices - 1) * zs);
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (z + u < k_slices) v += q[u];
+    }
+    out[r * out_pitch + col] = v;
+    fn(col, v);
+  }
+}
+
 // number of evaluation points it % every == 0 strictly before update s (the evaluation after
 // the last update of a call is not one of them)
 __device__ __forceinline__ int evals_before(int s, int every) { return s == 0 ? 0 : (s - 1) / every + 1; }
@@ -167,14 +204,15 @@ __device__ __forceinline__ void tile_eval(const PersistArgs& p, const float* Wl,
     __syncthreads();
     if (kh == 0) {
       const float bias = ks == 0 ? biasl[l31] : 0.f;
-      float* dst = p.eval_slabs + ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B) * NhP + n0 + l31;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = mt * 32 + acc_row(i, h);
-        const float v = acc[i] + X[row * kPbufPitch + l31] + bias;
-        if (row < rows) xwg_store(dst + (int64_t)row * NhP, v);
+        float* x = X + (mt * 32 + acc_row(i, h)) * kPbufPitch + l31;
+        *x = acc[i] + *x + bias;
       }
     }
+    __syncthreads();
+    slab_tile_store(X, p.eval_slabs + ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B) * NhP + n0,
+                    rows, NhP, tid);
   }
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
@@ -331,14 +369,14 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
       __syncthreads();
       if (kh == 0) {
         const float bias = ks == 0 ? biasl[l31_l] : 0.f;
-        float* dst = p.slabs + (int64_t)ks * B * NhP + n0 + l31_l;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int row = mt * 32 + acc_row(i, h_l);
-          const float v = acc[i] + X[row * kPbufPitch + l31_l] + bias;
-          if (row < B) xwg_store(dst + (int64_t)row * NhP, v);
+          float* x = X + (mt * 32 + acc_row(i, h_l)) * kPbufPitch + l31_l;
+          *x = acc[i] + *x + bias;
         }
       }
+      __syncthreads();
+      slab_tile_store(X, p.slabs + (int64_t)ks * B * NhP + n0, B, NhP, tid_l);
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       if (tid_l == 0)
@@ -376,20 +414,31 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     {
       const float c = red[62];
       const int sg_lo = p.K + p.D * p.K, sg_hi = p.K + 2 * p.D * p.K;
-      for (int base = 0; base < p.FR * kNB; base += kPT * 8) {
-        float q[8], e[8];
+      const bool any_e = c != 0.f && n0 + kNB > sg_lo && n0 < sg_hi;     // workgroup-uniform
+      const __amdgpu_buffer_rsrc_t dr = xwg_buffer(p.d_out + n0), er = xwg_buffer(p.e_out + n0);
+      for (int base = 0; base < p.FR * (kNB / 4); base += kPT * 4) {
+        f32x4 q[4], e[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
           const int idx = base + u * kPT + tid_l;
-          const int b = idx >> 5, n = n0 + (idx & 31);
-          const bool ok = idx < p.FR * kNB && b < B;
-          q[u] = ok ? xwg_load(p.d_out + (int64_t)b * NhP + n) : 0.f;
-          e[u] = (ok && c != 0.f && n >= sg_lo && n < sg_hi) ? xwg_load(p.e_out + (int64_t)b * NhP + n) : 0.f;
+          const int b = idx >> 3, c4 = (idx & 7) * 4;
+          const bool ok = idx < p.FR * (kNB / 4) && b < B;
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          q[u] = ok ? xwg_load4(dr, b * NhP + c4) : zero;
+          e[u] = ok && any_e ? xwg_load4(er, b * NhP + c4) : zero;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
           const int idx = base + u * kPT + tid_l;
-          if (idx < p.FR * kNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u] + c * e[u];
+          const int b = idx >> 3, c4 = (idx & 7) * 4;
+          if (idx < p.FR * (kNB / 4)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int n = n0 + c4 + j;
+              const float ev = (n >= sg_lo && n < sg_hi) ? e[u][j] : 0.f;   // (other columns of e_out hold no data)
+              X[(c4 + j) * DOP + b] = q[u][j] + c * ev;
+            }
+          }
         }
       }
     }
@@ -516,8 +565,6 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
   const int row = r0 + w;
   const bool owner_wave = w < p.R;
   const bool active = owner_wave && row < B;
-  const int nelem = min(p.R, B - r0) * Nh;
-  const int64_t zs = (int64_t)B * NhP;
 
   // ---- held-out evaluation number eidx (jitter stream `stream`): slot s = pass * R + r
   //      <-> held-out row pass * B + r0 + r, one wavefront per slot, forward only ---------
@@ -527,23 +574,16 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
     if (w == 0) flags_wait(p.flag_eval, p.G, etag, lane, flagp);
     __syncthreads();
     float eacc = 0.f;
-    for (int idx = tid; idx < nslots * Nh; idx += kPT) {
-      const int sl = idx / Nh, col = idx - sl * Nh;
-      const int pass = sl / p.R, r = sl - pass * p.R;
-      const bool valid = r0 + r < B && pass * B + r0 + r < p.n_test;
-      const float* src = p.eval_slabs +
-                         ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices) * B + min(r0 + r, B - 1)) * NhP + col;
-      float v = 0.f;
-      for (int z = 0; z < p.k_slices; z += 16) {
-        float q[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) q[u] = xwg_load(src + (int64_t)min(z + u, p.k_slices - 1) * zs);
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (z + u < p.k_slices) v += q[u];
-      }
-      X[sl * per_wave + col] = valid ? v : 0.f;
-      if (valid && col >= K + DK && col < K + 2 * DK) eacc += expf(v);
+    for (int pass = 0; pass < p.eval_passes; ++pass) {
+      const int nr = min(min(p.R, B - r0), p.n_test - pass * B - r0);
+      // (slots of rows past the held-out set are not read by anyone)
+      if (nr > 0)
+        slab_rows_sum(p.eval_slabs + ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices) * B + r0) * NhP,
+                      p.k_slices, B, NhP, nr, Nh, X + pass * p.R * per_wave, per_wave, tid,
+                      [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
+      const int nz = max(nr, 0);          // slots past the held-out set: zeros (their rows are masked)
+      for (int idx = tid; idx < (p.R - nz) * Nh; idx += kPT)
+        X[(pass * p.R + nz + idx / Nh) * per_wave + idx % Nh] = 0.f;
     }
     eacc = wave_sum_dpp(eacc);
     if (lane == 0) red[w] = eacc;
@@ -611,21 +651,8 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
     __syncthreads();
     BSIG_STAMP(4);
     float eacc = 0.f;
-    for (int idx = tid; idx < nelem; idx += kPT) {
-      const int r = idx / Nh, col = idx - r * Nh;
-      const float* src = p.slabs + (int64_t)(r0 + r) * NhP + col;
-      float v = 0.f;
-      for (int z = 0; z < p.k_slices; z += 16) {
-        float q[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) q[u] = xwg_load(src + (int64_t)min(z + u, p.k_slices - 1) * zs);
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (z + u < p.k_slices) v += q[u];
-      }
-      X[r * per_wave + col] = v;
-      if (col >= K + DK && col < K + 2 * DK) eacc += expf(v);
-    }
+    slab_rows_sum(p.slabs + (int64_t)r0 * NhP, p.k_slices, B, NhP, min(p.R, B - r0), Nh, X, per_wave, tid,
+                  [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
     eacc = wave_sum_dpp(eacc);
     if (lane == 0) red[w] = eacc;
     __syncthreads();

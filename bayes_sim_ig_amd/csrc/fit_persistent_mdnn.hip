@@ -84,7 +84,7 @@ struct MdnnArgs {
   // and their share of d_out Wh for ALL minibatch rows; per update owners -> (h2) -> head blocks
   // -> (o_wide) -> owners -> (d_out) -> head blocks -> (dz2_part) -> owners
   int wide, n_hb;
-  float* o_wide;     // [B][NhP]        raw head outputs, bias included
+  float* o_wide;     // [n_hb][B][32]   raw head outputs, bias included (block-major like the slabs)
   float* dz2_part;   // [n_hb][B][128]  partial d_out Wh of each head block
   unsigned* flag_h2; unsigned* flag_o; unsigned* flag_dout; unsigned* flag_dz2;
   unsigned launch_tag;   // flag_pack value of THIS launch: the small weights (and the W2 packs)
@@ -233,12 +233,12 @@ __device__ __forceinline__ void mdnn_tile_eval(const MdnnArgs& p, const float* W
     __syncthreads();
     if (kh == 0) {
       const float bias = ks == 0 ? biasl[l31] : 0.f;
-      float* dst = p.eval_slabs + ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B) * kMH + n0 + l31;
+      float* dst = fresh_ptr(p.eval_slabs + ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B + mt * 32 + 4 * h) * kMH + n0 + l31);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = mt * 32 + acc_row(i, h);
         const float v = acc[i] + X[row * kMPbuf + l31] + bias;
-        if (row < rows) xwg_store(dst + (int64_t)row * kMH, v);
+        if (row < rows) xwg_store(dst + acc_row0(i) * kMH, v);
       }
     }
   }
@@ -381,12 +381,12 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
       __syncthreads();
       if (kh == 0) {
         const float bias = ks == 0 ? biasl[l31_l] : 0.f;
-        float* dst = p.slabs + (int64_t)ks * B * kMH + n0 + l31_l;
+        float* dst = fresh_ptr(p.slabs + ((int64_t)ks * B + mt * 32 + 4 * h_l) * kMH + n0 + l31_l);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = mt * 32 + acc_row(i, h_l);
           const float v = acc[i] + X[row * kMPbuf + l31_l] + bias;
-          if (row < B) xwg_store(dst + (int64_t)row * kMH, v);
+          if (row < B) xwg_store(dst + acc_row0(i) * kMH, v);
         }
       }
       __builtin_amdgcn_s_waitcnt(0);
@@ -663,8 +663,10 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
       // ---- wide heads: head outputs of ALL minibatch rows for this block's 32 columns ------
       if (w == 0) flags_wait(p.flag_h2, p.n_owner, epoch, lane, flagp);
       __syncthreads();
+      BSIG_MSTAMP(7);
       BSIG_LOAD_ACTIVATIONS()
       __syncthreads();
+      BSIG_MSTAMP(8);
       {
         const int mt = w & 3, kh = w >> 2;
         f32x16 acc;
@@ -681,23 +683,29 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
         }
+        BSIG_MSTAMP(1);
         if (kh == 1) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) Xo[(mt * 32 + acc_row(i, h)) * kMPbuf + l31] = acc[i];
         }
         __syncthreads();
+        BSIG_MSTAMP(2);
         if (kh == 0) {
           const float bias = bsh[l31];
-          float* dst = p.o_wide + n0 + l31;
+          // block-major: [n_hb][B][32]
+          float* dst = fresh_ptr(p.o_wide + ((int64_t)hb * B + mt * 32 + 4 * h) * kMNB + l31);
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int row = mt * 32 + acc_row(i, h);
-            if (row < B) xwg_store(dst + (int64_t)row * p.NhP, acc[i] + Xo[row * kMPbuf + l31] + bias);
+            if (row < B) xwg_store(dst + acc_row0(i) * kMNB, acc[i] + Xo[row * kMPbuf + l31] + bias);
           }
         }
+        BSIG_MSTAMP(11);
         __builtin_amdgcn_s_waitcnt(0);
+        BSIG_MSTAMP(3);
         __syncthreads();
         if (tid == 0) flag_raise(p.flag_o, hb, epoch);
+        BSIG_MSTAMP(9);
       }
       // ---- ... and this block's share of d_out Wh (with the weights of this update's forward)
       if (w == 0) flags_wait(p.flag_dout, p.n_owner, epoch, lane, flagp);
@@ -722,16 +730,17 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
                                                          acc, 0, 0, 0);
             }
           }
-          float* dst = p.dz2_part + (int64_t)hb * B * kMH + col;
+          float* dst = fresh_ptr(p.dz2_part + ((int64_t)hb * B + mt * 32 + 4 * h) * kMH + col);
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int row = mt * 32 + acc_row(i, h);
-            if (row < B) xwg_store(dst + (int64_t)row * kMH, acc[i]);
+            if (row < B) xwg_store(dst + acc_row0(i) * kMH, acc[i]);
           }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) flag_raise(p.flag_dz2, hb, epoch);
+        BSIG_MSTAMP(10);
       }
     } else {
       if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
@@ -805,6 +814,36 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
 
 // ---- row-owner workgroups: layers 2.., NLL forward / backward ---------------------
 // FULL: full covariance (one lane per component runs the triangular solves: full_row)
+// A row owner's sum over the k-slices of its rows' layer-1 partial products: slabs [k_slices][B][128];
+// item = (row, column quad), kSumSub threads share an item's slices (16-byte loads, all in flight),
+// their partial sums meet in a fixed order through `part` ([kSumSub - 1][kSumItems] quads of LDS).
+// Returns the item's sum to the threads tid < kSumItems.  Ends on a workgroup barrier.
+constexpr int kSumItems = kMR * (kMH / 4), kSumSub = kMT / kSumItems, kSumFlight = 12;
+__device__ __forceinline__ f32x4 slab_quads_sum(const float* slabs, int k_slices, int zs, int row, int tid,
+                                                float* part) {
+  const int item = tid & (kSumItems - 1), sub = tid / kSumItems;
+  const int c4 = (item & 31) * 4;
+  const __amdgpu_buffer_rsrc_t sr = xwg_buffer(slabs);
+  const int per = ceil_div(k_slices, kSumSub);
+  const int z_lo = sub * per, z_hi = min(z_lo + per, k_slices);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int z = z_lo; z < z_hi; z += kSumFlight) {
+    f32x4 q[kSumFlight];
+#pragma unroll
+    for (int u = 0; u < kSumFlight; ++u) q[u] = xwg_load4(sr, min(z + u, z_hi - 1) * zs + row * kMH + c4);
+#pragma unroll
+    for (int u = 0; u < kSumFlight; ++u)
+      if (z + u < z_hi) v += q[u];
+  }
+  if (sub > 0) *reinterpret_cast<f32x4*>(part + ((sub - 1) * kSumItems + item) * 4) = v;
+  __syncthreads();
+  if (sub == 0) {
+#pragma unroll
+    for (int q = 1; q < kSumSub; ++q) v += *reinterpret_cast<const f32x4*>(part + ((q - 1) * kSumItems + item) * 4);
+  }
+  return v;
+}
+
 template <bool DP, bool WIDE, bool FULL>
 __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
   const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
@@ -818,6 +857,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   float* bhs = b2s + kMH;                    // [Nh16]
   float* wsc = bhs + Nh16;                   // [kMR][D + 3K] per-row scratch of diag_row
   float* red = wsc + kMR * per_wave;         // [64]
+  float* part4 = red + 64;                   // [(kSumSub - 1) * kSumItems * 4]  partial k-slice sums
   const int tid_0 = threadIdx.x, w_0 = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
   const int c16_0 = tid_0 & 15, g_0 = (tid_0 & 63) >> 4;
   const int o = blockIdx.x - p.G1;
@@ -862,10 +902,11 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       // (a data-parallel rank has them behind flag_pack, waited for at the top)
       if (!DP && w == 0) flags_wait(p.flag_small, p.n_small, (unsigned)step, lane, flagp);
       __syncthreads();
-      for (int idx = tid; idx < Nh16 * (kMH / 2); idx += kMT) {
-        const int n = idx >> 6, c2 = (idx & 63) * 2;
-        const float2 q = n < Nh ? xwg_load2(Wh + (int64_t)n * kMH + c2) : make_float2(0.f, 0.f);
-        *reinterpret_cast<float2*>(Whs + n * kMH + (c2 ^ (4 * (n & 15)))) = q;
+      const __amdgpu_buffer_rsrc_t whr = xwg_buffer(Wh);
+      for (int idx = tid; idx < Nh16 * (kMH / 4); idx += kMT) {
+        const int n = idx >> 5, c4 = (idx & 31) * 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Whs + n * kMH + (c4 ^ (4 * (n & 15)))) = n < Nh ? xwg_load4(whr, n * kMH + c4) : zero;
       }
       if (tid < kMH) b2s[tid] = xwg_load(p.params + p.b2_off + tid);
       for (int j = tid; j < Nh16; j += kMT) bhs[j] = j < Nh ? xwg_load(p.params + p.bh_off + j) : 0.f;
@@ -883,33 +924,13 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     for (int gp = 0; gp < p.eval_passes; ++gp) {
       const float* slabs = p.eval_slabs + (((int64_t)(eidx & 1) * p.eval_passes + gp) * p.k_slices) * zs;
       {
-        constexpr int kItems = kMR * 64, kSub = kMT / kItems;
-        const int item = tid & (kItems - 1), sub = tid / kItems;
-        const int r = item >> 6, c2 = (item & 63) * 2;
-        const bool ok = r0 + r < B && gp * B + r0 + r < p.n_test;
-        const float* src = slabs + (int64_t)min(r0 + r, B - 1) * kMH + c2;
-        const int per = ceil_div(p.k_slices, kSub);
-        const int z_lo = sub * per, z_hi = min(z_lo + per, p.k_slices);
-        float vx = 0.f, vy = 0.f;
-        for (int z = z_lo; z < z_hi; z += 24) {
-          float2 q[24];
-#pragma unroll
-          for (int u = 0; u < 24; ++u) q[u] = xwg_load2(src + (int64_t)min(z + u, z_hi - 1) * zs);
-#pragma unroll
-          for (int u = 0; u < 24; ++u)
-            if (z + u < z_hi) { vx += q[u].x; vy += q[u].y; }
-        }
-        if (kSub > 1) {
-          float* part = H2s;
-          if (sub > 0) { part[((sub - 1) * kItems + item) * 2] = vx; part[((sub - 1) * kItems + item) * 2 + 1] = vy; }
-          __syncthreads();
-          if (sub == 0) {
-#pragma unroll
-            for (int q = 1; q < kSub; ++q) { vx += part[((q - 1) * kItems + item) * 2]; vy += part[((q - 1) * kItems + item) * 2 + 1]; }
-          }
-        }
-        if (sub == 0) {
-          H1s[r * kMHP + c2] = ok ? tanhf(vx) : 0.f; H1s[r * kMHP + c2 + 1] = ok ? tanhf(vy) : 0.f;
+        const f32x4 v = slab_quads_sum(slabs, p.k_slices, (int)zs, min(r0 + (tid >> 5 & (kMR - 1)), B - 1), tid, part4);
+        if (tid < kSumItems) {
+          const int r = tid >> 5, c4 = (tid & 31) * 4;
+          const bool ok = r0 + r < B && gp * B + r0 + r < p.n_test;
+          float* hl = H1s + r * kMHP + c4;
+          hl[0] = ok ? tanhf(v.x) : 0.f; hl[1] = ok ? tanhf(v.y) : 0.f;
+          hl[2] = ok ? tanhf(v.z) : 0.f; hl[3] = ok ? tanhf(v.w) : 0.f;
         }
       }
       __syncthreads();
@@ -1061,20 +1082,22 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     BSIG_MSTAMP(4);
     // (kWhFlight 8-byte loads in flight per thread: the 139 KB of a 260-row head matrix arrive in
     // two round trips around the L2 instead of five -- this refresh sits on the owners' critical path)
-    constexpr int kWhFlight = 17;
-    for (int base = 0; base < (WIDE ? 0 : Nh16 * (kMH / 2)); base += kMT * kWhFlight) {
-      float2 q[kWhFlight];
+    constexpr int kWhFlight = 9;
+    const __amdgpu_buffer_rsrc_t whr = xwg_buffer(Wh);
+    for (int base = 0; base < (WIDE ? 0 : Nh16 * (kMH / 4)); base += kMT * kWhFlight) {
+      f32x4 q[kWhFlight];
 #pragma unroll
       for (int u = 0; u < kWhFlight; ++u) {
         const int idx = base + u * kMT + tid;
-        const int n = idx >> 6;
-        q[u] = n < Nh ? xwg_load2(Wh + (int64_t)n * kMH + (idx & 63) * 2) : make_float2(0.f, 0.f);
+        const int n = idx >> 5;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        q[u] = n < Nh ? xwg_load4(whr, n * kMH + (idx & 31) * 4) : zero;
       }
 #pragma unroll
       for (int u = 0; u < kWhFlight; ++u) {
         const int idx = base + u * kMT + tid;
-        const int n = idx >> 6, c2 = (idx & 63) * 2;
-        if (n < Nh16) *reinterpret_cast<float2*>(Whs + n * kMH + (c2 ^ (4 * (n & 15)))) = q[u];
+        const int n = idx >> 5, c4 = (idx & 31) * 4;
+        if (n < Nh16) *reinterpret_cast<f32x4*>(Whs + n * kMH + (c4 ^ (4 * (n & 15)))) = q[u];
       }
     }
     if (tid < kMH) b2s[tid] = xwg_load(p.params + p.b2_off + tid);
@@ -1098,35 +1121,15 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     {
       // (row, column pair) items; kSub threads share an item's k-slices, their partial
       // sums are combined in a fixed order through LDS
-      constexpr int kItems = kMR * 64, kSub = kMT / kItems;
-      const int item = tid & (kItems - 1), sub = tid / kItems;
-      const int r = item >> 6, c2 = (item & 63) * 2;
-      const bool ok = r0 + r < B;
-      const float* src = p.slabs + (int64_t)min(r0 + r, B - 1) * kMH + c2;
-      const int per = ceil_div(p.k_slices, kSub);
-      const int z_lo = sub * per, z_hi = min(z_lo + per, p.k_slices);
-      float vx = 0.f, vy = 0.f;
-      for (int z = z_lo; z < z_hi; z += 24) {
-        float2 q[24];
-#pragma unroll
-        for (int u = 0; u < 24; ++u) q[u] = xwg_load2(src + (int64_t)min(z + u, z_hi - 1) * zs);
-#pragma unroll
-        for (int u = 0; u < 24; ++u)
-          if (z + u < z_hi) { vx += q[u].x; vy += q[u].y; }
-      }
-      if (kSub > 1) {
-        float* part = H2s;                   // free until h2 is written
-        if (sub > 0) { part[((sub - 1) * kItems + item) * 2] = vx; part[((sub - 1) * kItems + item) * 2 + 1] = vy; }
-        __syncthreads();
-        if (sub == 0) {
-#pragma unroll
-          for (int q = 1; q < kSub; ++q) { vx += part[((q - 1) * kItems + item) * 2]; vy += part[((q - 1) * kItems + item) * 2 + 1]; }
-        }
-      }
-      if (sub == 0) {
-        vx = ok ? tanhf(vx) : 0.f; vy = ok ? tanhf(vy) : 0.f;
-        H1s[r * kMHP + c2] = vx; H1s[r * kMHP + c2 + 1] = vy;
-        if (ok) { xwg_store(p.h1 + (int64_t)(r0 + r) * kMH + c2, vx); xwg_store(p.h1 + (int64_t)(r0 + r) * kMH + c2 + 1, vy); }
+      const f32x4 v = slab_quads_sum(p.slabs, p.k_slices, (int)zs, min(r0 + (tid >> 5 & (kMR - 1)), B - 1), tid, part4);
+      if (tid < kSumItems) {
+        const int r = tid >> 5, c4 = (tid & 31) * 4;
+        const bool ok = r0 + r < B;
+        const float h0 = ok ? tanhf(v.x) : 0.f, h1v = ok ? tanhf(v.y) : 0.f;
+        const float h2v = ok ? tanhf(v.z) : 0.f, h3 = ok ? tanhf(v.w) : 0.f;
+        float* hl = H1s + r * kMHP + c4;
+        hl[0] = h0; hl[1] = h1v; hl[2] = h2v; hl[3] = h3;
+        if (ok) xwg_store4(xwg_buffer(p.h1), (r0 + r) * kMH + c4, h0, h1v, h2v, h3);
       }
     }
     __syncthreads();
@@ -1167,7 +1170,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       for (int idx = tid; idx < kMR * Nh16; idx += kMT) {
         const int r = idx / Nh16, j = idx - r * Nh16;
         const bool ok = j < Nh && r0 + r < B;
-        const float v = ok ? xwg_load(p.o_wide + (int64_t)(r0 + r) * p.NhP + j) : 0.f;
+        const float v = ok ? xwg_load(p.o_wide + ((int64_t)(j >> 5) * B + r0 + r) * kMNB + (j & 31)) : 0.f;
         Os[r * po + j] = v;
         if (ok && j >= K + DK && j < K + 2 * DK) eacc += expf(v);
       }
@@ -1429,7 +1432,7 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
                            (kMT / 32) * 32) * sizeof(float);
   size_t owner_lds = ((size_t)g->Nh16 * kMH + 2 * kMR * kMHP + (size_t)kMR * (g->Nh16 + 4) + kMH +
                       g->Nh16 + (size_t)kMR * (s.out_dim + 3 * s.n_comp + (full ? 3 * s.out_dim * s.n_comp : 0)) +
-                      64) * sizeof(float);
+                      64 + (kSumSub - 1) * kSumItems * 4) * sizeof(float);
   size_t small_lds = ((size_t)g->FR * kMHP + (size_t)kMNB * (g->FR + 4) + 64) * sizeof(float);
   g->wide = owner_lds > (size_t)kMLdsLimit ? 1 : 0;
   const char* force_wide = getenv("BSIG_MDNN_WIDE_HEADS");     // tests: the wide path on small heads

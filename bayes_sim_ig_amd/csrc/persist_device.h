@@ -7,6 +7,16 @@ namespace bsig {
 
 // row of element i of a 32x32 MFMA accumulator held by lane half h
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+// The compile-time part of acc_row: row(i, h) = acc_row0(i) + 4 * h.
+__device__ __forceinline__ constexpr int acc_row0(int i) { return (i & 3) + 8 * (i >> 2); }
+// A pointer the compiler must treat as new at this point.  The 16 row addresses of an accumulator
+// store are invariant across the update loop; hoisted out of it they do not fit the register file and
+// come back as scratch reloads, and the `s_waitcnt vmcnt(0)` in front of each reload's use makes every
+// write-through store wait for the acknowledgement of the one before (0.4 us each, measured).  Deriving
+// them from a fresh base keeps them two VALU instructions next to the store.
+template <typename T>
+__device__ __forceinline__ T* fresh_ptr(T* p) { asm volatile("" : "+v"(p)); return p; }
+__device__ __forceinline__ int fresh_value(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // One Adam step of a weight element / a bias element.  Written with explicit
 // fused operations so that every call site (the resident run, a data-parallel
@@ -41,6 +51,29 @@ __device__ inline float2 xwg_load2(const float* p) {
   const unsigned long long x = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return make_float2(__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32)));
+}
+
+// 16-byte write-through stores / cache-bypassing loads for the large cross-workgroup payloads
+// (slabs of partial products, gradient rows).  tools/micro/handoff_bench.hip: a 3200-dword payload
+// crosses workgroups in 2.3 us with four dwords per lane against 4.5 us with one (same cache policy,
+// `sc1`, same coherence -- 0 stale words); the time is in the number of memory transactions, not in
+// the bytes.  Buffer instructions through the clang builtins, so the compiler tracks them (several
+// in flight per lane, exact `s_waitcnt`s).  `base` must be workgroup-uniform; byte offsets are 32-bit.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kXwgPolicy = 16;          // gfx940+: sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xwg_buffer(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void xwg_store4(__amdgpu_buffer_rsrc_t r, int float_off, float a, float b,
+                                           float c, float d) {
+  const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, float_off * 4, 0, kXwgPolicy);
+}
+__device__ __forceinline__ f32x4 xwg_load4(__amdgpu_buffer_rsrc_t r, int float_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, kXwgPolicy);
+  f32x4 f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+  return f;
 }
 
 }  // namespace bsig

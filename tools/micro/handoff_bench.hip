@@ -2,6 +2,8 @@
 // gfx950 (payload + flag), for partners on the SAME XCD and on DIFFERENT XCDs, with
 //   mode 0: write-through stores + loads around the L2 (agent-scope relaxed atomics) -- what the
 //           persistent update kernels use for everything that crosses workgroups;
+//   mode 2: as mode 0 with 16-byte stores and loads (four dwords per lane);
+//   mode 3: as mode 2 through buffer_{load,store}_dwordx4 sc1 (clang builtins: loads pipelined);
 //   mode 1: plain stores (the L1 writes through to the XCD's L2) + L1-bypassing `sc0` loads that may
 //           hit in the L2: coherent only between workgroups that share an L2 (same XCD).
 // Build: hipcc --offload-arch=gfx950 -O3 -o handoff handoff_bench.hip
@@ -25,14 +27,32 @@ __device__ inline void store_plain(unsigned* p, unsigned v) {
   asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
 }
 
+// 16-byte write-through store / cache-bypassing load (the same cache policy bits as the agent-scope
+// relaxed atomics above, four dwords per lane)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void put4(unsigned* p, uint4 v) {
+  const u32x4 r = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(r) : "memory");
+}
+__device__ inline uint4 get4(const unsigned* p) {
+  u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+  return make_uint4(r.x, r.y, r.z, r.w);
+}
+
+// the same through buffer instructions (compiler-tracked: several loads in flight per lane), aux 16 = sc1
+__device__ inline __amdgpu_buffer_rsrc_t rsrc(const unsigned* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
 template <int MODE>
 __device__ inline void put(unsigned* p, unsigned v) {
-  if (MODE == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (MODE != 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else store_plain(p, v);
 }
 template <int MODE>
 __device__ inline unsigned get(const unsigned* p) {
-  if (MODE == 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (MODE != 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return load_sc0(p);
 }
 
@@ -55,6 +75,19 @@ __global__ __launch_bounds__(256) void pingpong(unsigned* xcc, const int* partne
     for (int half = 0; half < 2; ++half) {
       const bool sender = (half == 0) == first;
       if (sender) {
+        if (MODE == 2) {
+          for (int i = threadIdx.x * 4; i < payload; i += blockDim.x * 4) {
+            const unsigned b = (unsigned)(it * 2 + half + i);
+            put4(mine + i, make_uint4(b, b + 1, b + 2, b + 3));
+          }
+        } else if (MODE == 3) {
+          const __amdgpu_buffer_rsrc_t r = rsrc(mine);
+          for (int i = threadIdx.x * 4; i < payload; i += blockDim.x * 4) {
+            const unsigned b = (unsigned)(it * 2 + half + i);
+            const u32x4 v = {b, b + 1, b + 2, b + 3};
+            __builtin_amdgcn_raw_buffer_store_b128(v, r, i * 4, 0, 16);
+          }
+        } else
         for (int i = threadIdx.x; i < payload; i += blockDim.x) put<MODE>(mine + i, (unsigned)(it * 2 + half + i));
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -65,6 +98,21 @@ __global__ __launch_bounds__(256) void pingpong(unsigned* xcc, const int* partne
           while (get<MODE>(flags + other) != (unsigned)(it * 2 + half) && ++spins < (1u << 13)) {}
         }
         __syncthreads();
+        if (MODE == 3) {
+          const __amdgpu_buffer_rsrc_t r = rsrc(theirs);
+#pragma unroll 4
+          for (int i = threadIdx.x * 4; i < payload; i += blockDim.x * 4) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, i * 4, 0, 16);
+            const unsigned b = (unsigned)(it * 2 + half + i);
+            bad += (v.x != b) + (v.y != b + 1) + (v.z != b + 2) + (v.w != b + 3);
+          }
+        } else if (MODE == 2) {
+          for (int i = threadIdx.x * 4; i < payload; i += blockDim.x * 4) {
+            const uint4 v = get4(theirs + i);
+            const unsigned b = (unsigned)(it * 2 + half + i);
+            bad += (v.x != b) + (v.y != b + 1) + (v.z != b + 2) + (v.w != b + 3);
+          }
+        } else
         for (int i = threadIdx.x; i < payload; i += blockDim.x)
           bad += get<MODE>(theirs + i) != (unsigned)(it * 2 + half + i);
       }
@@ -100,10 +148,14 @@ int main() {
       pr[i] = j; pr[j] = i; ++npairs;
     }
     hipMemcpy(partner, pr.data(), G * 4, hipMemcpyHostToDevice);
-    for (int mode = 0; mode < 2; ++mode)
+    for (int mode : {0, 2, 3})     // (mode 1 -- plain stores + sc0 loads -- is not coherent: see profiles/r02_handoff_bench.txt)
       for (int payload : {0, 64, 1024, 3200}) {
         hipMemset(flags, 0, G * 4); hipMemset(stale, 0, 4); hipMemset(cycles, 0, G * 8);
-        if (mode == 0)
+        if (mode == 3)
+          hipLaunchKernelGGL(pingpong<3>, dim3(G), dim3(256), 100 * 1024, 0, xcc, partner, flags, data, payload, iters, stale, cycles);
+        else if (mode == 2)
+          hipLaunchKernelGGL(pingpong<2>, dim3(G), dim3(256), 100 * 1024, 0, xcc, partner, flags, data, payload, iters, stale, cycles);
+        else if (mode == 0)
           hipLaunchKernelGGL(pingpong<0>, dim3(G), dim3(256), 100 * 1024, 0, xcc, partner, flags, data, payload, iters, stale, cycles);
         else
           hipLaunchKernelGGL(pingpong<1>, dim3(G), dim3(256), 100 * 1024, 0, xcc, partner, flags, data, payload, iters, stale, cycles);
