@@ -421,18 +421,26 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
     __syncthreads();
     BSIG_MSTAMP(10);
-    for (int base = 0; base < p.FR * kMNB; base += kMT * 8) {
-      float q[8];
+    {
+      // [FR, 32] block of dz1, transposed into X: 16 bytes per lane, 8 lanes per row
+      const __amdgpu_buffer_rsrc_t zr = xwg_buffer(p.dz1 + n0);
+      for (int base = 0; base < p.FR * (kMNB / 4); base += kMT * 2) {
+        f32x4 q[2];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * kMT + tid_l;
-        const int b = idx >> 5;
-        q[u] = (idx < p.FR * kMNB && b < B) ? xwg_load(p.dz1 + (int64_t)b * kMH + n0 + (idx & 31)) : 0.f;
-      }
+        for (int u = 0; u < 2; ++u) {
+          const int idx = base + u * kMT + tid_l;
+          const int b = idx >> 3;
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          q[u] = (idx < p.FR * (kMNB / 4) && b < B) ? xwg_load4(zr, b * kMH + (idx & 7) * 4) : zero;
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * kMT + tid_l;
-        if (idx < p.FR * kMNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u];
+        for (int u = 0; u < 2; ++u) {
+          const int idx = base + u * kMT + tid_l;
+          if (idx < p.FR * (kMNB / 4)) {
+            float* x = X + ((idx & 7) * 4) * DOP + (idx >> 3);
+            x[0] = q[u].x; x[DOP] = q[u].y; x[2 * DOP] = q[u].z; x[3 * DOP] = q[u].w;
+          }
+        }
       }
     }
     __syncthreads();
@@ -633,30 +641,42 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
     const float a0 = (float)(p.lr / (1.0 - b1t));
     const float a1 = (float)(1.0 / sqrt(1.0 - b2t));
     BSIG_MSTAMP(0);
-#define BSIG_LOAD_ACTIVATIONS() /* [B, 128], 8-byte loads */                                   \
-    for (int base = 0; base < B * (kMH / 2); base += kMT * 8) {                                 \
-      float2 q[8];                                                                              \
-      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
-        const int idx = min(base + u * kMT + tid, B * (kMH / 2) - 1);                           \
-        q[u] = xwg_load2(hsrc + (int64_t)(idx >> 6) * kMH + (idx & 63) * 2);                    \
-      }                                                                                         \
-      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
-        const int idx = base + u * kMT + tid;                                                   \
-        if (idx < B * (kMH / 2))                                                                \
-          *reinterpret_cast<float2*>(Hs + (idx >> 6) * kMHP + (idx & 63) * 2) = q[u];           \
+#define BSIG_LOAD_ACTIVATIONS() /* [B, 128], 16-byte loads */                                  \
+    {                                                                                           \
+      const __amdgpu_buffer_rsrc_t hr = xwg_buffer(hsrc);                                       \
+      for (int base = 0; base < B * (kMH / 4); base += kMT * 4) {                               \
+        f32x4 q[4];                                                                             \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+          const int idx = min(base + u * kMT + tid, B * (kMH / 4) - 1);                         \
+          q[u] = xwg_load4(hr, (idx >> 5) * kMH + (idx & 31) * 4);                              \
+        }                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+          const int idx = base + u * kMT + tid;                                                 \
+          if (idx < B * (kMH / 4))                                                              \
+            *reinterpret_cast<f32x4*>(Hs + (idx >> 5) * kMHP + (idx & 31) * 4) = q[u];          \
+        }                                                                                       \
       }                                                                                         \
     }
 #define BSIG_LOAD_GRADIENT_BLOCK() /* this block's gradient columns [B, 32], transposed */      \
-    for (int base = 0; base < p.FR * kMNB; base += kMT * 8) {                                   \
-      float q[8];                                                                               \
-      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
-        const int idx = base + u * kMT + tid;                                                   \
-        const int b = idx >> 5, n = n0 + (idx & 31);                                            \
-        q[u] = (idx < p.FR * kMNB && b < B && n < nrows) ? xwg_load(dsrc + (int64_t)b * dpitch + n) : 0.f; \
-      }                                                                                         \
-      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                           \
-        const int idx = base + u * kMT + tid;                                                   \
-        if (idx < p.FR * kMNB) X[(idx & 31) * DOP + (idx >> 5)] = q[u];                         \
+    {                                                                                           \
+      const __amdgpu_buffer_rsrc_t gr = xwg_buffer(dsrc);                                       \
+      for (int base = 0; base < p.FR * (kMNB / 4); base += kMT * 2) {                           \
+        f32x4 q[2];                                                                             \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                         \
+          const int idx = base + u * kMT + tid;                                                 \
+          const int b = idx >> 3, n = n0 + (idx & 7) * 4;                                       \
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};                                              \
+          q[u] = (idx < p.FR * (kMNB / 4) && b < B && n < nrows) ? xwg_load4(gr, b * dpitch + n) : zero; \
+        }                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                         \
+          const int idx = base + u * kMT + tid;                                                 \
+          if (idx < p.FR * (kMNB / 4)) {                                                        \
+            const int n = n0 + (idx & 7) * 4;                                                   \
+            float* x = X + ((idx & 7) * 4) * DOP + (idx >> 3);                                  \
+            x[0] = n < nrows ? q[u].x : 0.f; x[DOP] = n + 1 < nrows ? q[u].y : 0.f;            \
+            x[2 * DOP] = n + 2 < nrows ? q[u].z : 0.f; x[3 * DOP] = n + 3 < nrows ? q[u].w : 0.f; \
+          }                                                                                     \
+        }                                                                                       \
       }                                                                                         \
     }
     if (WIDE && whead) {
@@ -1076,48 +1096,57 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     // ---- weights of this update (written by the small-weight workgroups) ---------
     // (first update of a launch, and the only one of a data-parallel launch: flag_pack above)
     // (wide heads: the owners only need W2 / b2 -- the first four small-weight workgroups)
+    if (active) {      // target row: two dependent loads, issued before the wait instead of after the weights
+      const int64_t yrow = p.ids[(int64_t)step * B + row];
+      for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
+    }
     if (!DP && t > 0 && w == 0)
       flags_wait(p.flag_small, WIDE ? kMH / kMNB : p.n_small, epoch - 1u, lane, flagp);
     __syncthreads();
     BSIG_MSTAMP(4);
-    // (kWhFlight 8-byte loads in flight per thread: the 139 KB of a 260-row head matrix arrive in
-    // two round trips around the L2 instead of five -- this refresh sits on the owners' critical path)
-    constexpr int kWhFlight = 9;
-    const __amdgpu_buffer_rsrc_t whr = xwg_buffer(Wh);
-    for (int base = 0; base < (WIDE ? 0 : Nh16 * (kMH / 4)); base += kMT * kWhFlight) {
-      f32x4 q[kWhFlight];
-#pragma unroll
-      for (int u = 0; u < kWhFlight; ++u) {
-        const int idx = base + u * kMT + tid;
-        const int n = idx >> 5;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        q[u] = n < Nh ? xwg_load4(whr, n * kMH + (idx & 31) * 4) : zero;
-      }
-#pragma unroll
-      for (int u = 0; u < kWhFlight; ++u) {
-        const int idx = base + u * kMT + tid;
-        const int n = idx >> 5, c4 = (idx & 31) * 4;
-        if (n < Nh16) *reinterpret_cast<f32x4*>(Whs + n * kMH + (c4 ^ (4 * (n & 15)))) = q[u];
-      }
+    // The head matrix refresh sits on the owners' critical path (a CU pulls ~40 GB/s through
+    // cache-bypassing loads, tools/micro/fanout_bench.hip: 73 KB of a 144-row matrix = 2 us), and the
+    // first-layer flags have usually been up for a while when it ends: wavefront 0 polls them while
+    // wavefronts 1..7 fetch (kWhFlight 16-byte loads in flight per thread).
+    // (this wavefront's W2 operand registers ride in the same window)
+    float w2f[32];
+#define BSIG_LOAD_W2F()                                                                        \
+    _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) {                                          \
+      const float* src = p.w2f_pack + (step & 1) * (kMH * kMH) + (((w * 8 + tt) * 2) * 64 + lane) * 2; \
+      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);                              \
+      w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y; \
     }
-    if (tid < kMH) b2s[tid] = xwg_load(p.params + p.b2_off + tid);
-    for (int j = tid; j < Nh16; j += kMT) bhs[j] = j < Nh ? xwg_load(p.params + p.bh_off + j) : 0.f;
-    if (active) {      // target row
-      const int64_t yrow = p.ids[(int64_t)step * B + row];
-      for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
+    if (w == 0) {
+      flags_wait(p.flag_fwd, p.G1, epoch, lane, flagp);
+      BSIG_LOAD_W2F()
+    } else {
+      BSIG_LOAD_W2F()
+      constexpr int kWhFlight = 11, kFetch = kMT - 64;
+      const int ft = tid - 64;
+      const __amdgpu_buffer_rsrc_t whr = xwg_buffer(Wh);
+      for (int base = 0; base < (WIDE ? 0 : Nh16 * (kMH / 4)); base += kFetch * kWhFlight) {
+        f32x4 q[kWhFlight];
+#pragma unroll
+        for (int u = 0; u < kWhFlight; ++u) {
+          const int idx = base + u * kFetch + ft;
+          const int n = idx >> 5;
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          q[u] = n < Nh ? xwg_load4(whr, n * kMH + (idx & 31) * 4) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < kWhFlight; ++u) {
+          const int idx = base + u * kFetch + ft;
+          const int n = idx >> 5, c4 = (idx & 31) * 4;
+          if (n < Nh16) *reinterpret_cast<f32x4*>(Whs + n * kMH + (c4 ^ (4 * (n & 15)))) = q[u];
+        }
+      }
+      if (ft < kMH) b2s[ft] = xwg_load(p.params + p.b2_off + ft);
+      for (int j = ft; j < Nh16; j += kFetch) bhs[j] = j < Nh ? xwg_load(p.params + p.bh_off + j) : 0.f;
     }
     // ---- h1 = tanh(sum of the k-slices) (b1 rides on slice 0) -----------------------
     BSIG_MSTAMP(5);
-    if (w == 0) flags_wait(p.flag_fwd, p.G1, epoch, lane, flagp);
     __syncthreads();
     BSIG_MSTAMP(6);
-    float w2f[32];
-#pragma unroll
-    for (int tt = 0; tt < 8; ++tt) {
-      const float* src = p.w2f_pack + (step & 1) * (kMH * kMH) + (((w * 8 + tt) * 2) * 64 + lane) * 2;
-      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);
-      w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y;
-    }
     {
       // (row, column pair) items; kSub threads share an item's k-slices, their partial
       // sums are combined in a fixed order through LDS

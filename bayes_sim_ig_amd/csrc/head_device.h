@@ -325,21 +325,32 @@ __device__ inline void granule_publish(unsigned long long* g, int slot, uint32_t
   __hip_atomic_store(g + slot * kGranStride, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// (All the polls of a round are issued before the first is looked at: with a test between them the
+// compiler waits for each load in turn, and a 188-flag fan-in cost three memory round trips -- 1.6 us
+// on flags that were already up -- instead of one.)
+template <int NU>
+__device__ __forceinline__ void granule_poll(const unsigned long long* g, int G, uint32_t tag, int lane,
+                                             bool (&ok)[4], float (&v)[4]) {
+  unsigned long long x[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    x[u] = __hip_atomic_load(g + min(lane + 64 * u, G - 1) * kGranStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    if (!ok[u] && (uint32_t)(x[u] >> 32) == tag) { ok[u] = true; v[u] = __uint_as_float((uint32_t)x[u]); }
+}
 __device__ inline float granule_gather(unsigned long long* g, int G, uint32_t tag, int lane,
                                        int32_t* flag) {
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   bool ok[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) ok[u] = lane + 64 * u >= G;
+  const int nu = (G + 63) >> 6;
   for (unsigned spin = 0;; ++spin) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (!ok[u]) {
-        const unsigned long long x =
-            __hip_atomic_load(g + (lane + 64 * u) * kGranStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(x >> 32) == tag) { ok[u] = true; v[u] = __uint_as_float((uint32_t)x); }
-      }
-    }
+    if (nu <= 1) granule_poll<1>(g, G, tag, lane, ok, v);
+    else if (nu == 2) granule_poll<2>(g, G, tag, lane, ok, v);
+    else if (nu == 3) granule_poll<3>(g, G, tag, lane, ok, v);
+    else granule_poll<4>(g, G, tag, lane, ok, v);
     if (__all(ok[0] && ok[1] && ok[2] && ok[3])) break;
     if (spin > (1u << 18)) {
       if (flag && lane == 0) atomicOr(flag, 2);
@@ -353,18 +364,25 @@ __device__ inline float granule_gather(unsigned long long* g, int G, uint32_t ta
 __device__ inline void flag_raise(unsigned* flags, int slot, unsigned epoch) {
   __hip_atomic_store(flags + slot * kFlagStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wait until flags[0..G) >= epoch (G <= 256; one wavefront polls)
+// wait until flags[0..G) >= epoch (G <= 256; one wavefront polls; the flags only grow)
+template <int NU>
+__device__ __forceinline__ bool flags_poll(const unsigned* flags, int G, unsigned epoch, int lane) {
+  unsigned x[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    x[u] = __hip_atomic_load(flags + min(lane + 64 * u, G - 1) * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool ok = true;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) ok = ok && x[u] >= epoch;
+  return __all(ok);
+}
 __device__ inline void flags_wait(unsigned* flags, int G, unsigned epoch, int lane, int32_t* flag) {
-  bool ok[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) ok[u] = lane + 64 * u >= G;
+  const int nu = (G + 63) >> 6;
   for (unsigned spin = 0;; ++spin) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (!ok[u])
-        ok[u] = __hip_atomic_load(flags + (lane + 64 * u) * kFlagStride, __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT) >= epoch;
-    if (__all(ok[0] && ok[1] && ok[2] && ok[3])) break;
+    const bool done = nu <= 1 ? flags_poll<1>(flags, G, epoch, lane)
+                    : nu == 2 ? flags_poll<2>(flags, G, epoch, lane)
+                    : nu == 3 ? flags_poll<3>(flags, G, epoch, lane) : flags_poll<4>(flags, G, epoch, lane);
+    if (done) break;
     if (spin > (1u << 18)) {
       if (flag && lane == 0) atomicOr(flag, 2);
       break;

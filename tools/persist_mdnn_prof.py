@@ -67,9 +67,9 @@ for u in range(2, 7):
     per.append(min(st[g, u + 1, 0] for g in tiles) - t0)
     for label, grp, k, fn in rows:
         acc[label].append(fn([st[g, u, k] for g in grp]) - t0)
-print('update period %.2f us' % np.mean(per))
+print('update period %.2f us' % np.mean(per) + ('   per update: ' + ' '.join('%.2f' % x for x in per) if os.environ.get('PER_UPDATE') == '1' else ''))
 for label, _, _, _ in rows:
-    print('    %-52s %6.2f' % (label, np.mean(acc[label])))
+    print('    %-52s %6.2f' % (label, np.mean(acc[label])) + ('   [' + ' '.join('%.2f' % x for x in acc[label]) + ']' if os.environ.get('PER_UPDATE') == '1' else ''))
 if os.environ.get('DETAIL') == '1':
     u = 4
     t0 = min(st[g, u, 0] for g in tiles)
