@@ -63,6 +63,7 @@ struct PersistArgs {
   // Adam step of the PREVIOUS update (on the reduced gradients) is taken while the
   // tile is loaded (adam_pending)
   float* grads; int adam_pending;
+  int quad_ok;                       // weight rows are 16-byte aligned quads (w_off, Fdim multiples of 4)
   // held-out evaluations inside the launch (mdnn.py:235-242; do_eval): after update `it`
   // with it % eval_every == 0, or after the last of the call's n_total updates.  The tile
   // workgroups form the held-out rows' products while they wait for the row owners of the
@@ -259,7 +260,54 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
   // (three passes: every load is issued before the first store -- the stores of a
   // data-parallel launch's pending Adam step may alias the loads for the compiler, and
   // interleaved they serialise into 16 dependent round trips: 10 us instead of 3)
-  {
+  if (DP && p.quad_ok) {
+    // A data-parallel launch only passes through the tile here (pending Adam step, then the weights
+    // into LDS; its dW goes to the gradient buffer), and Adam is elementwise: the tile is taken as
+    // rows of 16-byte quads -- one 1 KB row of W / exp_avg / exp_avg_sq / gradients per wavefront
+    // instruction, all 16 loads of a thread in flight -- instead of 64 dword loads per lane in the
+    // accumulator layout.
+    f32x4 Wq[4], Mq[4], Vq[4], Gq4[4];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + q * 8 + w;
+      Wq[q] = zero; Mq[q] = zero; Vq[q] = zero; Gq4[q] = zero;
+      if (n < Nh && k0 + 4 * lane < p.Fdim) {
+        const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + 4 * lane;
+        Wq[q] = *reinterpret_cast<const f32x4*>(p.params + off);
+        if (pend) {
+          Mq[q] = *reinterpret_cast<const f32x4*>(p.m1 + off);
+          Vq[q] = *reinterpret_cast<const f32x4*>(p.m2 + off);
+          Gq4[q] = *reinterpret_cast<const f32x4*>(p.grads + off);
+        }
+      }
+    }
+    if (pend) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float m = Mq[q][j], v = Vq[q][j];
+          Wq[q][j] = adam_weight(Gq4[q][j], m, v, Wq[q][j], pa0, pa1, ak);
+          Mq[q][j] = m; Vq[q][j] = v;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + q * 8 + w;
+        if (n < Nh && k0 + 4 * lane < p.Fdim) {
+          const int64_t off = p.w_off + (int64_t)n * p.Fdim + k0 + 4 * lane;
+          *reinterpret_cast<f32x4*>(p.params + off) = Wq[q];
+          *reinterpret_cast<f32x4*>(p.m1 + off) = Mq[q];
+          *reinterpret_cast<f32x4*>(p.m2 + off) = Vq[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(Wl + (q * 8 + w) * kPitch + 4 * lane) = Wq[q];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Mr[i] = 0.f; Vr[i] = 0.f; }
+  } else {
     float Wv[16], Gq[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -864,6 +912,9 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.grads = b.grads; p.adam_pending = b.adam_pending;
   p.feats = b.feats; p.ld_feats = b.ld_feats; p.feat_ids = b.feat_ids; p.y = b.y; p.ldy = b.ldy; p.ids = b.ids;
   p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq; p.w_off = b.w_off; p.b_off = b.b_off;
+  p.quad_ok = (p.w_off % 4 == 0 && p.Fdim % 4 == 0 &&
+               ((reinterpret_cast<uintptr_t>(b.params) | reinterpret_cast<uintptr_t>(b.exp_avg) |
+                 reinterpret_cast<uintptr_t>(b.exp_avg_sq) | reinterpret_cast<uintptr_t>(b.grads)) & 15) == 0) ? 1 : 0;
   p.state = b.state; p.train_loss = b.train_loss;
   p.lr = hy.lr; p.beta1 = hy.beta1; p.beta2 = hy.beta2;
   p.adam_eps = hy.adam_eps; p.eps_noise = hy.eps_noise; p.min_w = hy.min_weight;

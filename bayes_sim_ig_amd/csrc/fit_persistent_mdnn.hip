@@ -95,6 +95,7 @@ struct MdnnArgs {
   // and the Adam step of the PREVIOUS update (on the reduced gradients) is taken by the
   // weights' owners while they load them (adam_pending)
   float* grads; int adam_pending;
+  int pair_ok;                       // rows of W1 are 8-byte aligned pairs (w1_off, I even)
   // held-out evaluations inside the launch (mdnn.py:235-242; do_eval), as in
   // fit_persistent.hip: the tile workgroups form the held-out rows' first-layer products
   // while they wait for the row owners of the NEXT update (their LDS still holds the
@@ -280,7 +281,48 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
   // (three passes: every load is issued before the first store of a data-parallel launch's
   // pending Adam step -- interleaved, the possibly aliasing stores serialise the loads)
-  {
+  if (DP && p.pair_ok) {
+    // A data-parallel launch only passes through the tile here (pending Adam step, weights into
+    // LDS), and Adam is elementwise: the tile is taken as rows of 8-byte pairs (the rows of W1 are
+    // I floats apart -- 11 802 for the Ant summaries: 8-byte aligned, not 16), 512 contiguous bytes
+    // per wavefront instruction and all 32 loads of a thread in flight, instead of 64 dword loads
+    // per lane in the accumulator layout.
+    float2 Wq[8], Mq[8], Vq[8], Gq2[8];
+    const int c2 = (tid & 127) * 2, rq = tid >> 7;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t off = p.w1_off + (int64_t)(n0 + q * 4 + rq) * p.I + k0 + c2;
+      Wq[q] = Mq[q] = Vq[q] = Gq2[q] = make_float2(0.f, 0.f);
+      if (k0 + c2 < p.I) {
+        Wq[q] = *reinterpret_cast<const float2*>(p.params + off);
+        if (pend) {
+          Mq[q] = *reinterpret_cast<const float2*>(p.m1 + off);
+          Vq[q] = *reinterpret_cast<const float2*>(p.m2 + off);
+          Gq2[q] = *reinterpret_cast<const float2*>(p.grads + off);
+        }
+      }
+    }
+    if (pend) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        Wq[q].x = adam_weight(Gq2[q].x, Mq[q].x, Vq[q].x, Wq[q].x, pa0, pa1, ak);
+        Wq[q].y = adam_weight(Gq2[q].y, Mq[q].y, Vq[q].y, Wq[q].y, pa0, pa1, ak);
+      }
+      if (k0 + c2 < p.I) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int64_t off = p.w1_off + (int64_t)(n0 + q * 4 + rq) * p.I + k0 + c2;
+          *reinterpret_cast<float2*>(p.params + off) = Wq[q];
+          *reinterpret_cast<float2*>(p.m1 + off) = Mq[q];
+          *reinterpret_cast<float2*>(p.m2 + off) = Vq[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<float2*>(Wl + (q * 4 + rq) * kMPitch + c2) = Wq[q];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Mr[i] = 0.f; Vr[i] = 0.f; }
+  } else {
     float Wv[16], Gq[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -1584,6 +1626,9 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.x_fac = fac ? 1 : 0; p.xS = b.x_s; p.xA = b.x_a;
   p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq;
   p.w1_off = b.w1_off; p.b1_off = b.b1_off; p.w2_off = b.w2_off; p.b2_off = b.b2_off;
+  p.pair_ok = (p.w1_off % 2 == 0 && s.input_dim % 2 == 0 &&
+               ((reinterpret_cast<uintptr_t>(b.params) | reinterpret_cast<uintptr_t>(b.exp_avg) |
+                 reinterpret_cast<uintptr_t>(b.exp_avg_sq) | reinterpret_cast<uintptr_t>(b.grads)) & 7) == 0) ? 1 : 0;
   p.wh_off = b.wh_off; p.bh_off = b.bh_off;
   p.state = b.state; p.train_loss = b.train_loss;
   p.lr = hy.lr; p.beta1 = hy.beta1; p.beta2 = hy.beta2;
