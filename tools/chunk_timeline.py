@@ -23,6 +23,7 @@ def main(db, out=None):
     calls = collections.Counter()
     idle = 0.0
     total = 0.0
+    gaps = collections.OrderedDict()
     for a, b in wins:
         total += rows[b][1] - rows[a][1]
         last_end = rows[a][1]
@@ -31,15 +32,28 @@ def main(db, out=None):
             busy[short] = busy.get(short, 0.0) + (e - s)
             calls[short] += 1
             idle += max(0.0, s - last_end)
+            gaps['gap before ' + short] = gaps.get('gap before ' + short, 0.0) + max(0.0, s - last_end)
             last_end = max(last_end, e)
         idle += max(0.0, rows[b][1] - last_end)
+        gaps['gap before the next fit_begin_kernel'] = gaps.get('gap before the next fit_begin_kernel', 0.0) + max(0.0, rows[b][1] - last_end)
     n = float(len(wins))
     lines = ['# %d chunks of %d kernel launches; averages per chunk' % (len(wins), shape),
              '%-72s %7s %10s' % ('kernel', 'calls', 'busy_us')]
     for k, v in sorted(busy.items(), key=lambda kv: -kv[1]):
         lines.append('%-72s %7.1f %10.1f' % (k, calls[k] / n, v / n / 1e3))
     lines.append('%-72s %7s %10.1f' % ('idle between kernels', '', idle / n / 1e3))
+    for k, v in gaps.items():
+        lines.append('%-72s %7s %10.1f' % ('  ' + k[:68], '', v / n / 1e3))
     lines.append('%-72s %7s %10.1f' % ('chunk (begin to begin)', '', total / n / 1e3))
+    if wins:
+        g = sorted(sum(max(0.0, rows[i + 1][1] - max(r[2] for r in rows[a:i + 1])) for i in range(a, b)) / 1e3 for a, b in wins)
+        lines.append('# idle per chunk over the %d chunks: min %.1f, median %.1f, max %.1f us; sorted: %s' % (
+            len(g), g[0], g[len(g) // 2], g[-1], ' '.join('%.0f' % x for x in g)))
+    if wins:                        # one window in full: offsets from its fit_begin_kernel, us
+        a, b = wins[len(wins) // 2]
+        lines.append('# one chunk: start offset / duration (us)')
+        for name, s_, e in rows[a:b + 1]:
+            lines.append('#   %9.1f %9.1f  %s' % ((s_ - rows[a][1]) / 1e3, (e - s_) / 1e3, name.split('(')[0].replace('void ', '')[:70]))
     text = '\n'.join(lines) + '\n'
     if out:
         open(out, 'w').write(text)
