@@ -148,6 +148,39 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
   }
 }
 
+// The same for rows that are 16-byte aligned on both sides (every staging copy of the fit: the
+// summarizers write rows with a leading dimension that is a multiple of four): float4 moves, four
+// in flight per thread.  The scalar kernel moved the 0.9 GB of a 100k-row ShadowHand chunk at
+// 0.2 TB/s (8.7 ms, 11 % of a scaled-batch fit).
+__global__ __launch_bounds__(256) void copy_rows_vec_kernel(const float* __restrict__ src,
+                                                            int64_t ld_src,
+                                                            const int32_t* __restrict__ rows,
+                                                            float* __restrict__ dst,
+                                                            int64_t ld_dst, int64_t n_rows,
+                                                            int64_t cols) {
+  const int64_t c4n = cols >> 2;
+  for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+    const float* s = src + (rows ? (int64_t)rows[r] : r) * ld_src;
+    float* d = dst + r * ld_dst;
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    float4* d4 = reinterpret_cast<float4*>(d);
+    for (int64_t c0 = threadIdx.x; c0 < c4n; c0 += 4 * blockDim.x) {
+      float4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t c = c0 + u * blockDim.x;
+        if (c < c4n) q[u] = s4[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t c = c0 + u * blockDim.x;
+        if (c < c4n) d4[c] = q[u];
+      }
+    }
+    for (int64_t c = (c4n << 2) + threadIdx.x; c < cols; c += blockDim.x) d[c] = s[c];
+  }
+}
+
 }  // namespace bsig
 
 using namespace bsig;
@@ -182,9 +215,15 @@ extern "C" int bsig_copy_rows(const float* src, int64_t ld_src, const int32_t* r
                               bsig_stream_t stream) {
   BSIG_REQUIRE(src && dst && n_rows >= 0 && cols >= 0, "copy_rows: bad args");
   if (n_rows == 0 || cols == 0) return BSIG_OK;
-  hipLaunchKernelGGL(copy_rows_kernel, dim3((int)std::min<int64_t>(n_rows, 8192)),
-                     dim3(cols >= 192 ? 256 : 64), 0, as_stream(stream), src, ld_src, rows,
-                     dst, ld_dst, n_rows, cols);
+  const bool vec = cols >= 256 && ld_src % 4 == 0 && ld_dst % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(copy_rows_vec_kernel, dim3((int)std::min<int64_t>(n_rows, 16384)), dim3(256), 0,
+                       as_stream(stream), src, ld_src, rows, dst, ld_dst, n_rows, cols);
+  else
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((int)std::min<int64_t>(n_rows, 8192)),
+                       dim3(cols >= 192 ? 256 : 64), 0, as_stream(stream), src, ld_src, rows,
+                       dst, ld_dst, n_rows, cols);
   BSIG_CHECK_LAUNCH("copy_rows");
   return BSIG_OK;
 }

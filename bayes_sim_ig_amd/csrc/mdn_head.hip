@@ -311,7 +311,18 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
   float eps = 0.f;
   if (want_eps) {
     float s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-    for (int i = lane + 256; i < a.n_sig; i += 64) s += a.sig_partials[i];
+    // (a split-K head product delivers up to 2048 partials: eight loads in flight per lane --
+    // one at a time, the 28 dependent round trips were most of this kernel at minibatch 8192)
+    for (int base = 256; base < a.n_sig; base += 512) {
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + lane + 64 * u;
+        q[u] = i < a.n_sig ? a.sig_partials[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += q[u];
+    }
     eps = a.eps_noise * (wave_sum(s) / ((float)a.batch * (float)DK));
   }
   __builtin_amdgcn_wave_barrier();
@@ -524,7 +535,9 @@ static int head_geom(const bsig_head_dims* d, int64_t batch, HeadGeom* g) {
     return BSIG_EUNSUPPORTED;
   }
   g->blocks = (int)ceil_div<int64_t>(batch, g->R);
-  g->slabs = batch > 1024 ? (int)std::min<int64_t>(ceil_div<int64_t>(batch, 512), kMaxSlabs) : 1;
+  // (128 rows per slab: one pass of 8 rows in flight per thread -- at 512 rows per slab the 80
+  // workgroups of a minibatch of 8192 made four dependent passes: 21 us)
+  g->slabs = batch > 1024 ? (int)std::min<int64_t>(ceil_div<int64_t>(batch, 128), kMaxSlabs) : 1;
   g->rows_per_slab = (int)ceil_div<int64_t>(batch, g->slabs);
   return BSIG_OK;
 }

@@ -416,3 +416,29 @@ def test_reference_autograd_pattern(B, tag):
     with torch.no_grad():                      # inference path: plain tensors
         out = m.mdn_loss_fn(*m.forward(x, noise=torch.from_numpy(g['noise']).to(DEV)), y)
     assert not out.requires_grad
+
+
+# ------------------------------------------------------------------- row copies
+@pytest.mark.parametrize('n,cols,ld_src,ld_dst,gather', [
+    (37, 2310, 2312, 2312, False),     # the staging copy of a ShadowHand chunk: 16-byte rows, float4 path
+    (37, 2310, 2312, 2312, True),      # ... gathered through a row table
+    (5, 2310, 2311, 2312, False),      # unaligned source rows: scalar path
+    (64, 259, 260, 264, True),         # a tail of three columns after the float4 part
+    (300, 40, 40, 40, False),          # narrow rows (scalar kernel, 64 threads)
+    (20000, 302, 304, 304, False),     # more rows than workgroups (grid stride)
+])
+def test_copy_rows_is_exact(B, n, cols, ld_src, ld_dst, gather):
+    """bsig_copy_rows (the staging / gather copy of the fit, mdnn.py:208-218): bit-exact, columns
+    past `cols` of the destination untouched, for the float4 and the scalar kernel."""
+    lib, L = B._lib.load(), B._lib
+    g = torch.Generator(device='cpu').manual_seed(n + cols)
+    n_src = n + 11
+    src = torch.randn(n_src, ld_src, generator=g).to(DEV)
+    dst = torch.full((n, ld_dst), -7.0, device=DEV)
+    rows = torch.randint(0, n_src, (n,), generator=g, dtype=torch.int32).to(DEV) if gather else None
+    L.check(lib.bsig_copy_rows(L.ptr(src), ld_src, None if rows is None else L.ptr(rows), L.ptr(dst),
+                               ld_dst, n, cols, L.stream()))
+    torch.cuda.synchronize()
+    want = src[rows.long()] if gather else src[:n]
+    assert torch.equal(dst[:, :cols], want[:, :cols])
+    assert bool((dst[:, cols:] == -7.0).all())

@@ -43,9 +43,9 @@ rows = [('last tile wg has its summary tile in LDS', tiles, 1, np.max),
         ('owners: first / last start of the update', owners, 0, np.min),
         ('owners: last start of the update', owners, 0, np.max),
         ('owners: last has the small weights flags', owners, 4, np.max),
-        ('owners: last has Wh in LDS', owners, 5, np.max),
-        ('owners: first released by the forward flags', owners, 6, np.min),
-        ('owners: last released by the forward flags', owners, 6, np.max),
+        ('owners: wave 0 has seen the forward flags (the others fetch Wh, W2)', owners, 5, np.max),
+        ('owners: first has Wh + W2 registers and the forward flags', owners, 6, np.min),
+        ('owners: last has Wh + W2 registers and the forward flags', owners, 6, np.max),
         ('owners: last h1 (k-slice sum, tanh)', owners, 7, np.max),
         ('owners: last h2', owners, 8, np.max),
         ('owners: last head outputs', owners, 9, np.max),
@@ -69,7 +69,7 @@ for u in range(2, 7):
         acc[label].append(fn([st[g, u, k] for g in grp]) - t0)
 print('update period %.2f us' % np.mean(per) + ('   per update: ' + ' '.join('%.2f' % x for x in per) if os.environ.get('PER_UPDATE') == '1' else ''))
 for label, _, _, _ in rows:
-    print('    %-52s %6.2f' % (label, np.mean(acc[label])) + ('   [' + ' '.join('%.2f' % x for x in acc[label]) + ']' if os.environ.get('PER_UPDATE') == '1' else ''))
+    print('    %-68s %6.2f' % (label, np.mean(acc[label])) + ('   [' + ' '.join('%.2f' % x for x in acc[label]) + ']' if os.environ.get('PER_UPDATE') == '1' else ''))
 if os.environ.get('DETAIL') == '1':
     u = 4
     t0 = min(st[g, u, 0] for g in tiles)
@@ -85,7 +85,7 @@ if os.environ.get('WIDE_DETAIL') == '1':
     t0 = min(st[g, u, 0] for g in tiles)
     print('update %d, head-block workgroups (us after t0): h2 flags seen / h2 in LDS / head outputs flagged / d_out flags seen / d_out block in LDS / dz2 share flagged / weights published' % u)
     for g in small[4:]:
-        print('   wg %3d: %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f' % tuple([g] + [st[g, u, k] - t0 for k in (7, 8, 9, 4, 5, 10, 6)]) + '   [mfma issued %.2f, exchanged %.2f, bias read %.2f, first store %.2f, stores issued %.2f, acked %.2f]' % tuple(st[g, u, k] - t0 for k in (1, 2, 13, 14, 11, 3)))
+        print('   wg %3d: %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f' % tuple([g] + [st[g, u, k] - t0 for k in (7, 8, 9, 4, 5, 10, 6)]) + '   [mfma issued %.2f, exchanged %.2f, stores issued %.2f, acked %.2f]' % tuple(st[g, u, k] - t0 for k in (1, 2, 11, 3)))
     print('owners: fwd flags seen / h1 / h2 (flagged) / head outputs in LDS + exp sum published / rows finished / d_out published / flag_own')
     for g in owners[:6]:
         print('   wg %3d: %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f' % tuple([g] + [st[g, u, k] - t0 for k in (6, 7, 8, 9, 13, 14, 15)]))
