@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libbsig_hip.so')
+# (BSIG_LIB_PATH: another build of the same library, for A/B measurements of kernel variants)
+LIB_PATH = os.environ.get('BSIG_LIB_PATH') or os.path.join(_HERE, 'lib', 'libbsig_hip.so')
 
 BSIG_OK, BSIG_EINVAL, BSIG_ELAUNCH, BSIG_EUNSUPPORTED, BSIG_ENONFINITE = 0, -1, -2, -3, -4
 EPI_NONE, EPI_BIAS, EPI_BIAS_ACT, EPI_COS_SIN, EPI_COS_OFF, EPI_MUL_DACT = range(6)
