@@ -482,7 +482,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   constexpr int kAs = lds_floats<BM, AKM>(), kBs = lds_floats<BN, BKM>();
   constexpr int kEpi = WM * WN * 32 * 32;  // per-wave [32][32] epilogue patches
 #ifdef BSIG_LDS_DB
-  constexpr bool kDoubleLds = TM * TN == 4;   // 128x128 tiles: two LDS images, one barrier per K step
+#ifndef BSIG_LDS_DB_MIN
+#define BSIG_LDS_DB_MIN 4
+#endif
+  constexpr bool kDoubleLds = TM * TN >= BSIG_LDS_DB_MIN;   // large tiles: two LDS images, one barrier per K step
 #else
   constexpr bool kDoubleLds = false;
 #endif
