@@ -47,6 +47,10 @@ CONFIGS = {
     'shadow_more': dict(task='ShadowHand (cfg/shadow_hand_more.yaml)', model='MDNN',
                         summarizer='summary_corrdiff', t=51, sd=211, ad=20, d=32, k=10,
                         hidden=[128, 128], n_feat=0, pairs=5_000),
+    # cfg/anymal.yaml:103-109 as shipped (obs/act 48/12 [ext]): W = 10 waypoints of 47 x 12 products,
+    # I = 56402 -- 221 k-slices, more tile workgroups than CUs: per-phase kernels
+    'anymal_yaml': dict(task='Anymal (cfg/anymal.yaml)', model='MDNN', summarizer='summary_corrdiff',
+                        t=21, sd=48, ad=12, d=13, k=10, hidden=[128, 128], n_feat=0, pairs=5_000),
     'cfg5': dict(task='ShadowHand', model='MDRFF', summarizer='summary_start', t=11, sd=211,
                  ad=20, d=32, k=4, hidden=[], n_feat=4096, pairs=100_000),
 }
