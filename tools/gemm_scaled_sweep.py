@@ -16,7 +16,7 @@ TILES = {0: '64x64', 1: '128x128', 3: '128x64', 4: '128x96', 5: '96x128'}
 
 
 def run(m, n, k, akm, bkm, gather, reps=10):
-    pool = 80000
+    pool = 80000 if k < 50000 and n < 50000 else 1000
     if gather == 'a':        # A rows gathered from a pool (minibatch rows)
         a = torch.randn(pool, k, device=dev)
         rows_a = torch.randint(0, pool, (m,), device=dev, dtype=torch.int32)
@@ -51,7 +51,12 @@ shapes = [('fwd head 8192x260x4096 NT gathered A', 8192, 260, 4096, 0, 0, 'a'),
           ('dW head 260x4096x8192 TN gathered B', 260, 4096, 8192, 1, 1, 'b'),
           ('fwd L1 8192x128x11802 NT gathered A', 8192, 128, 11802, 0, 0, 'a'),
           ('dW L1 128x11802x8192 TN gathered B', 128, 11802, 8192, 1, 1, 'b'),
-          ('eval head 20000x260x4096 NT', 20000, 260, 4096, 0, 0, None)]
+          ('eval head 20000x260x4096 NT', 20000, 260, 4096, 0, 0, None),
+          # minibatch-100 products of a first layer too wide for the persistent kernel
+          # (cfg/shadow_hand_more.yaml, I = 105002; cfg/anymal.yaml, I = 56402)
+          ('wide L1 fwd 100x128x105002 NT gathered A', 100, 128, 105002, 0, 0, 'a'),
+          ('wide L1 dW 128x105002x100 TN gathered B', 128, 105002, 100, 1, 1, 'b'),
+          ('wide L1 fwd 100x128x56402 NT gathered A', 100, 128, 56402, 0, 0, 'a')]
 only = sys.argv[1:]
 for name, m, n, k, akm, bkm, g in shapes:
     if only and not any(o in name for o in only):
@@ -62,7 +67,7 @@ for name, m, n, k, akm, bkm, g in shapes:
     print('%-40s %.2f GFLOP  planner: %.1f us = %.1f TFLOP/s' % (name, fl / 1e9, auto, fl / auto / 1e6), flush=True)
     for tile, tname in TILES.items():
         row = []
-        for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+        for sp in ((1, 2, 3, 4, 6, 8, 12, 16) if k < 50000 else (16, 32, 48, 64, 96, 128, 192, 256)):
             os.environ['BSIG_GEMM_TILE'] = str(tile)
             os.environ['BSIG_GEMM_SPLITS'] = str(sp)
             us = run(m, n, k, akm, bkm, g, 5)
