@@ -53,6 +53,7 @@ class FitBuffers(C.Structure):
 _PROTOS = {
     'bsig_last_error': (C.c_char_p, []),
     'bsig_version': (C.c_int, []),
+    'bsig_abi_info': (u64, [C.c_int]),
     'bsig_device_count': (C.c_int, []),
     'bsig_summary_dim': (i64, [C.c_int] * 5),
     'bsig_summary_start': (C.c_int, [vp, vp, vp, i64] + [C.c_int] * 5 + [i64, vp]),
@@ -141,8 +142,39 @@ def load():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        _check_abi(lib)
         _lib = lib
     return _lib
+
+
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'bsig.h')
+
+
+def header_hash(path=HEADER_PATH):
+    """64-bit FNV-1a of include/bsig.h (what build.sh hands the compiler as BSIG_HEADER_HASH)."""
+    h = 0xcbf29ce484222325
+    with open(path, 'rb') as f:
+        for b in f.read():
+            h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _check_abi(lib):
+    """The library's view of include/bsig.h against this binding's: struct sizes always, the
+    header text when the header is next to the package (a library or an object file built against
+    another revision of the header must not be driven through these ctypes mirrors)."""
+    want = {1: C.sizeof(HeadDims), 2: C.sizeof(MdnCfg), 3: C.sizeof(FitBuffers),
+            4: FitBuffers.x_kind.offset}
+    for which, size in want.items():
+        got = int(lib.bsig_abi_info(which))
+        if got != size:
+            raise RuntimeError('libbsig_hip.so was built against another include/bsig.h (layout %d: '
+                               'library %d, binding %d): rebuild with ./build.sh' % (which, got, size))
+    built = int(lib.bsig_abi_info(0))
+    if built and os.path.exists(HEADER_PATH) and built != header_hash():
+        raise RuntimeError('libbsig_hip.so was built from another revision of include/bsig.h '
+                           '(hash %016x, header %016x): rebuild with ./build.sh'
+                           % (built, header_hash()))
 
 
 def require_gpu():

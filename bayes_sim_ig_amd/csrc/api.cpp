@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
+#include <cstdint>
 #include <cstdio>
 
 #include "../../include/bsig.h"
@@ -17,7 +19,26 @@ void set_error(const char* fmt, ...) {
 }  // namespace bsig
 
 extern "C" const char* bsig_last_error(void) { return bsig::g_err; }
-extern "C" int bsig_version(void) { return 100; }
+extern "C" int bsig_version(void) { return 101; }
+
+// What the library was compiled against, for a binding to compare with its own view
+// (bayes_sim_ig_amd/_lib.py: ctypes mirrors of the structs; a stale object built against an
+// older include/bsig.h would otherwise fail silently).  which: 0 -> FNV-1a hash of the header
+// text the build saw (build.sh passes it), 1..3 -> sizeof bsig_head_dims / bsig_mdn_cfg /
+// bsig_fit_buffers, 4 -> offsetof(bsig_fit_buffers, x_kind).
+#ifndef BSIG_HEADER_HASH
+#define BSIG_HEADER_HASH 0ull
+#endif
+extern "C" uint64_t bsig_abi_info(int which) {
+  switch (which) {
+    case 0: return (uint64_t)BSIG_HEADER_HASH;
+    case 1: return sizeof(bsig_head_dims);
+    case 2: return sizeof(bsig_mdn_cfg);
+    case 3: return sizeof(bsig_fit_buffers);
+    case 4: return offsetof(bsig_fit_buffers, x_kind);
+    default: return 0;
+  }
+}
 extern "C" int bsig_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return BSIG_ELAUNCH;

@@ -8,7 +8,28 @@
 // collective must run on the HIP runtime that owns the caller's streams — and the
 // library stays loadable on hosts without RCCL (single-GPU use never touches this file).
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// No RCCL headers on this host: the six entry points this file binds with dlsym, declared as
+// RCCL's public API has them (the library itself is still found, or not, at run time).
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3,
+               ncclInvalidArgument = 4, ncclInvalidUsage = 5 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclBroadcast(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
 
 #include <cstring>
 #include <mutex>

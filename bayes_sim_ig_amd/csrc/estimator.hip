@@ -377,6 +377,7 @@ struct bsig_fit_plan {
   size_t persist_bytes;
   hipStream_t cap_stream;
   hipGraphExec_t g_step, g_grad, g_apply, g_eval;
+  const float* graph_feats;    // the feature block the captured graphs read (kernel argument)
 };
 
 namespace bsig {
@@ -603,7 +604,12 @@ static int capture(bsig_fit_plan* p, hipGraphExec_t* out, F&& body) {
 }
 
 static int ensure_graphs(bsig_fit_plan* p) {
+  PlanMem fm; plan_mem(p, &fm);
+  // the graphs carry the feature block's address as a kernel argument: a block handed over in
+  // place (bsig_fit_set_features) or taken back (bsig_fit_begin) invalidates them
+  if (p->g_eval && p->graph_feats != fm.feats) drop_graphs(p);
   if (!p->use_graph || p->g_eval) return BSIG_OK;
+  p->graph_feats = fm.feats;
   if (p->split_adam) {
     if (!p->persistent && !p->persistent_mdnn) {
       BSIG_TRY(capture(p, &p->g_grad, [&](hipStream_t s) { return enqueue_grad(p, s, false); }));
@@ -823,6 +829,16 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
   return BSIG_OK;
 }
 
+// Does a captured graph of this plan read the MDRFF feature block?  (Then the block must stay
+// at the workspace address the graphs were captured with: a caller's block is copied there.)
+static bool graphs_read_feats(const bsig_fit_plan* p) {
+  if (!p->use_graph) return false;       // direct launches take the pointer of the call
+  if (!p->persistent) return true;       // update and evaluation graphs
+  if (p->buf.n_test < 1 || p->n_updates < 1) return false;
+  const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
+  return (no_ike && no_ike[0] == '1') || !persist_eval_supported(persist_shape(p));
+}
+
 extern "C" int bsig_fit_set_features(bsig_fit_plan* p, const float* feats, int64_t ld_feats,
                                      int64_t rows, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound && feats, "fit_set_features: plan not bound / null");
@@ -831,7 +847,7 @@ extern "C" int bsig_fit_set_features(bsig_fit_plan* p, const float* feats, int64
                "fit_set_features: need the %lld training + %lld held-out rows",
                (long long)p->buf.n_train, (long long)p->buf.n_test);
   p->ext_feats = nullptr;
-  if (ld_feats == p->cfg.rff_feats && aligned(feats, 16)) {
+  if (ld_feats == p->cfg.rff_feats && aligned(feats, 16) && !graphs_read_feats(p)) {
     // a dense block of feature rows: the kernels read it in place (the caller keeps it alive
     // until the call's work has been enqueued and run)
     p->ext_feats = feats;

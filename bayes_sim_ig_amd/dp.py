@@ -136,11 +136,17 @@ class DataParallel:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def gather_counts(self, value, device='cpu'):
-        """Every rank's ``value`` (a small non-negative number), on every rank."""
-        slots = torch.zeros(self.world, dtype=torch.float32, device=device)
-        slots[self.rank] = float(value)
+        """Every rank's ``value`` (a non-negative integer below 2**48), on every rank.  Exact:
+        the exchange sums fp32, so the value travels as three 16-bit digits, each in a slot only
+        its own rank fills."""
+        value = int(value)
+        assert 0 <= value < (1 << 48)
+        slots = torch.zeros(3 * self.world, dtype=torch.float32, device=device)
+        for d in range(3):
+            slots[3 * self.rank + d] = float((value >> (16 * d)) & 0xFFFF)
         self.allreduce_sum(slots)
-        return [int(v) for v in slots.cpu().tolist()]
+        got = [int(v) for v in slots.cpu().tolist()]
+        return [got[3 * r] | (got[3 * r + 1] << 16) | (got[3 * r + 2] << 32) for r in range(self.world)]
 
     def mean_losses(self, train_loss, test_loss, n_test):
         """Global mean train loss per update (equal local batches) and the

@@ -167,9 +167,10 @@ def cpu_baseline(cfg, theta, states, actions, budget_s=12.0, max_chunks=12):
                          torch.__version__, best_nt, ncpu)}
 
 
-def nll_check(pkg, cfg, theta, states, actions, device):
+def nll_check(pkg, cfg, theta, states, actions, device, lazy=True):
     """Teacher-forced first chunk, EPS_NOISE=0: held-out NLL of the HIP path
-    vs the oracle from identical weights / minibatch ids."""
+    vs the oracle from identical weights / minibatch ids.  lazy: cross-correlation
+    summaries reach run_training the way BayesSim.fit hands them over (factor rows, f2)."""
     from oracle import summarize as osum
     old = pkg.MDNN.EPS_NOISE
     pkg.MDNN.EPS_NOISE = 0.0
@@ -179,7 +180,7 @@ def nll_check(pkg, cfg, theta, states, actions, device):
         m = min(1000, theta.shape[0])
         th, st, ac = theta[:m], states[:m], actions[:m]
         ids = np.random.RandomState(5).randint(0, max(int(m * 0.8), 1), (100, 100))
-        summ = bs._summarize(st, ac)
+        summ = bs._summarize(st, ac, lazy=lazy)
         got = bs.model.run_training(summ, th, 100, 100, ids_table=ids)
         ora = build_oracle(cfg, summ.shape[1], 77, 0.0,
                            freqs=bs.model.rff.freqs.cpu().numpy() if cfg['model'] == 'MDRFF' else None)

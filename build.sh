@@ -1,24 +1,38 @@
 #!/usr/bin/env bash
 # Build libbsig_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+# An object is rebuilt when the CONTENT of its source, of any csrc header, of include/bsig.h or the
+# flags changed (a stamp next to the object; file times do not survive every transport).
 set -euo pipefail
 cd "$(dirname "$0")"
 SRC=bayes_sim_ig_amd/csrc
 OUT=bayes_sim_ig_amd/lib
 mkdir -p "$OUT" "$OUT/obj"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+HHASH=$(python3 - <<'PY'
+h = 0xcbf29ce484222325
+for b in open('include/bsig.h', 'rb').read():
+    h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+print('0x%016xull' % h)
+PY
+)
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBSIG_HEADER_HASH=$HHASH"
+COMMON=$(cat "$SRC"/*.h include/bsig.h | sha256sum | cut -d' ' -f1)
 pids=()
-for f in summarizers gemm_f32 gemm_tile_64 gemm_tile_128 gemm_tile_128x32 gemm_tile_128x64 gemm_tile_128x96 gemm_tile_96x128 mdn_head flat_ops estimator fit_persistent fit_persistent_mdnn; do
-  if [ ! -f "$OUT/obj/$f.o" ] || [ "$SRC/$f.hip" -nt "$OUT/obj/$f.o" ] || [ -n "$(find "$SRC" -name '*.h' -newer "$OUT/obj/$f.o")" ] || [ include/bsig.h -nt "$OUT/obj/$f.o" ]; then
-    hipcc $FLAGS -c "$SRC/$f.hip" -o "$OUT/obj/$f.o" &
+build_one() {  # name, source, extra flags
+  local stamp="$OUT/obj/$1.stamp"
+  local want="$(echo "$FLAGS $3 $COMMON" | cat - "$2" | sha256sum | cut -d' ' -f1)"
+  if [ ! -f "$OUT/obj/$1.o" ] || [ ! -f "$stamp" ] || [ "$(cat "$stamp")" != "$want" ]; then
+    ( hipcc $FLAGS $3 -c "$2" -o "$OUT/obj/$1.o" && echo "$want" > "$stamp" ) &
     pids+=($!)
   fi
+}
+for f in summarizers gemm_f32 gemm_tile_64 gemm_tile_128 gemm_tile_128x32 gemm_tile_128x64 gemm_tile_128x96 gemm_tile_96x128 mdn_head flat_ops estimator fit_persistent fit_persistent_mdnn; do
+  build_one "$f" "$SRC/$f.hip" ""
 done
 for f in api comm; do
-  if [ ! -f "$OUT/obj/$f.o" ] || [ "$SRC/$f.cpp" -nt "$OUT/obj/$f.o" ] || [ include/bsig.h -nt "$OUT/obj/$f.o" ] || [ "$SRC/common.h" -nt "$OUT/obj/$f.o" ]; then
-    hipcc $FLAGS -x hip -c "$SRC/$f.cpp" -o "$OUT/obj/$f.o" &
-    pids+=($!)
-  fi
+  build_one "$f" "$SRC/$f.cpp" "-x hip"
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+rc=0
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
+[ $rc -eq 0 ] || { echo "build failed" >&2; exit 1; }
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbsig_hip.so" "$OUT"/obj/*.o -ldl
 echo "built $OUT/libbsig_hip.so"

@@ -38,6 +38,12 @@ typedef void* bsig_stream_t; /* hipStream_t */
 
 const char* bsig_last_error(void);
 int bsig_version(void);
+/* What the library was compiled against, so that a binding can compare it with its own view of
+ * this header before the first call: which = 0 -> FNV-1a (64-bit) hash of this file's text as the
+ * build saw it; 1, 2, 3 -> sizeof(bsig_head_dims), sizeof(bsig_mdn_cfg), sizeof(bsig_fit_buffers);
+ * 4 -> offsetof(bsig_fit_buffers, x_kind); anything else 0.  (No reference counterpart: the
+ * reference has no native boundary.) */
+uint64_t bsig_abi_info(int which);
 /* Number of devices visible to the library, or a negative code. */
 int bsig_device_count(void);
 

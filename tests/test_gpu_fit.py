@@ -167,9 +167,9 @@ def test_bayessim_on_reference_pendulum_fixture(B):
     tsa = torch.from_numpy(g['true_data']).reshape(1, -1, 4).to(DEV)
     mog = bsim.predict(tsa[:, :, :3].contiguous(), tsa[:, :, 3:].contiguous())
     nll = -mog.eval(g['true_params'].reshape(1, -1).astype(np.float64), log=True)
-    np.testing.assert_allclose(nll, g['mog.nll_true'], rtol=2e-4)
-    np.testing.assert_allclose(mog.a, g['mog.a'], rtol=2e-4, atol=1e-6)
-    np.testing.assert_allclose(np.stack([c.m for c in mog.xs]), g['mog.ms'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(nll, g['mog.nll_true'], rtol=1e-4)
+    np.testing.assert_allclose(mog.a, g['mog.a'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(np.stack([c.m for c in mog.xs]), g['mog.ms'], rtol=1e-4, atol=1e-6)
 
 
 def test_bayessim_multi_trajectory_refit_runs(B):
@@ -515,6 +515,43 @@ def test_fit_projects_blocks_of_chunks_at_once(B):
     torch.testing.assert_close(fa, fb, rtol=1e-2, atol=2e-3)
 
 
+@pytest.mark.parametrize('variant', ['full_cov', 'no_persistent', 'no_inkernel_eval', 'no_graph'])
+def test_fit_hands_each_chunk_its_own_features_on_graph_paths(B, variant):
+    """The same comparison for MDRFF plans whose updates or evaluations replay HIP graphs (full
+    covariance, BSIG_NO_PERSISTENT=1, evaluation graphs between the launches): the graphs carry
+    the feature block's address as a kernel argument, and BayesSim.fit hands every chunk another
+    slice of the block's features -- chunks 2..N must train on THEIR features (a graph captured
+    on chunk 1's slice would not), bsig_fit_set_features / bsig_fit_begin."""
+    import os
+    import bench
+    cfg = dict(task='synthetic', model='MDRFF', summarizer='summary_start', t=11, sd=5, ad=2,
+               d=3, k=4, hidden=[], n_feat=256, pairs=3500, full=variant == 'full_cov')
+    env = {'no_persistent': {'BSIG_NO_PERSISTENT': '1'},
+           'no_inkernel_eval': {'BSIG_NO_INKERNEL_EVAL': '1'}}.get(variant, {})
+    B.MDNN.USE_GRAPH = variant != 'no_graph'
+    B.MDNN.EPS_NOISE = 0.0
+    theta, states, actions = bench.synth_pairs(cfg, 3500, 3, DEV)
+    out = []
+    os.environ.update(env)
+    try:
+        for pre in ('0', '1'):
+            os.environ['BSIG_NO_FIT_PREPROJECT'] = pre
+            bs = bench.build_gpu_model(B, cfg, DEV, 77)
+            np.random.seed(11)
+            out.append((bs.fit(theta, states, actions), bs.model._flat.clone()))
+            expect = 0 if variant in ('full_cov', 'no_persistent') else 1
+            assert B._lib.load().bsig_fit_is_persistent(bs.model._plan) == expect
+    finally:
+        for k in list(env) + ['BSIG_NO_FIT_PREPROJECT']:
+            os.environ.pop(k, None)
+    (la, fa), (lb, fb) = out
+    assert len(la) == len(lb) == 4
+    for x, y in zip(la, lb):
+        np.testing.assert_allclose(x['train_loss'], y['train_loss'], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(x['test_loss'], y['test_loss'], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(fa, fb, rtol=1e-2, atol=2e-3)
+
+
 def test_full_size_chunk_protocol_fit(B):
     """cfg5-shaped fit (ShadowHand MDRFF-4096, summary_start) over 20 chunks with
     the reference defaults (EPS_NOISE=1e-5, numpy-RNG ids): finite, 6+6 logs per
@@ -575,32 +612,90 @@ def _fp64_oracle(bench, cfg, in_dim, w0, freqs):
     return o
 
 
+def _bracket_chunk(B, name, seed, lazy, n_updates=100, must_factor=None):
+    """One teacher-forced chunk three ways: HIP, the fp32 oracle, the fp64 oracle (same start
+    weights, same ids, EPS_NOISE = 0).  Returns the three log dicts and the GPU model."""
+    import bench
+    from oracle import summarize as osum
+    B.MDNN.EPS_NOISE = 0.0
+    cfg = dict(bench.CONFIGS[name])
+    torch.set_num_threads(8)
+    theta, states, actions = bench.synth_pairs(cfg, 1000, seed, DEV)
+    ids = np.random.RandomState(5).randint(0, 800, (n_updates, 100))
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    w0 = {k: v.cpu().clone() for k, v in bs.model.state_dict().items()}
+    summ = bs._summarize(states, actions, lazy=lazy)
+    if lazy:      # the factor rows must reach the kernel as factor rows (f2), not expanded
+        assert isinstance(summ, B.summarizers.CrossCorrFactors)
+    hip = bs.model.run_training(summ, theta, n_updates, 100, ids_table=ids)
+    if lazy if must_factor is None else must_factor:
+        assert B._lib.load().bsig_fit_accepts_factors(bs.model._plan) == 1
+    s_cpu = osum.SUMMARIZERS[cfg['summarizer']](states.cpu(), actions.cpu())
+    o32 = bench.build_oracle(cfg, s_cpu.shape[1], 77, 0.0)
+    o32.load_state_dict(w0)
+    f32 = o32.run_training(s_cpu, theta.cpu(), n_updates, 100, ids_table=ids)
+    del o32
+    o64 = _fp64_oracle(bench, cfg, s_cpu.shape[1], w0, None)
+    f64 = o64.run_training(s_cpu.double(), theta.cpu().double(), n_updates, 100, ids_table=ids)
+    return hip, f32, f64, bs
+
+
+def _assert_bracket(hip, f32, f64):
+    """|hip - f64| <= |cpu_f32 - f64| + 1e-4 |f64| at every logging point."""
+    for key in ('test_loss', 'train_loss'):
+        h, a, r = (np.asarray(v[key], dtype=np.float64) for v in (hip, f32, f64))
+        bound = np.abs(a - r) + 1e-4 * np.abs(r) + 1e-6
+        assert (np.abs(h - r) <= bound).all(), (key, h - r, a - r)
+
+
+@pytest.mark.parametrize('lazy', [False, True])
 @pytest.mark.parametrize('seed', [3, 4, 5])
-def test_cfg3_chunk_within_reference_fp32_noise_of_fp64(B, seed):
+def test_cfg3_chunk_within_reference_fp32_noise_of_fp64(B, seed, lazy):
     """cfg3 (Ant MDNN on 11802-wide cross-correlations): the first layer sums 11802 fp32
     products per output, so two fp32 evaluation orders of the SAME chunk differ by more than
     1e-4 in the held-out NLL -- the reference's own fp32 CPU path included.  The yardstick is
     therefore the same teacher-forced chunk run by the oracle in fp64: the HIP path must be
     as close to it as the reference's fp32 path is, plus the north-star 1e-4:
-        |hip - f64| <= |cpu_f32 - f64| + 1e-4 |f64|     at every logging point."""
+        |hip - f64| <= |cpu_f32 - f64| + 1e-4 |f64|     at every logging point.
+    lazy: the summaries reach the update kernel as cross-correlation FACTOR rows (f2; what
+    BayesSim.fit runs) -- the mdnn_updates_kernel<., FAC> path against the oracle itself.
+    Beside the bracket, the direct north-star statement on the final held-out NLL:
+    |hip - cpu_f32| <= 1e-4 |cpu_f32| (summarizers.py:106-119 into mdnn.py:228-242)."""
+    hip, f32, f64, _ = _bracket_chunk(B, 'cfg3', seed, lazy)
+    _assert_bracket(hip, f32, f64)
+    g, r = hip['test_loss'][-1], f32['test_loss'][-1]
+    assert abs(g - r) <= 1e-4 * abs(r), (g, r)
+
+
+@pytest.mark.parametrize('lazy', [False, True])
+def test_cfg3_chunk_from_factor_rows_matches_oracle_directly(B, lazy):
+    """bench.nll_check on cfg3 (what the bench line's per_config reports) with the summaries as
+    factor rows and as materialised rows: the FAC kernel path vs the fp32 oracle at 1e-4."""
     import bench
-    from oracle import summarize as osum
-    B.MDNN.EPS_NOISE = 0.0
     cfg = dict(bench.CONFIGS['cfg3'])
+    theta, states, actions = bench.synth_pairs(cfg, 1000, 3, DEV)
     torch.set_num_threads(8)
-    theta, states, actions = bench.synth_pairs(cfg, 1000, seed, DEV)
-    ids = np.random.RandomState(5).randint(0, 800, (100, 100))
-    bs = bench.build_gpu_model(B, cfg, DEV, 77)
-    w0 = {k: v.cpu().clone() for k, v in bs.model.state_dict().items()}
-    summ = bs._summarize(states, actions)
-    hip = bs.model.run_training(summ, theta, 100, 100, ids_table=ids)
-    s_cpu = osum.SUMMARIZERS[cfg['summarizer']](states.cpu(), actions.cpu())
-    o32 = bench.build_oracle(cfg, summ.shape[1], 77, 0.0)
-    o32.load_state_dict(w0)
-    f32 = o32.run_training(s_cpu, theta.cpu(), 100, 100, ids_table=ids)
-    o64 = _fp64_oracle(bench, cfg, summ.shape[1], w0, None)
-    f64 = o64.run_training(s_cpu.double(), theta.cpu().double(), 100, 100, ids_table=ids)
+    res = bench.nll_check(B, cfg, theta, states, actions, DEV, lazy=lazy)
+    assert res['rel_diff'] < 1e-4, res
+
+
+@pytest.mark.parametrize('name', ['anymal_yaml', 'shadow_more'])
+@pytest.mark.parametrize('seed', [3, 4])
+def test_wide_crosscorr_chunk_within_reference_fp32_noise_of_fp64(B, name, seed):
+    """cfg/anymal.yaml (I = 56402) and cfg/shadow_hand_more.yaml (I = 105002) as shipped: most
+    of their inputs are near-constant products whose first-layer gradients are rounding noise,
+    which Adam turns into full-size steps -- two fp32 evaluation orders of the same chunk part
+    after ~40 updates.  Same yardstick as cfg3: the chunk in fp64; the HIP path must be as
+    close to it as the reference's fp32 path is (+ 1e-4) at every logging point of the 100
+    updates, through the path BayesSim.fit takes (factor rows where the plan accepts them)."""
+    hip, f32, f64, bs = _bracket_chunk(B, name, seed, lazy=True, must_factor=False)
+    _assert_bracket(hip, f32, f64)
+
+
+@pytest.mark.parametrize('name', ['anymal_yaml', 'shadow_more'])
+def test_wide_crosscorr_chunk_20_updates_matches_oracle(B, name):
+    """... and before the fp32 paths part: 20 teacher-forced updates, every loss within the
+    north-star 1e-4 of the fp32 oracle."""
+    hip, f32, _, _ = _bracket_chunk(B, name, 3, lazy=True, n_updates=20, must_factor=False)
     for key in ('test_loss', 'train_loss'):
-        h, a, r = (np.asarray(v[key], dtype=np.float64) for v in (hip, f32, f64))
-        bound = np.abs(a - r) + 1e-4 * np.abs(r) + 1e-6
-        assert (np.abs(h - r) <= bound).all(), (key, h - r, a - r)
+        np.testing.assert_allclose(hip[key], f32[key], rtol=1e-4, atol=1e-6)
