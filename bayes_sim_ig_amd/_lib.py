@@ -103,6 +103,7 @@ _PROTOS = {
     'bsig_fit_flush': (C.c_int, [vp, vp]),
     'bsig_fit_is_persistent': (C.c_int, [vp]),
     'bsig_fit_accepts_factors': (C.c_int, [vp]),
+    'bsig_fit_accepts_factor_rows': (C.c_int, [vp, C.c_int, C.c_int]),
     'bsig_fit_takes_features': (C.c_int, [vp, i64]),
     'bsig_fit_eval': (C.c_int, [vp, vp]),
     'bsig_fit_updates': (C.c_int, [vp, i64, vp]),

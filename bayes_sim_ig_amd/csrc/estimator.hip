@@ -371,6 +371,8 @@ struct bsig_fit_plan {
   bool use_graph, split_adam;
   bool persistent;             // updates run in the persistent kernel (persist.h)
   bool persistent_mdnn;        // single-rank MDNN [128, 128] updates: fit_persistent_mdnn.hip
+  bool persistent_mdnn_cap;    // ... the plan's shape is covered (persistent_mdnn: this binding is)
+  bool mdnn_streams;           // ... with a streamed first layer (cross-correlation factor rows only)
   int dp_evals_done;           // data-parallel + in-launch evaluations: bsig_fit_eval calls so far
   bool adam_pending;           // ... data-parallel: the Adam step on the reduced gradients is
                                // taken by the next launch (or flushed before an evaluation)
@@ -749,6 +751,8 @@ extern "C" int bsig_fit_create_sized(const bsig_mdn_cfg* cfg, int64_t batch,
   p->persistent_mdnn = cfg->rff_feats == 0 && p->L.n_layers == 2 && n_updates > 0 &&
                        !(no_persist && no_persist[0] == '1') &&
                        persist_mdnn_supported(persist_mdnn_shape(p));
+  p->persistent_mdnn_cap = p->persistent_mdnn;
+  p->mdnn_streams = p->persistent_mdnn && persist_mdnn_streams(persist_mdnn_shape(p)) != 0;
   if (p->persistent_mdnn)
     p->persist_bytes = round_up<size_t>(persist_mdnn_workspace_bytes(persist_mdnn_shape(p)), 256);
   if (p->hoist) {
@@ -789,6 +793,11 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
                (long long)b->n_test, (long long)p->max_test);
   const bool fac = b->x_kind == BSIG_X_CROSSCORR_FACTORS;
   BSIG_REQUIRE(b->x_kind == BSIG_X_ROWS || fac, "fit_bind: unknown x_kind %d", b->x_kind);
+  // a streamed first layer exists for factor rows only: summary rows of that width go through
+  // the per-phase kernels
+  const bool mdnn_now = p->persistent_mdnn_cap &&
+                        (!p->mdnn_streams || (fac && persist_mdnn_accepts_factors(persist_mdnn_shape(p), b->x_s, b->x_a)));
+  if (mdnn_now != p->persistent_mdnn) { drop_graphs(p); p->persistent_mdnn = mdnn_now; p->bound = false; }
   if (fac) {
     BSIG_REQUIRE(b->x_s >= 1 && b->x_a >= 1 && (int64_t)b->x_s * b->x_a + 2 == p->cfg.input_dim,
                  "fit_bind: factor rows S=%d A=%d do not give the %d inputs of the first layer",
@@ -796,7 +805,7 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
     BSIG_REQUIRE(b->ldx_train >= b->x_s + b->x_a + 3, "fit_bind: factor rows need a pitch >= S + A + 3");
     BSIG_REQUIRE(b->n_test == 0 || b->ldx_test >= p->cfg.input_dim,
                  "fit_bind: the held-out rows are summary rows (ldx_test >= input_dim)");
-    if (!bsig_fit_accepts_factors(p)) {
+    if (!bsig_fit_accepts_factor_rows(p, b->x_s, b->x_a)) {
       set_error("fit_bind: this plan runs kernels that read materialised summary rows "
                 "(bsig_fit_accepts_factors); expand the factors (bsig_crosscorr_expand)");
       return BSIG_EUNSUPPORTED;
@@ -929,7 +938,9 @@ extern "C" int bsig_fit_apply(bsig_fit_plan* p, bsig_stream_t stream) {
   BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_apply: plan not bound with SPLIT_ADAM");
   // persistent kernel: the step is taken by the next bsig_fit_grad launch while it
   // loads its tiles (bsig_fit_eval / bsig_fit_flush take it at once)
-  if (p->persistent || p->persistent_mdnn) { p->adam_pending = true; return BSIG_OK; }
+  if (p->persistent || (p->persistent_mdnn && !p->mdnn_streams)) { p->adam_pending = true; return BSIG_OK; }
+  // (a streamed first layer: the flat Adam kernel, with the step sizes the launch left in the state block)
+  if (p->persistent_mdnn) return enqueue_apply(p, as_stream(stream));
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_apply, as_stream(stream))); return BSIG_OK; }
   return enqueue_apply(p, as_stream(stream));
 }
@@ -946,7 +957,16 @@ extern "C" int bsig_fit_takes_features(const bsig_fit_plan* p, int64_t n_train) 
 extern "C" int bsig_fit_accepts_factors(const bsig_fit_plan* p) {
   // every update runs in the persistent kernel of the two-layer MDNN, whose first-layer tile
   // workgroups form the products; the evaluations read materialised held-out rows
-  return p && p->persistent_mdnn && p->n_updates >= 1 ? 1 : 0;
+  // (a plan with a streamed first layer: only through bsig_fit_accepts_factor_rows, which sees S and A)
+  return p && p->persistent_mdnn_cap && !p->mdnn_streams && p->n_updates >= 1 ? 1 : 0;
+}
+
+extern "C" int bsig_fit_accepts_factor_rows(const bsig_fit_plan* p, int s_dim, int a_dim) {
+  // ... for these factor dimensions: a plan whose first layer is STREAMED (it does not fit the
+  // chip: cfg/anymal.yaml, cfg/shadow_hand_more.yaml) covers A % 4 == 0 and factor rows of two
+  // minibatches in a workgroup's LDS
+  return p && p->persistent_mdnn_cap && p->n_updates >= 1 &&
+                 persist_mdnn_accepts_factors(persist_mdnn_shape(p), s_dim, a_dim) ? 1 : 0;
 }
 
 extern "C" int bsig_fit_is_persistent(const bsig_fit_plan* p) {
@@ -987,7 +1007,8 @@ static int enqueue_updates(bsig_fit_plan* p, int64_t n, hipStream_t st) {
     for (int64_t it = 0; it < n; ++it) {
       BSIG_TRY(p->persistent ? enqueue_persistent(p, 1, st, dp_eval_total(p))
                              : enqueue_persistent_mdnn(p, 1, st, dp_eval_total(p)));
-      p->adam_pending = true;
+      if (p->persistent_mdnn && p->mdnn_streams) BSIG_TRY(enqueue_apply(p, st));
+      else p->adam_pending = true;
     }
     return BSIG_OK;
   }

@@ -40,6 +40,12 @@ struct PersistMdnnBuffers {
 struct PersistHyper;   // persist.h
 
 bool persist_mdnn_supported(const PersistMdnnShape& s);
+// ... with the first layer STREAMED by the tile workgroups (it does not fit the chip): such a plan
+// takes cross-correlation factor rows only, its Adam step of a data-parallel rank and its held-out
+// evaluations run outside the launches
+int persist_mdnn_streams(const PersistMdnnShape& s);
+// ... and S x A cross-correlation factor rows are covered (bsig.h: x_kind)
+bool persist_mdnn_accepts_factors(const PersistMdnnShape& s, int S, int A);
 // ... and the held-out evaluations of up to s.max_test rows can run inside the launches
 bool persist_mdnn_eval_supported(const PersistMdnnShape& s);
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s);

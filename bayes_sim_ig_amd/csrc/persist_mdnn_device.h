@@ -1,0 +1,1451 @@
+// Device side of the persistent update kernels of the two-layer MDNN (fit_persistent_mdnn.hip:
+// W1 tiles resident on the chip; fit_persistent_mdnn_stream.hip: W1 streamed): the argument
+// block, the tile / small-weight / row-owner workgroup bodies.  Reference: mdnn.py:89-125
+// (forward), :127-178 (NLL), :203/:219-233 (Adam, update loop).
+#pragma once
+#include "persist_mdnn.h"
+
+#include <algorithm>
+
+#include "persist.h"
+#include "persist_device.h"
+
+namespace bsig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMT = 512;            // threads per workgroup (8 wavefronts)
+constexpr int kMC = 256;            // first-layer input columns per tile workgroup
+constexpr int kMPitch = kMC + 4;    // LDS row pitch of the summary / weight tiles
+constexpr int kMNB = 32;            // weight rows per tile / small-weight workgroup
+constexpr int kMH = 128;            // hidden width (both layers)
+constexpr int kMHP = kMH + 4;       // LDS pitch of a 128-wide activation row
+constexpr int kMR = 4;              // minibatch rows per owner workgroup (power of two <= 8)
+constexpr int kMPbuf = 33;
+constexpr int kMLdsLimit = 160 * 1024;
+
+struct MdnnArgs {
+  int B, FR, I, Nh, Nh16, NhP, D, K;
+  int k_slices, G1, n_owner, n_small;
+  int n_updates, x_floats;
+  const float* x; int64_t ldx; const int32_t* ids;
+  int x_fac, xS, xA;   // x rows are cross-correlation factors [sf S | af A | mean | std | 1]
+                       // (x_test rows are always materialised summaries)
+  const float* y; int64_t ldy;
+  float* params; float* m1; float* m2;
+  int64_t w1_off, b1_off, w2_off, b2_off, wh_off, bh_off;
+  int32_t* state; float* train_loss;
+  double lr, beta1, beta2;
+  float adam_eps, eps_noise, min_w, ll_limit, inv_norm;
+  // exchange area (written through, read around the L2)
+  float* slabs;   // [k_slices][B][128] first-layer partial products
+  float* dz1;     // [B][128]   owners -> tiles
+  float* h1;      // [B][128]   owners -> small-weight workgroups (W2 blocks)
+  float* h2;      // [B][128]   ... (head blocks)
+  float* dz2;     // [B][128]   ... (W2 blocks)
+  float* d_out;   // [B][NhP]   ... (head blocks)
+  // W2 again, in the order the owners' MFMA operands want it (one coalesced 8-byte load
+  // per lane and instruction): written by the W2 small-weight workgroups next to `params`
+  // Two copies by the parity of the update that reads them: the copy of update t stays
+  // intact while update t's Adam step writes the copy of t+1 (an evaluation at the end of
+  // update t still reads W2 as of t).
+  float* w2f_pack;   // [2][8 waves][8 tt][2][64 lanes][2]: W2[16w + c16][16tt + 4g + 2half + e]
+  float* w2b_pack;   // [2][8 waves][8 tt][2][64 lanes][2]: W2[16tt + 4g + 2half + e][16w + c16]
+  unsigned* flag_fwd; unsigned* flag_own; unsigned* flag_small; unsigned* flag_pack;
+  // WIDE heads (Nh > 272: the head matrix no longer fits the row owners' LDS next to their
+  // activations -- the reference YAMLs' 10 components with D > 13, cfg/ant.yaml:69-70): the
+  // head-block workgroups, which hold 32 rows of the head matrix anyway, form the head outputs
+  // and their share of d_out Wh for ALL minibatch rows; per update owners -> (h2) -> head blocks
+  // -> (o_wide) -> owners -> (d_out) -> head blocks -> (dz2_part) -> owners
+  int wide, n_hb;
+  float* o_wide;     // [n_hb][B][32]   raw head outputs, bias included (block-major like the slabs)
+  float* dz2_part;   // [n_hb][B][128]  partial d_out Wh of each head block
+  unsigned* flag_h2; unsigned* flag_o; unsigned* flag_dout; unsigned* flag_dz2;
+  unsigned launch_tag;   // flag_pack value of THIS launch: the small weights (and the W2 packs)
+                         // as of its start are out, one flag per small-weight workgroup
+  unsigned long long* gran;
+  // data-parallel ranks (one update per launch, the caller all-reduces `grads` between
+  // launches): weight / bias gradients go to `grads` (flat layout) instead of into Adam,
+  // and the Adam step of the PREVIOUS update (on the reduced gradients) is taken by the
+  // weights' owners while they load them (adam_pending)
+  float* grads; int adam_pending;
+  int pair_ok;                       // rows of W1 are 8-byte aligned pairs (w1_off, I even)
+  // held-out evaluations inside the launch (mdnn.py:235-242; do_eval), as in
+  // fit_persistent.hip: the tile workgroups form the held-out rows' first-layer products
+  // while they wait for the row owners of the NEXT update (their LDS still holds the
+  // evaluated weights); the owners run layers 2.. and the forward NLL of their held-out
+  // rows after they have published that update's rows.
+  int do_eval, eval_every, n_total, n_test, eval_passes;
+  const float* x_test; int64_t ldx_test;
+  const float* y_test; int64_t ldy_test;
+  float* test_loss;                  // [n_evals]
+  float* eval_slabs;                 // [2][eval_passes][k_slices][B][128]
+  float* eval_out;                   // [n_test][NhP] head outputs of the held-out rows (staging)
+  unsigned* flag_eval;               // [G1]  evaluation number + 1
+  unsigned long long* gran_eval;     // [2][kXwgMax] {tag, value}: sum exp(pre), sum logsumexp
+  long long* prof;   // diagnostics: [256][kMProfUpdates][16] wall-clock stamps, or null
+  // where the row owners take the first-layer pre-activations from: o_k_slices slabs [B][128]
+  // behind G1 flags.  Resident W1 tiles: the tiles' split-K slabs (slabs, k_slices, flag_fwd);
+  // streamed W1: ONE slab, already summed by the tile workgroups (hpre, 1, flag_red)
+  const float* o_slabs; int o_k_slices; unsigned* o_flags;
+  // ---- streamed first layer (fit_persistent_mdnn_stream.hip): W1 does not fit the chip
+  //      (cfg/anymal.yaml I = 56402, cfg/shadow_hand_more.yaml I = 105002); tile workgroup g
+  //      walks the 64-column chunks [g*s_chunks/G1, (g+1)*s_chunks/G1) of W1, all 128 rows
+  int stream, s_chunks;
+  int s_nip, s_pf;     // factor rows in LDS: sf slots [0, s_nip), af | mean std 0.. at s_nip, pitch s_pf
+  float* hpre;         // [B][128] layer-1 pre-activations summed over the tile workgroups (+ b1)
+  unsigned* flag_red;  // [G1] the quads of hpre this workgroup sums are out
+};
+
+constexpr int kMProfUpdates = 8;
+#define BSIG_MSTAMP(k)                                                              \
+  do {                                                                              \
+    if (p.prof && threadIdx.x == 0 && t < kMProfUpdates)                            \
+      p.prof[((int64_t)blockIdx.x * kMProfUpdates + t) * 16 + (k)] = wall_clock64(); \
+  } while (0)
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// First-layer inputs from cross-correlation FACTOR rows (summarizers.py:106-119; layout in
+// bsig.h): x[i*A + j] = sf[i] * af[j] -- the one fp32 multiply the summarizer itself would
+// do --, x[S*A] = mean * 1, x[S*A + 1] = std * 1; columns beyond that come out as 1 * 1 and
+// are masked by the callers.  FacCols: where the two factors of the four consecutive inputs
+// x[col .. col+3] sit inside a factor row (the same for every row).
+struct FacCols { int oi[4], oj[4]; };
+__device__ __forceinline__ FacCols fac_cols(int col, int S, int A) {
+  const int SA = S * A, one = S + A + 2;
+  // col / A without an integer division: float estimate, two corrections (col < 2^24)
+  int i = (int)((float)col * __builtin_amdgcn_rcpf((float)A));
+  if (i * A > col) --i;
+  if ((i + 1) * A <= col) ++i;
+  int j = col - i * A;
+  FacCols c;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = col + e;
+    c.oi[e] = k < SA ? i : (k == SA ? S + A : (k == SA + 1 ? S + A + 1 : one));
+    c.oj[e] = k < SA ? S + j : one;
+    if (++j == A) { j = 0; ++i; }
+  }
+  return c;
+}
+__device__ __forceinline__ float4 fac_load4(const float* __restrict__ rowp, const FacCols& c) {
+  return make_float4(rowp[c.oi[0]] * rowp[c.oj[0]], rowp[c.oi[1]] * rowp[c.oj[1]],
+                     rowp[c.oi[2]] * rowp[c.oj[2]], rowp[c.oi[3]] * rowp[c.oj[3]]);
+}
+
+// one [<=104, 256] summary tile = 13 float4 per thread in named registers
+#define BSIG_MPF_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#define BSIG_MPF_DECL(u) float4 pf##u;
+#define BSIG_MPF_LOAD(u)                                                                    \
+  {                                                                                         \
+    const int idx = min((u) * kMT + tid, nvec - 1);                                         \
+    const int64_t fr = (int64_t)p.ids[pf_row0 + (idx >> 6)];                                \
+    if constexpr (FAC) {                                                                    \
+      pf##u = fac_load4(p.x + fr * p.ldx, fcols);                                           \
+    } else {                                                                                \
+      const int64_t col = min((int64_t)k0 + (idx & 63) * 4, p.ldx - 4);                     \
+      pf##u = *reinterpret_cast<const float4*>(p.x + fr * p.ldx + col);                     \
+    }                                                                                       \
+  }
+#define BSIG_MPF_ZERO(u) pf##u = make_float4(0.f, 0.f, 0.f, 0.f);
+// columns >= I (row padding, the tail of the last k-slice) enter as zeros
+#define BSIG_MPF_STORE(u)                                                                   \
+  {                                                                                         \
+    const int idx = (u) * kMT + tid;                                                        \
+    if (idx < nvec) {                                                                       \
+      const int col = k0 + (idx & 63) * 4;                                                  \
+      float4 v = pf##u;                                                                     \
+      v.x = col + 0 < p.I ? v.x : 0.f; v.y = col + 1 < p.I ? v.y : 0.f;                     \
+      v.z = col + 2 < p.I ? v.z : 0.f; v.w = col + 3 < p.I ? v.w : 0.f;                     \
+      *reinterpret_cast<float4*>(Fl + (idx >> 6) * kMPitch + (idx & 63) * 4) = v;           \
+    }                                                                                       \
+  }
+
+// number of evaluation points it % every == 0 strictly before update s (the evaluation after
+// the last update of a call is not one of them)
+__device__ __forceinline__ int mdnn_evals_before(int s, int every) { return s == 0 ? 0 : (s - 1) / every + 1; }
+
+// ---- tile workgroups, evaluation number eidx: held-out summaries x this tile's weights (the
+//      A operand straight from memory: the minibatch tile in LDS is still needed for dW1)
+//      -> evaluation slabs, flag
+__device__ __forceinline__ void mdnn_tile_eval(const MdnnArgs& p, const float* Wl, float* X,
+                                               const float* biasl, int eidx) {
+  // (laundered: nothing below may be computed ahead of the update loop and kept live in it)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wg = blockIdx.x, ks = wg % p.k_slices, nb = wg / p.k_slices;
+  const int n0 = nb * kMNB, k0 = ks * kMC;
+  const int B = p.B;
+  const int mt = w & 3, kh = w >> 2;
+  for (int pass = 0; pass < p.eval_passes; ++pass) {
+    const int rows = min(B, p.n_test - pass * B);
+    if (rows <= 0) break;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* src = p.x_test + (int64_t)(pass * B + min(mt * 32 + l31, rows - 1)) * p.ldx_test;
+    const float* bp = Wl + l31 * kMPitch + kh * 128 + 4 * h;
+    // two halves of the k range: 8 x 16 bytes of the A operand in registers at a time
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      float4 areg[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int col = k0 + kh * 128 + 64 * half + 8 * q + 4 * h;
+        float4 v = *reinterpret_cast<const float4*>(src + min((int64_t)col, p.ldx_test - 4));
+        v.x = col + 0 < p.I ? v.x : 0.f; v.y = col + 1 < p.I ? v.y : 0.f;
+        v.z = col + 2 < p.I ? v.z : 0.f; v.w = col + 3 < p.I ? v.w : 0.f;
+        areg[q] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 64 * half + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[q].w, b4.w, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();                       // X free (previous pass read)
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h)) * kMPbuf + l31] = acc[i];
+    }
+    __syncthreads();
+    if (kh == 0) {
+      const float bias = ks == 0 ? biasl[l31] : 0.f;
+      float* dst = fresh_ptr(p.eval_slabs + ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B + mt * 32 + 4 * h) * kMH + n0 + l31);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = mt * 32 + acc_row(i, h);
+        const float v = acc[i] + X[row * kMPbuf + l31] + bias;
+        if (row < rows) xwg_store(dst + acc_row0(i) * kMH, v);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0)
+    flag_raise(p.flag_eval, wg, (unsigned)eidx + 1u);
+}
+
+// ---- tile workgroups: first-layer partial products, dW1, Adam -------------------
+template <bool DP, bool FAC>
+__device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* smem) {
+  float* Fl = smem;                          // [FR][kMPitch] minibatch summaries (this k-slice)
+  float* Wl = Fl + p.FR * kMPitch;           // [32][kMPitch] weight tile (authoritative copy)
+  float* X = Wl + kMNB * kMPitch;            // scratch: forward k-halves | dz1^T
+  float* red = X + p.x_floats;               // [64]
+  float* biasl = red + 64;                   // [3][32] b1, exp_avg, exp_avg_sq (k-slice 0)
+  float* bpart = biasl + 96;                 // [16][32] partial column sums of dz1 (k-slice 0)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wg = blockIdx.x, ks = wg % p.k_slices, nb = wg / p.k_slices;
+  const int n0 = nb * kMNB, k0 = ks * kMC;
+  const int B = p.B;
+  int32_t* flagp = p.state + 2;
+  const int step0 = p.state[0];
+  double b1t = reinterpret_cast<const double*>(p.state + 12)[0];
+  double b2t = reinterpret_cast<const double*>(p.state + 12)[1];
+  float a0 = 0.f, a1 = 0.f;
+  const AdamK ak{1.0f - (float)p.beta1, (float)p.beta2, 1.0f - (float)p.beta2, p.adam_eps};
+
+  float Mr[16], Vr[16];
+  const int kcol = 32 * w + l31;
+  const bool col_ok = k0 + kcol < p.I;
+  const bool pend = DP && p.adam_pending != 0;
+  // first launch of a run_training call: a fresh optimizer (mdnn.py:203) -- the moments start
+  // at zero in the registers, nobody has to clear (or read) them in memory
+  const bool fresh = !DP && step0 == 0;
+  const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
+  const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
+  // (three passes: every load is issued before the first store of a data-parallel launch's
+  // pending Adam step -- interleaved, the possibly aliasing stores serialise the loads)
+  if (DP && p.pair_ok) {
+    // A data-parallel launch only passes through the tile here (pending Adam step, weights into
+    // LDS), and Adam is elementwise: the tile is taken as rows of 8-byte pairs (the rows of W1 are
+    // I floats apart -- 11 802 for the Ant summaries: 8-byte aligned, not 16), 512 contiguous bytes
+    // per wavefront instruction and all 32 loads of a thread in flight, instead of 64 dword loads
+    // per lane in the accumulator layout.
+    float2 Wq[8], Mq[8], Vq[8], Gq2[8];
+    const int c2 = (tid & 127) * 2, rq = tid >> 7;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t off = p.w1_off + (int64_t)(n0 + q * 4 + rq) * p.I + k0 + c2;
+      Wq[q] = Mq[q] = Vq[q] = Gq2[q] = make_float2(0.f, 0.f);
+      if (k0 + c2 < p.I) {
+        Wq[q] = *reinterpret_cast<const float2*>(p.params + off);
+        if (pend) {
+          Mq[q] = *reinterpret_cast<const float2*>(p.m1 + off);
+          Vq[q] = *reinterpret_cast<const float2*>(p.m2 + off);
+          Gq2[q] = *reinterpret_cast<const float2*>(p.grads + off);
+        }
+      }
+    }
+    if (pend) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        Wq[q].x = adam_weight(Gq2[q].x, Mq[q].x, Vq[q].x, Wq[q].x, pa0, pa1, ak);
+        Wq[q].y = adam_weight(Gq2[q].y, Mq[q].y, Vq[q].y, Wq[q].y, pa0, pa1, ak);
+      }
+      if (k0 + c2 < p.I) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int64_t off = p.w1_off + (int64_t)(n0 + q * 4 + rq) * p.I + k0 + c2;
+          *reinterpret_cast<float2*>(p.params + off) = Wq[q];
+          *reinterpret_cast<float2*>(p.m1 + off) = Mq[q];
+          *reinterpret_cast<float2*>(p.m2 + off) = Vq[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<float2*>(Wl + (q * 4 + rq) * kMPitch + c2) = Wq[q];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Mr[i] = 0.f; Vr[i] = 0.f; }
+  } else {
+    float Wv[16], Gq[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + acc_row(i, h);
+      Wv[i] = 0.f; Gq[i] = 0.f; Mr[i] = 0.f; Vr[i] = 0.f;
+      if (col_ok) {
+        const int64_t off = p.w1_off + (int64_t)n * p.I + k0 + kcol;
+        Wv[i] = p.params[off];
+        if (!fresh) { Mr[i] = p.m1[off]; Vr[i] = p.m2[off]; }
+        if (pend) Gq[i] = p.grads[off];
+      }
+    }
+    if (pend) {   // written back at once: a data-parallel launch changes the tile only here
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Wv[i] = adam_weight(Gq[i], Mr[i], Vr[i], Wv[i], pa0, pa1, ak);
+      if (col_ok) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t off = p.w1_off + (int64_t)(n0 + acc_row(i, h)) * p.I + k0 + kcol;
+          p.params[off] = Wv[i]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Wl[acc_row(i, h) * kMPitch + kcol] = Wv[i];
+  }
+  if (ks == 0 && tid < kMNB) {
+    const int64_t off = p.b1_off + n0 + tid;
+    float bw = p.params[off], bm = fresh ? 0.f : p.m1[off], bv = fresh ? 0.f : p.m2[off];
+    if (pend) {
+      bw = adam_bias(p.grads[off], bm, bv, bw, pa0, pa1, ak);
+      p.params[off] = bw; p.m1[off] = bm; p.m2[off] = bv;
+    }
+    biasl[tid] = bw; biasl[32 + tid] = bm; biasl[64 + tid] = bv;
+  }
+  for (int idx = tid; idx < (p.FR - B) * kMPitch; idx += kMT) Fl[B * kMPitch + idx] = 0.f;
+  const int DOP = p.FR + 4;
+  const int nvec = B * (kMC / 4);
+  bool bias_pending = false;
+  auto bias_step = [&](int n) {
+    float g = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMT / 32; ++q) g += bpart[q * 32 + n];
+    float bm = biasl[32 + n], bv = biasl[64 + n];
+    biasl[n] = adam_bias(g, bm, bv, biasl[n], a0, a1, ak);
+    biasl[32 + n] = bm;
+    biasl[64 + n] = bv;
+  };
+
+  if (tid == 0) red[63] = 0.f;
+  BSIG_MPF_LIST(BSIG_MPF_DECL)
+  if (p.n_updates > 0) {
+    const int64_t pf_row0 = (int64_t)step0 * B;
+    FacCols fcols{};
+    if constexpr (FAC) fcols = fac_cols(k0 + (tid & 63) * 4, p.xS, p.xA);
+    BSIG_MPF_LIST(BSIG_MPF_LOAD)
+  } else {
+    BSIG_MPF_LIST(BSIG_MPF_ZERO)
+  }
+  __syncthreads();
+
+  for (int t = 0; t < p.n_updates; ++t) {
+    int tid_l = tid, l31_l = l31, h_l = h, kcol_l = kcol;
+    asm volatile("" : "+v"(tid_l), "+v"(l31_l), "+v"(h_l), "+v"(kcol_l));
+    const int step = step0 + t;
+    const unsigned epoch = (unsigned)step + 1u;
+    if (red[63] != 0.f) break;   // time-out bit as sampled during the previous update's wait
+    BSIG_MSTAMP(0);
+    // ---- 1. summary tile -> LDS ------------------------------------------------
+    BSIG_MPF_LIST(BSIG_MPF_STORE)
+    __syncthreads();
+    BSIG_MSTAMP(1);
+
+    // ---- 2. partial forward: P[b, n] = sum_{k in slice} X[b, k] W1[n, k] ---------
+    {
+      const int mt = w & 3, kh = w >> 2;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = Fl + (mt * 32 + l31_l) * kMPitch + kh * 128 + 4 * h_l;
+      const float* bp = Wl + l31_l * kMPitch + kh * 128 + 4 * h_l;
+#pragma unroll 4
+      for (int kk = 0; kk < 128; kk += 8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      }
+      BSIG_MSTAMP(2);
+      if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h_l)) * kMPbuf + l31_l] = acc[i];
+      }
+      if (bias_pending && w == kMT / 64 - 1 && lane < kMNB) bias_step(lane);
+      bias_pending = false;
+      __syncthreads();
+      if (kh == 0) {
+        const float bias = ks == 0 ? biasl[l31_l] : 0.f;
+        float* dst = fresh_ptr(p.slabs + ((int64_t)ks * B + mt * 32 + 4 * h_l) * kMH + n0 + l31_l);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mt * 32 + acc_row(i, h_l);
+          const float v = acc[i] + X[row * kMPbuf + l31_l] + bias;
+          if (row < B) xwg_store(dst + acc_row0(i) * kMH, v);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid_l == 0)
+        flag_raise(p.flag_fwd, wg, epoch);
+      BSIG_MSTAMP(3);
+    }
+
+    // ---- while the owners work: the evaluation due after the previous update (this tile
+    //      still holds those weights), next summary tile, Adam scalars -------------------
+    if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
+      mdnn_tile_eval(p, Wl, X, biasl, mdnn_evals_before(step, p.eval_every) - 1);
+    // the time-out bit (set by any bounded poll on the chip), sampled off the critical path:
+    // tested at the top of the next update
+    if (tid_l == 0)
+      red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
+    if (t + 1 < p.n_updates) {
+      const int64_t pf_row0 = (int64_t)(step + 1) * B;
+      FacCols fcols{};
+      if constexpr (FAC) fcols = fac_cols(k0 + (tid_l & 63) * 4, p.xS, p.xA);
+      BSIG_MPF_LIST(BSIG_MPF_LOAD)
+    }
+    b1t *= p.beta1; b2t *= p.beta2;
+    a0 = (float)(p.lr / (1.0 - b1t));
+    a1 = (float)(1.0 / sqrt(1.0 - b2t));
+
+    if constexpr (FAC) {   // (diagnostics) the factor products of the next tile are in registers
+      if (p.prof) { asm volatile("" :: "v"(pf0.x), "v"(pf12.w)); BSIG_MSTAMP(8); }
+    }
+    // ---- 3. dW1 = dz1^T X on this tile, Adam ---------------------------------------
+    if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
+    __syncthreads();
+    BSIG_MSTAMP(10);
+    {
+      // [FR, 32] block of dz1, transposed into X: 16 bytes per lane, 8 lanes per row
+      const __amdgpu_buffer_rsrc_t zr = xwg_buffer(p.dz1 + n0);
+      for (int base = 0; base < p.FR * (kMNB / 4); base += kMT * 2) {
+        f32x4 q[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int idx = base + u * kMT + tid_l;
+          const int b = idx >> 3;
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          q[u] = (idx < p.FR * (kMNB / 4) && b < B) ? xwg_load4(zr, b * kMH + (idx & 7) * 4) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int idx = base + u * kMT + tid_l;
+          if (idx < p.FR * (kMNB / 4)) {
+            float* x = X + ((idx & 7) * 4) * DOP + (idx >> 3);
+            x[0] = q[u].x; x[DOP] = q[u].y; x[2 * DOP] = q[u].z; x[3 * DOP] = q[u].w;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    BSIG_MSTAMP(11);
+    if (ks == 0) {                         // b1 of this block: column sums of dz1
+      const int n = tid_l & 31, part = tid_l >> 5;
+      float g = 0.f;
+      for (int b = part; b < B; b += kMT / 32) g += X[n * DOP + b];
+      bpart[part * 32 + n] = g;
+    }
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = X + l31_l * DOP + 4 * h_l;
+      const float* bp = Fl + (4 * h_l) * kMPitch + kcol_l;
+      for (int bb = 0; bb < p.FR; bb += 8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + bb);
+        const float f0 = bp[(bb + 0) * kMPitch], f1 = bp[(bb + 1) * kMPitch];
+        const float f2 = bp[(bb + 2) * kMPitch], f3 = bp[(bb + 3) * kMPitch];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, f0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, f1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, f2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, f3, acc, 0, 0, 0);
+      }
+      if (DP) {
+        // this rank's share of the gradient: summed over the ranks by the caller
+        if (k0 + kcol_l < p.I) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            p.grads[p.w1_off + (int64_t)(n0 + acc_row(i, h_l)) * p.I + k0 + kcol_l] = acc[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float* wp = Wl + acc_row(i, h_l) * kMPitch + kcol_l;
+          *wp = adam_weight(acc[i], Mr[i], Vr[i], *wp, a0, a1, ak);
+        }
+      }
+    }
+    bias_pending = ks == 0 && !DP;
+    __syncthreads();
+    if (DP && ks == 0 && tid_l < kMNB) {
+      float g = 0.f;
+#pragma unroll
+      for (int q = 0; q < kMT / 32; ++q) g += bpart[q * 32 + tid_l];
+      p.grads[p.b1_off + n0 + tid_l] = g;
+    }
+    BSIG_MSTAMP(12);
+  }
+
+  // ---- the evaluation after the last update of the call ------------------------------
+  // (a data-parallel rank: in the launch that only takes the pending Adam step of that update)
+  if (p.do_eval && step0 + p.n_updates == p.n_total && (!DP || p.n_updates == 0)) {
+    if (bias_pending && tid < kMNB) bias_step(tid);
+    bias_pending = false;
+    __syncthreads();
+    mdnn_tile_eval(p, Wl, X, biasl, mdnn_evals_before(p.n_total - 1, p.eval_every));
+  }
+  // ---- write the tile back, advance the engine state ---------------------------
+  if (col_ok && !DP) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + acc_row(i, h);
+      const int64_t off = p.w1_off + (int64_t)n * p.I + k0 + kcol;
+      p.params[off] = Wl[acc_row(i, h) * kMPitch + kcol]; p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+    }
+  }
+  if (bias_pending && tid < kMNB) bias_step(tid);
+  if (!DP && ks == 0 && tid < kMNB) {
+    p.params[p.b1_off + n0 + tid] = biasl[tid];
+    p.m1[p.b1_off + n0 + tid] = biasl[32 + tid];
+    p.m2[p.b1_off + n0 + tid] = biasl[64 + tid];
+  }
+  if (wg == 0 && tid == 0 && p.n_updates > 0) {
+    int32_t* st = p.state;
+    reinterpret_cast<double*>(st + 12)[0] = b1t;
+    reinterpret_cast<double*>(st + 12)[1] = b2t;
+    reinterpret_cast<float*>(st)[4] = a0;
+    reinterpret_cast<float*>(st)[5] = a1;
+    // (one jitter stream per update and per evaluation, in program order)
+    int n_ev = 0;
+    if (p.do_eval) {
+      n_ev = mdnn_evals_before(step0 + p.n_updates, p.eval_every) - mdnn_evals_before(step0, p.eval_every);
+      if (!DP && step0 + p.n_updates == p.n_total && (p.n_total - 1) % p.eval_every != 0) ++n_ev;
+    }
+    reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)(p.n_updates + n_ev);
+    st[0] = step0 + p.n_updates;
+  }
+}
+
+// ---- small-weight workgroups: 32 rows of W2 or of the head matrix ----------------
+template <bool DP, bool WIDE>
+__device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* smem) {
+  float* Hs = smem;                          // [FR][kMHP] input activations of the layer
+  float* X = Hs + p.FR * kMHP;               // [32][FR + 4] output gradients, transposed
+  float* red = X + kMNB * (p.FR + 4);        // [64]
+  float* Wb = red + 64;                      // wide heads: [32][kMHP] this block's weights, operand order
+  float* Xo = Wb + kMNB * kMHP;              // ... [128][33] k-half exchange of the head-output product
+  float* bsh = Xo + 128 * kMPbuf;            // ... [32] this block's biases
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int sb = blockIdx.x - p.G1 - p.n_owner;
+  const bool is_w2 = sb < kMH / kMNB;
+  const int n0 = (is_w2 ? sb : sb - kMH / kMNB) * kMNB;
+  const int nrows = is_w2 ? kMH : p.Nh;
+  const int64_t w_off = is_w2 ? p.w2_off : p.wh_off, b_off = is_w2 ? p.b2_off : p.bh_off;
+  const float* dsrc = is_w2 ? p.dz2 : p.d_out;
+  const int dpitch = is_w2 ? kMH : p.NhP;
+  const float* hsrc = is_w2 ? p.h1 : p.h2;
+  const int B = p.B, DOP = p.FR + 4;
+  const bool whead = WIDE && !is_w2;         // forms head outputs / d_out Wh for all rows (MdnnArgs)
+  const int hb = sb - kMH / kMNB;
+  int32_t* flagp = p.state + 2;
+  const int step0 = p.state[0];
+  double b1t = reinterpret_cast<const double*>(p.state + 12)[0];
+  double b2t = reinterpret_cast<const double*>(p.state + 12)[1];
+  const AdamK ak{1.0f - (float)p.beta1, (float)p.beta2, 1.0f - (float)p.beta2, p.adam_eps};
+
+  const bool pend = DP && p.adam_pending != 0;
+  const bool fresh = !DP && step0 == 0;      // fresh optimizer: the moments start at zero
+  const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
+  const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
+  // waves 0-3: element i of lane (h, l31) of wave w <-> W[n0 + acc_row(i, h)][32w + l31]
+  float Wr[16], Mr[16], Vr[16];
+  const int kcol = 32 * (w & 3) + l31;
+  {
+    float Gq[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + acc_row(i, h);
+      Wr[i] = 0.f; Mr[i] = 0.f; Vr[i] = 0.f; Gq[i] = 0.f;
+      if (w < 4 && n < nrows) {
+        const int64_t off = w_off + (int64_t)n * kMH + kcol;
+        Wr[i] = p.params[off];
+        if (!fresh) { Mr[i] = p.m1[off]; Vr[i] = p.m2[off]; }
+        if (pend) Gq[i] = p.grads[off];
+      }
+    }
+    if (pend) {   // (all loads before the first store: see the tile workgroups)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + acc_row(i, h);
+        if (w < 4 && n < nrows) {
+          const int64_t off = w_off + (int64_t)n * kMH + kcol;
+          Wr[i] = adam_weight(Gq[i], Mr[i], Vr[i], Wr[i], pa0, pa1, ak);
+          xwg_store(p.params + off, Wr[i]); p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+        }
+      }
+    }
+  }
+  // the owners' operand-order copies of W2 (see MdnnArgs)
+  auto publish_w2 = [&](int i, int h, int kcol, int for_step) {
+    const int n = n0 + acc_row(i, h);
+    const int lf = ((kcol >> 2) & 3) * 16 + (n & 15), lb = ((n >> 2) & 3) * 16 + (kcol & 15);
+    const int par = (for_step & 1) * (kMH * kMH);
+    xwg_store(p.w2f_pack + par + ((((n >> 4) * 8 + (kcol >> 4)) * 2 + ((kcol >> 1) & 1)) * 64 + lf) * 2 + (kcol & 1), Wr[i]);
+    xwg_store(p.w2b_pack + par + ((((kcol >> 4) * 8 + (n >> 4)) * 2 + ((n >> 1) & 1)) * 64 + lb) * 2 + (n & 1), Wr[i]);
+  };
+  if (is_w2 && w < 4) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) publish_w2(i, h, kcol, step0);
+  }
+  // wave 4, lanes 0-31: the 32 biases
+  const bool bias_lane = w == 4 && lane < kMNB && n0 + lane < nrows;
+  float bw = 0.f, bm = 0.f, bv = 0.f;
+  if (bias_lane) {
+    const int64_t off = b_off + n0 + lane;
+    bw = p.params[off];
+    if (!fresh) { bm = p.m1[off]; bv = p.m2[off]; }
+    if (pend) {
+      bw = adam_bias(p.grads[off], bm, bv, bw, pa0, pa1, ak);
+      xwg_store(p.params + off, bw); p.m1[off] = bm; p.m2[off] = bv;
+    }
+  }
+#define BSIG_REFRESH_OPERAND_COPY()                                                        \
+  if constexpr (WIDE) {                                                                     \
+    if (whead && w < 4) {                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) Wb[acc_row(i, h) * kMHP + kcol] = Wr[i]; \
+    } else if (whead && w == 4 && lane < kMNB) {                                            \
+      bsh[lane] = bw;                                                                       \
+    }                                                                                       \
+  }
+  BSIG_REFRESH_OPERAND_COPY()
+  // the weights as of the start of this launch are out (owners wait for every block)
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0)
+    flag_raise(p.flag_pack, sb, p.launch_tag);
+  for (int idx = tid; idx < (p.FR - B) * kMHP; idx += kMT) Hs[B * kMHP + idx] = 0.f;
+  __syncthreads();
+
+  for (int t = 0; t < p.n_updates; ++t) {
+    const int step = step0 + t;
+    const unsigned epoch = (unsigned)step + 1u;
+    if (run_aborted(flagp, red, tid)) break;
+    b1t *= p.beta1; b2t *= p.beta2;
+    const float a0 = (float)(p.lr / (1.0 - b1t));
+    const float a1 = (float)(1.0 / sqrt(1.0 - b2t));
+    BSIG_MSTAMP(0);
+#define BSIG_LOAD_ACTIVATIONS() /* [B, 128], 16-byte loads */                                  \
+    {                                                                                           \
+      const __amdgpu_buffer_rsrc_t hr = xwg_buffer(hsrc);                                       \
+      for (int base = 0; base < B * (kMH / 4); base += kMT * 4) {                               \
+        f32x4 q[4];                                                                             \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+          const int idx = min(base + u * kMT + tid, B * (kMH / 4) - 1);                         \
+          q[u] = xwg_load4(hr, (idx >> 5) * kMH + (idx & 31) * 4);                              \
+        }                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+          const int idx = base + u * kMT + tid;                                                 \
+          if (idx < B * (kMH / 4))                                                              \
+            *reinterpret_cast<f32x4*>(Hs + (idx >> 5) * kMHP + (idx & 31) * 4) = q[u];          \
+        }                                                                                       \
+      }                                                                                         \
+    }
+#define BSIG_LOAD_GRADIENT_BLOCK() /* this block's gradient columns [B, 32], transposed */      \
+    {                                                                                           \
+      const __amdgpu_buffer_rsrc_t gr = xwg_buffer(dsrc);                                       \
+      for (int base = 0; base < p.FR * (kMNB / 4); base += kMT * 2) {                           \
+        f32x4 q[2];                                                                             \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                         \
+          const int idx = base + u * kMT + tid;                                                 \
+          const int b = idx >> 3, n = n0 + (idx & 7) * 4;                                       \
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};                                              \
+          q[u] = (idx < p.FR * (kMNB / 4) && b < B && n < nrows) ? xwg_load4(gr, b * dpitch + n) : zero; \
+        }                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                         \
+          const int idx = base + u * kMT + tid;                                                 \
+          if (idx < p.FR * (kMNB / 4)) {                                                        \
+            const int n = n0 + (idx & 7) * 4;                                                   \
+            float* x = X + ((idx & 7) * 4) * DOP + (idx >> 3);                                  \
+            x[0] = n < nrows ? q[u].x : 0.f; x[DOP] = n + 1 < nrows ? q[u].y : 0.f;            \
+            x[2 * DOP] = n + 2 < nrows ? q[u].z : 0.f; x[3 * DOP] = n + 3 < nrows ? q[u].w : 0.f; \
+          }                                                                                     \
+        }                                                                                       \
+      }                                                                                         \
+    }
+    if (WIDE && whead) {
+      // ---- wide heads: head outputs of ALL minibatch rows for this block's 32 columns ------
+      if (w == 0) flags_wait(p.flag_h2, p.n_owner, epoch, lane, flagp);
+      __syncthreads();
+      BSIG_MSTAMP(7);
+      BSIG_LOAD_ACTIVATIONS()
+      __syncthreads();
+      BSIG_MSTAMP(8);
+      {
+        const int mt = w & 3, kh = w >> 2;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* ap = Hs + (mt * 32 + l31) * kMHP + kh * 64 + 4 * h;
+        const float* bp = Wb + l31 * kMHP + kh * 64 + 4 * h;
+#pragma unroll 4
+        for (int kk = 0; kk < 64; kk += 8) {
+          const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
+          const float4 b4 = *reinterpret_cast<const float4*>(bp + kk);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        BSIG_MSTAMP(1);
+        if (kh == 1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Xo[(mt * 32 + acc_row(i, h)) * kMPbuf + l31] = acc[i];
+        }
+        __syncthreads();
+        BSIG_MSTAMP(2);
+        if (kh == 0) {
+          const float bias = bsh[l31];
+          // block-major: [n_hb][B][32]
+          float* dst = fresh_ptr(p.o_wide + ((int64_t)hb * B + mt * 32 + 4 * h) * kMNB + l31);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = mt * 32 + acc_row(i, h);
+            if (row < B) xwg_store(dst + acc_row0(i) * kMNB, acc[i] + Xo[row * kMPbuf + l31] + bias);
+          }
+        }
+        BSIG_MSTAMP(11);
+        __builtin_amdgcn_s_waitcnt(0);
+        BSIG_MSTAMP(3);
+        __syncthreads();
+        if (tid == 0) flag_raise(p.flag_o, hb, epoch);
+        BSIG_MSTAMP(9);
+      }
+      // ---- ... and this block's share of d_out Wh (with the weights of this update's forward)
+      if (w == 0) flags_wait(p.flag_dout, p.n_owner, epoch, lane, flagp);
+      __syncthreads();
+      BSIG_MSTAMP(4);
+      BSIG_LOAD_GRADIENT_BLOCK()
+      __syncthreads();
+      {
+        const int mt = w & 3, ih = w >> 2;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const int col = (2 * ih + jt) * 32 + l31;
+          f32x16 acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+          for (int g8 = 0; g8 < 4; ++g8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = 8 * g8 + 4 * h + e;
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[k * DOP + mt * 32 + l31], Wb[k * kMHP + col],
+                                                         acc, 0, 0, 0);
+            }
+          }
+          float* dst = fresh_ptr(p.dz2_part + ((int64_t)hb * B + mt * 32 + 4 * h) * kMH + col);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = mt * 32 + acc_row(i, h);
+            if (row < B) xwg_store(dst + acc_row0(i) * kMH, acc[i]);
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) flag_raise(p.flag_dz2, hb, epoch);
+        BSIG_MSTAMP(10);
+      }
+    } else {
+      if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
+      __syncthreads();
+      BSIG_MSTAMP(4);
+      BSIG_LOAD_ACTIVATIONS()
+      BSIG_LOAD_GRADIENT_BLOCK()
+    }
+    __syncthreads();
+    BSIG_MSTAMP(5);
+    if (w < 4) {
+      // (laundered: the 48 store addresses below are recomputed per update, not kept live)
+      int h_l = h, kcol_l = kcol;
+      asm volatile("" : "+v"(h_l), "+v"(kcol_l));
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = X + l31 * DOP + 4 * h;
+      const float* bp = Hs + (4 * h) * kMHP + kcol;
+      for (int bb = 0; bb < p.FR; bb += 8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + bb);
+        const float f0 = bp[(bb + 0) * kMHP], f1 = bp[(bb + 1) * kMHP];
+        const float f2 = bp[(bb + 2) * kMHP], f3 = bp[(bb + 3) * kMHP];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, f0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, f1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, f2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, f3, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + acc_row(i, h_l);
+        if (DP) {
+          if (n < nrows) p.grads[w_off + (int64_t)n * kMH + kcol_l] = acc[i];
+        } else {
+          Wr[i] = adam_weight(acc[i], Mr[i], Vr[i], Wr[i], a0, a1, ak);
+          if (n < nrows) xwg_store(p.params + w_off + (int64_t)n * kMH + kcol_l, Wr[i]);
+          if (is_w2) publish_w2(i, h_l, kcol_l, step + 1);
+        }
+      }
+    } else if (bias_lane) {
+      float g = 0.f;
+      for (int b = 0; b < B; ++b) g += X[lane * DOP + b];
+      if (DP) {
+        p.grads[b_off + n0 + lane] = g;
+      } else {
+        bw = adam_bias(g, bm, bv, bw, a0, a1, ak);
+        xwg_store(p.params + b_off + n0 + lane, bw);
+      }
+    }
+    if (!DP) {
+      BSIG_REFRESH_OPERAND_COPY()   // (all reads of the old copy are behind the barrier above)
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid == 0)
+        flag_raise(p.flag_small, sb, epoch);
+    }
+    BSIG_MSTAMP(6);
+  }
+  if (!DP) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + acc_row(i, h);
+      if (w < 4 && n < nrows) {
+        const int64_t off = w_off + (int64_t)n * kMH + kcol;
+        p.m1[off] = Mr[i]; p.m2[off] = Vr[i];
+      }
+    }
+    if (bias_lane) { p.m1[b_off + n0 + lane] = bm; p.m2[b_off + n0 + lane] = bv; }
+  }
+}
+
+// ---- row-owner workgroups: layers 2.., NLL forward / backward ---------------------
+// FULL: full covariance (one lane per component runs the triangular solves: full_row)
+// A row owner's sum over the k-slices of its rows' layer-1 partial products: slabs [k_slices][B][128];
+// item = (row, column quad), kSumSub threads share an item's slices (16-byte loads, all in flight),
+// their partial sums meet in a fixed order through `part` ([kSumSub - 1][kSumItems] quads of LDS).
+// Returns the item's sum to the threads tid < kSumItems.  Ends on a workgroup barrier.
+constexpr int kSumItems = kMR * (kMH / 4), kSumSub = kMT / kSumItems, kSumFlight = 12;
+__device__ __forceinline__ f32x4 slab_quads_sum(const float* slabs, int k_slices, int zs, int row, int tid,
+                                                float* part) {
+  const int item = tid & (kSumItems - 1), sub = tid / kSumItems;
+  const int c4 = (item & 31) * 4;
+  const __amdgpu_buffer_rsrc_t sr = xwg_buffer(slabs);
+  const int per = ceil_div(k_slices, kSumSub);
+  const int z_lo = sub * per, z_hi = min(z_lo + per, k_slices);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int z = z_lo; z < z_hi; z += kSumFlight) {
+    f32x4 q[kSumFlight];
+#pragma unroll
+    for (int u = 0; u < kSumFlight; ++u) q[u] = xwg_load4(sr, min(z + u, z_hi - 1) * zs + row * kMH + c4);
+#pragma unroll
+    for (int u = 0; u < kSumFlight; ++u)
+      if (z + u < z_hi) v += q[u];
+  }
+  if (sub > 0) *reinterpret_cast<f32x4*>(part + ((sub - 1) * kSumItems + item) * 4) = v;
+  __syncthreads();
+  if (sub == 0) {
+#pragma unroll
+    for (int q = 1; q < kSumSub; ++q) v += *reinterpret_cast<const f32x4*>(part + ((q - 1) * kSumItems + item) * 4);
+  }
+  return v;
+}
+
+template <bool DP, bool WIDE, bool FULL>
+__device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
+  const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
+  const int po = Nh16 + 4;                   // pitch of a head-output row
+  const int per_wave = D + 3 * K + (FULL ? 3 * DK : 0);
+  float* Whs = smem;                         // [Nh16][128], element (n, i) at n*128 + (i ^ 4(n & 15))
+  float* H1s = Whs + (WIDE ? 0 : Nh16 * kMH);   // [kMR][kMHP]  (wide heads: no head matrix here)
+  float* H2s = H1s + kMR * kMHP;             // [kMR][kMHP]  h2, later dz2 in place
+  float* Os = H2s + kMR * kMHP;              // [kMR][po]    head outputs, later d_out in place
+  float* b2s = Os + kMR * po;                // [128]
+  float* bhs = b2s + kMH;                    // [Nh16]
+  float* wsc = bhs + Nh16;                   // [kMR][D + 3K] per-row scratch of diag_row
+  float* red = wsc + kMR * per_wave;         // [64]
+  float* part4 = red + 64;                   // [(kSumSub - 1) * kSumItems * 4]  partial k-slice sums
+  const int tid_0 = threadIdx.x, w_0 = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
+  const int c16_0 = tid_0 & 15, g_0 = (tid_0 & 63) >> 4;
+  const int o = blockIdx.x - p.G1;
+  const int r0 = o * kMR;
+  int32_t* flagp = p.state + 2;
+  const int step0 = p.state[0];
+  const uint64_t rng_seed = reinterpret_cast<const uint64_t*>(p.state + 8)[0];
+  const uint64_t rng_ctr0 = reinterpret_cast<const uint64_t*>(p.state + 8)[1];
+  HeadArgs a{};
+  a.D = D; a.K = K; a.Nh = Nh; a.batch = B; a.from_tuple = 0;
+  a.Ls = FULL ? D * (D - 1) / 2 : 0;
+  a.min_w = p.min_w; a.ll_limit = p.ll_limit; a.inv_norm = p.inv_norm;
+  a.eps_noise = p.eps_noise; a.seed = rng_seed; a.d_out = p.d_out;
+  const float norm = (float)B * (float)DK;
+  // (wave w <-> minibatch row r0 + w in the row-wise phases)
+  const float* Wh = p.params + p.wh_off;
+  const int64_t zs = (int64_t)B * kMH;
+  // W2 is the B operand of two products, one column block of 16 per wave, straight
+  // from registers: w2f[4t + j] = W2[16w + c16][16t + 4g + j] (forward, fetched under the
+  // k-slice sum), w2b[4t + j] = W2[16t + 4g + j][16w + c16] (backward, fetched under the
+  // wait for the other owners' rows)
+
+
+  // ---- held-out evaluation number eidx (jitter stream `stream`), forward only: per pass,
+  //      this owner's 4 rows of the pass go through layers 2.. (the weights in LDS / the
+  //      W2 pack are the evaluated ones); head outputs are parked in memory until the
+  //      batch-wide sum of exp(pre) is known, then one wavefront per row takes the NLL
+  auto owner_eval = [&](int eidx, uint64_t stream, int step, bool refresh) {
+    int c16 = c16_0, g = g_0, tid = tid_0;
+    const int w = w_0;
+    asm volatile("" : "+v"(c16), "+v"(g), "+v"(tid));
+    const int lane = tid & 63, rowA = c16 & (kMR - 1);
+    const unsigned etag = (unsigned)eidx + 1u;
+    float* tile = Os + (w & (kMR - 1)) * po;
+    float* yv = wsc + (w & (kMR - 1)) * per_wave;
+    float* rk = yv + D;
+    float* lpk = rk + K;
+    float* dlg = lpk + K;
+    if (refresh) {
+      // after the last update of the call: the head matrix and the biases in LDS are those
+      // of that update -- fetch what its Adam step published
+      // (a data-parallel rank has them behind flag_pack, waited for at the top)
+      if (!DP && w == 0) flags_wait(p.flag_small, p.n_small, (unsigned)step, lane, flagp);
+      __syncthreads();
+      const __amdgpu_buffer_rsrc_t whr = xwg_buffer(Wh);
+      for (int idx = tid; idx < Nh16 * (kMH / 4); idx += kMT) {
+        const int n = idx >> 5, c4 = (idx & 31) * 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Whs + n * kMH + (c4 ^ (4 * (n & 15)))) = n < Nh ? xwg_load4(whr, n * kMH + c4) : zero;
+      }
+      if (tid < kMH) b2s[tid] = xwg_load(p.params + p.b2_off + tid);
+      for (int j = tid; j < Nh16; j += kMT) bhs[j] = j < Nh ? xwg_load(p.params + p.bh_off + j) : 0.f;
+    }
+    if (w == 0) flags_wait(p.flag_eval, p.G1, etag, lane, flagp);
+    __syncthreads();
+    float w2f[32];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const float* src = p.w2f_pack + (step & 1) * (kMH * kMH) + (((w * 8 + tt) * 2) * 64 + lane) * 2;
+      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);
+      w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y;
+    }
+    float eacc = 0.f;
+    for (int gp = 0; gp < p.eval_passes; ++gp) {
+      const float* slabs = p.eval_slabs + (((int64_t)(eidx & 1) * p.eval_passes + gp) * p.k_slices) * zs;
+      {
+        const f32x4 v = slab_quads_sum(slabs, p.k_slices, (int)zs, min(r0 + (tid >> 5 & (kMR - 1)), B - 1), tid, part4);
+        if (tid < kSumItems) {
+          const int r = tid >> 5, c4 = (tid & 31) * 4;
+          const bool ok = r0 + r < B && gp * B + r0 + r < p.n_test;
+          float* hl = H1s + r * kMHP + c4;
+          hl[0] = ok ? tanhf(v.x) : 0.f; hl[1] = ok ? tanhf(v.y) : 0.f;
+          hl[2] = ok ? tanhf(v.z) : 0.f; hl[3] = ok ? tanhf(v.w) : 0.f;
+        }
+      }
+      __syncthreads();
+      {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = H1s + rowA * kMHP + 4 * g;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+          acc = mfma16(a4.x, w2f[4 * tt + 0], acc);
+          acc = mfma16(a4.y, w2f[4 * tt + 1], acc);
+          acc = mfma16(a4.z, w2f[4 * tt + 2], acc);
+          acc = mfma16(a4.w, w2f[4 * tt + 3], acc);
+        }
+        if (4 * g < kMR) {
+          const int n = 16 * w + c16;
+          const float bias = b2s[n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * kMHP + n] = tanhf(acc[r] + bias);
+        }
+      }
+      __syncthreads();
+      for (int cb = w; cb * 16 < Nh16; cb += 8) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int n = 16 * cb + c16;
+        const float* ap = H2s + rowA * kMHP + 4 * g;
+        const float* bp = Whs + n * kMH;
+        const int sw = 4 * c16;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+          const float4 b4 = *reinterpret_cast<const float4*>(bp + ((16 * tt + 4 * g) ^ sw));
+          acc = mfma16(a4.x, b4.x, acc);
+          acc = mfma16(a4.y, b4.y, acc);
+          acc = mfma16(a4.z, b4.z, acc);
+          acc = mfma16(a4.w, b4.w, acc);
+        }
+        if (4 * g < kMR) {
+          const float bias = bhs[n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * g + r;
+            const float v = acc[r] + bias;
+            Os[rr * po + n] = v;
+            if (r0 + rr < B && gp * B + r0 + rr < p.n_test && n >= K + DK && n < K + 2 * DK) eacc += expf(v);
+          }
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < kMR * Nh; idx += kMT) {
+        const int r = idx / Nh, j = idx - r * Nh;
+        const int erow = gp * B + r0 + r;
+        if (r0 + r < B && erow < p.n_test) xwg_store(p.eval_out + (int64_t)erow * p.NhP + j, Os[r * po + j]);
+      }
+      __syncthreads();
+    }
+    eacc = wave_sum_dpp(eacc);
+    if (lane == 0) red[w] = eacc;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+      float sx = 0.f;
+      for (int q = 0; q < kMT / 64; ++q) sx += red[q];
+      granule_publish(p.gran_eval, o, etag, sx);
+    }
+    HeadArgs ae = a;
+    ae.d_out = nullptr;                      // forward only
+    ae.batch = p.n_test;
+    ae.stream_id = stream;
+    float lse_acc = 0.f;
+    bool bad = false;
+    for (int gp = 0; gp < p.eval_passes; ++gp) {
+      for (int idx = tid; idx < kMR * Nh; idx += kMT) {
+        const int r = idx / Nh, j = idx - r * Nh;
+        const int erow = gp * B + r0 + r;
+        Os[r * po + j] = (r0 + r < B && erow < p.n_test) ? xwg_load(p.eval_out + (int64_t)erow * p.NhP + j) : 0.f;
+      }
+      const int erow = gp * B + r0 + w;
+      const bool act = w < kMR && r0 + w < B && erow < p.n_test;
+      if (act)
+        for (int j = lane; j < D; j += 64) yv[j] = p.y_test[(int64_t)erow * p.ldy_test + j];
+      __syncthreads();
+      if (w < kMR) {
+        RowOut ro;
+        ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
+#pragma unroll
+        for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
+        auto eval_eps = [&] {
+          return p.eps_noise != 0.f
+                     ? p.eps_noise * (granule_gather(p.gran_eval, p.n_owner, etag, lane, flagp) /
+                                      ((float)p.n_test * (float)DK))
+                     : 0.f;
+        };
+        if constexpr (FULL) full_row(ae, erow, act, lane, tile, yv, rk, dlg, dlg + K, eval_eps, ro);
+        else diag_row(ae, erow, act, lane, tile, yv, rk, lpk, dlg, eval_eps, ro);
+        if (act) lse_acc += ro.lse;
+        bad |= ro.bad;
+      }
+      __syncthreads();
+    }
+    if (lane == 0) red[16 + w] = lse_acc;
+    __syncthreads();
+    if (tid == 0) {
+      float sl = 0.f;
+      for (int q = 0; q < kMR; ++q) sl += red[16 + q];
+      granule_publish(p.gran_eval + kGranArr, o, etag, sl);
+    }
+    if (o == 0 && w == 0) {
+      const float sum = granule_gather(p.gran_eval + kGranArr, p.n_owner, etag, lane, flagp);
+      if (lane == 0) {
+        const float l = -sum / (float)p.n_test;
+        p.test_loss[p.state[1]] = l;
+        p.state[1] = p.state[1] + 1;
+        if (!isfinite(l)) atomicOr(flagp, 1);
+      }
+    }
+    if (bad) atomicOr(flagp, 1);
+    __syncthreads();
+  };
+  const int ev0 = p.do_eval ? mdnn_evals_before(step0, p.eval_every) : 0;
+
+  if (w_0 == 0) flags_wait(p.flag_pack, p.n_small, p.launch_tag, tid_0 & 63, flagp);
+  __syncthreads();
+  for (int t = 0; t < p.n_updates; ++t) {
+    // lane-derived indices are laundered once per update so that the address
+    // arithmetic built on them is recomputed, not kept live across the update loop
+    int c16 = c16_0, g = g_0, w = w_0, tid = tid_0;
+    asm volatile("" : "+v"(c16), "+v"(g), "+v"(tid));
+    asm volatile("" : "+s"(w));
+    const int lane = tid & 63, rowA = c16 & (kMR - 1);
+    const int row = r0 + w;
+    const bool active = w < kMR && row < B;
+    float* tile = Os + (w & (kMR - 1)) * po;
+    float* yv = wsc + (w & (kMR - 1)) * per_wave;
+    float* rk = yv + D;
+    float* lpk = rk + K;
+    float* dlg = lpk + K;
+    const int step = step0 + t;
+    const unsigned epoch = (unsigned)step + 1u;
+    const uint32_t tag = epoch * 4u;
+    if (run_aborted(flagp, red, tid)) break;
+    BSIG_MSTAMP(0);
+    // ---- weights of this update (written by the small-weight workgroups) ---------
+    // (first update of a launch, and the only one of a data-parallel launch: flag_pack above)
+    // (wide heads: the owners only need W2 / b2 -- the first four small-weight workgroups)
+    if (active) {      // target row: two dependent loads, issued before the wait instead of after the weights
+      const int64_t yrow = p.ids[(int64_t)step * B + row];
+      for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
+    }
+    if (!DP && t > 0 && w == 0)
+      flags_wait(p.flag_small, WIDE ? kMH / kMNB : p.n_small, epoch - 1u, lane, flagp);
+    __syncthreads();
+    BSIG_MSTAMP(4);
+    // The head matrix refresh sits on the owners' critical path (a CU pulls ~40 GB/s through
+    // cache-bypassing loads, tools/micro/fanout_bench.hip: 73 KB of a 144-row matrix = 2 us), and the
+    // first-layer flags have usually been up for a while when it ends: wavefront 0 polls them while
+    // wavefronts 1..7 fetch (kWhFlight 16-byte loads in flight per thread).
+    // (this wavefront's W2 operand registers ride in the same window)
+    float w2f[32];
+#define BSIG_LOAD_W2F()                                                                        \
+    _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) {                                          \
+      const float* src = p.w2f_pack + (step & 1) * (kMH * kMH) + (((w * 8 + tt) * 2) * 64 + lane) * 2; \
+      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);                              \
+      w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y; \
+    }
+    if (w == 0) {
+      flags_wait(p.o_flags, p.G1, epoch, lane, flagp);
+      BSIG_LOAD_W2F()
+    } else {
+      BSIG_LOAD_W2F()
+      constexpr int kWhFlight = 11, kFetch = kMT - 64;
+      const int ft = tid - 64;
+      const __amdgpu_buffer_rsrc_t whr = xwg_buffer(Wh);
+      for (int base = 0; base < (WIDE ? 0 : Nh16 * (kMH / 4)); base += kFetch * kWhFlight) {
+        f32x4 q[kWhFlight];
+#pragma unroll
+        for (int u = 0; u < kWhFlight; ++u) {
+          const int idx = base + u * kFetch + ft;
+          const int n = idx >> 5;
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          q[u] = n < Nh ? xwg_load4(whr, n * kMH + (idx & 31) * 4) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < kWhFlight; ++u) {
+          const int idx = base + u * kFetch + ft;
+          const int n = idx >> 5, c4 = (idx & 31) * 4;
+          if (n < Nh16) *reinterpret_cast<f32x4*>(Whs + n * kMH + (c4 ^ (4 * (n & 15)))) = q[u];
+        }
+      }
+      if (ft < kMH) b2s[ft] = xwg_load(p.params + p.b2_off + ft);
+      for (int j = ft; j < Nh16; j += kFetch) bhs[j] = j < Nh ? xwg_load(p.params + p.bh_off + j) : 0.f;
+    }
+    // ---- h1 = tanh(sum of the k-slices) (b1 rides on slice 0) -----------------------
+    BSIG_MSTAMP(5);
+    __syncthreads();
+    BSIG_MSTAMP(6);
+    {
+      // (row, column pair) items; kSub threads share an item's k-slices, their partial
+      // sums are combined in a fixed order through LDS
+      const f32x4 v = slab_quads_sum(p.o_slabs, p.o_k_slices, (int)zs, min(r0 + (tid >> 5 & (kMR - 1)), B - 1), tid, part4);
+      if (tid < kSumItems) {
+        const int r = tid >> 5, c4 = (tid & 31) * 4;
+        const bool ok = r0 + r < B;
+        const float h0 = ok ? tanhf(v.x) : 0.f, h1v = ok ? tanhf(v.y) : 0.f;
+        const float h2v = ok ? tanhf(v.z) : 0.f, h3 = ok ? tanhf(v.w) : 0.f;
+        float* hl = H1s + r * kMHP + c4;
+        hl[0] = h0; hl[1] = h1v; hl[2] = h2v; hl[3] = h3;
+        if (ok) xwg_store4(xwg_buffer(p.h1), (r0 + r) * kMH + c4, h0, h1v, h2v, h3);
+      }
+    }
+    __syncthreads();
+    BSIG_MSTAMP(7);
+    // ---- h2 = tanh(h1 W2^T + b2): wave w -> columns 16w .. 16w+15 -------------------
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* ap = H1s + rowA * kMHP + 4 * g;
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+        acc = mfma16(a4.x, w2f[4 * tt + 0], acc);
+        acc = mfma16(a4.y, w2f[4 * tt + 1], acc);
+        acc = mfma16(a4.z, w2f[4 * tt + 2], acc);
+        acc = mfma16(a4.w, w2f[4 * tt + 3], acc);
+      }
+      if (4 * g < kMR) {
+        const int n = 16 * w + c16;
+        const float bias = b2s[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * g + r;
+          const float v = tanhf(acc[r] + bias);
+          H2s[rr * kMHP + n] = v;
+          if (r0 + rr < B) xwg_store(p.h2 + (int64_t)(r0 + rr) * kMH + n, v);
+        }
+      }
+    }
+    if constexpr (WIDE) __builtin_amdgcn_s_waitcnt(0);   // h2 rows are out before the flag
+    __syncthreads();
+    BSIG_MSTAMP(8);
+    float eacc = 0.f;
+    if constexpr (WIDE) {
+      // ---- wide heads: the head-block workgroups form h2 Wh^T + bh for all rows ------------
+      if (tid == 0) flag_raise(p.flag_h2, o, epoch);
+      if (w == 0) flags_wait(p.flag_o, p.n_hb, epoch, lane, flagp);
+      __syncthreads();
+      for (int idx = tid; idx < kMR * Nh16; idx += kMT) {
+        const int r = idx / Nh16, j = idx - r * Nh16;
+        const bool ok = j < Nh && r0 + r < B;
+        const float v = ok ? xwg_load(p.o_wide + ((int64_t)(j >> 5) * B + r0 + r) * kMNB + (j & 31)) : 0.f;
+        Os[r * po + j] = v;
+        if (ok && j >= K + DK && j < K + 2 * DK) eacc += expf(v);
+      }
+    }
+    // ---- head outputs = h2 Wh^T + bh: column blocks w, w+8, w+16 -----------------------
+    for (int cb = w; !WIDE && cb * 16 < Nh16; cb += 8) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int n = 16 * cb + c16;
+      const float* ap = H2s + rowA * kMHP + 4 * g;
+      const float* bp = Whs + n * kMH;
+      const int sw = 4 * c16;                      // = 4 * (n & 15)
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + ((16 * tt + 4 * g) ^ sw));
+        acc = mfma16(a4.x, b4.x, acc);
+        acc = mfma16(a4.y, b4.y, acc);
+        acc = mfma16(a4.z, b4.z, acc);
+        acc = mfma16(a4.w, b4.w, acc);
+      }
+      if (4 * g < kMR) {
+        const float bias = bhs[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * g + r;
+          const float v = acc[r] + bias;
+          Os[rr * po + n] = v;
+          if (r0 + rr < B && n >= K + DK && n < K + 2 * DK) eacc += expf(v);
+        }
+      }
+    }
+    eacc = wave_sum_dpp(eacc);
+    if (lane == 0) red[w] = eacc;
+    __syncthreads();
+    if (tid == 0) {
+      float sx = 0.f;
+      for (int q = 0; q < kMT / 64; ++q) sx += red[q];
+      granule_publish(p.gran, o, tag + 1, sx);
+    }
+    BSIG_MSTAMP(9);
+    // ---- row-wise NLL forward / backward (one wavefront per row) -----------------------
+    RowOut ro;
+    ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
+#pragma unroll
+    for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
+    // one jitter stream per update and per evaluation, in program order
+    a.stream_id = rng_ctr0 + (uint64_t)t +
+                  (uint64_t)(p.do_eval ? mdnn_evals_before(step, p.eval_every) - ev0 : 0);
+    {
+      auto row_eps = [&] {
+        return p.eps_noise != 0.f
+                   ? p.eps_noise * (granule_gather(p.gran, p.n_owner, tag + 1, lane, flagp) / norm)
+                   : 0.f;
+      };
+      if constexpr (FULL) full_row(a, row, active, lane, tile, yv, rk, dlg, dlg + K, row_eps, ro);
+      else diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, row_eps, ro);
+    }
+    {
+      const float uds_w = wave_sum_dpp(ro.uds);
+      if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float sl = 0.f, su = 0.f;
+      for (int q = 0; q < kMR; ++q) { sl += red[16 + q]; su += red[32 + q]; }
+      granule_publish(p.gran + kGranArr, o, tag + 2, su);
+      granule_publish(p.gran + 2 * kGranArr, o, tag + 3, sl);
+    }
+    BSIG_MSTAMP(13);
+    float w2b[32];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const float* src = p.w2b_pack + (step & 1) * (kMH * kMH) + (((w * 8 + tt) * 2) * 64 + lane) * 2;
+      const float2 lo = xwg_load2(src), hi = xwg_load2(src + 128);
+      w2b[4 * tt + 0] = lo.x; w2b[4 * tt + 1] = lo.y; w2b[4 * tt + 2] = hi.x; w2b[4 * tt + 3] = hi.y;
+    }
+    // the jitter-scale gradient term d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
+    // needs the sum over the whole minibatch
+    {
+      float c = 0.f;
+      if (p.eps_noise != 0.f)
+        c = p.eps_noise / norm * granule_gather(p.gran + kGranArr, p.n_owner, tag + 2, lane, flagp);
+      if (active) {
+        if constexpr (FULL) {
+          // exp(pre) of the row: third block of full_row's scratch, [d][k] like the head outputs
+          const float* sg0 = dlg + K + 2 * DK;
+          if (c != 0.f)
+            for (int j = lane; j < DK; j += 64) tile[K + DK + j] += c * sg0[j];
+        } else {
+          const int groups = 64 / K, TPR = groups * K;
+          const int k = lane % K, d0 = lane / K;
+          if (c != 0.f && lane < TPR) {
+#pragma unroll
+            for (int q = 0; q < kElemsPerLane; ++q) {
+              const int d = d0 + q * groups;
+              if (d < D) tile[K + DK + d * K + k] += c * ro.esg0[q];
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
+        __builtin_amdgcn_wave_barrier();
+        float* dst = p.d_out + (int64_t)row * p.NhP;
+        for (int j = lane; j < Nh; j += 64) xwg_store(dst + j, tile[j]);
+      }
+    }
+    if (ro.bad) atomicOr(flagp, 1);
+    if constexpr (WIDE) __builtin_amdgcn_s_waitcnt(0);   // d_out rows are out before the flag
+    __syncthreads();
+    BSIG_MSTAMP(14);
+    if constexpr (WIDE) {
+      // ---- wide heads: dz2 = (sum of the head blocks' shares of d_out Wh) * (1 - h2^2) -------
+      if (tid == 0) flag_raise(p.flag_dout, o, epoch);
+      if (w == 0) flags_wait(p.flag_dz2, p.n_hb, epoch, lane, flagp);
+      __syncthreads();
+      if (tid < kMR * 64) {
+        const int r = tid >> 6, c2 = (tid & 63) * 2;
+        const float* src = p.dz2_part + (int64_t)min(r0 + r, B - 1) * kMH + c2;
+        float vx = 0.f, vy = 0.f;
+        for (int z = 0; z < p.n_hb; z += 8) {
+          float2 q[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) q[u] = xwg_load2(src + (int64_t)min(z + u, p.n_hb - 1) * zs);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (z + u < p.n_hb) { vx += q[u].x; vy += q[u].y; }
+        }
+        const float hx = H2s[r * kMHP + c2], hy = H2s[r * kMHP + c2 + 1];
+        vx *= 1.0f - hx * hx; vy *= 1.0f - hy * hy;
+        H2s[r * kMHP + c2] = vx; H2s[r * kMHP + c2 + 1] = vy;
+        if (r0 + r < B) {
+          xwg_store(p.dz2 + (int64_t)(r0 + r) * kMH + c2, vx);
+          xwg_store(p.dz2 + (int64_t)(r0 + r) * kMH + c2 + 1, vy);
+        }
+      }
+    }
+    // ---- dz2 = (d_out Wh) * (1 - h2^2): wave w -> columns 16w .. 16w+15 ----------------
+    if constexpr (!WIDE) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int i = 16 * w + c16;
+      const float* ap = Os + rowA * po + 4 * g;
+      for (int tt = 0; tt * 16 < Nh16; ++tt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+        const float* bp = Whs + (16 * tt + 4 * g) * kMH;
+        // rows 16tt + 4g + j: (row & 15) = 4g + j
+        const float f0 = bp[0 * kMH + (i ^ (4 * (4 * g + 0)))];
+        const float f1 = bp[1 * kMH + (i ^ (4 * (4 * g + 1)))];
+        const float f2 = bp[2 * kMH + (i ^ (4 * (4 * g + 2)))];
+        const float f3 = bp[3 * kMH + (i ^ (4 * (4 * g + 3)))];
+        acc = mfma16(a4.x, f0, acc);
+        acc = mfma16(a4.y, f1, acc);
+        acc = mfma16(a4.z, f2, acc);
+        acc = mfma16(a4.w, f3, acc);
+      }
+      if (4 * g < kMR) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * g + r;
+          const float hv = H2s[rr * kMHP + i];
+          const float v = acc[r] * (1.0f - hv * hv);
+          H2s[rr * kMHP + i] = v;            // same lane read h2 just above
+          if (r0 + rr < B) xwg_store(p.dz2 + (int64_t)(r0 + rr) * kMH + i, v);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- dz1 = (dz2 W2) * (1 - h1^2) -------------------------------------------------------
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int i = 16 * w + c16;
+      const float* ap = H2s + rowA * kMHP + 4 * g;
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * tt);
+        acc = mfma16(a4.x, w2b[4 * tt + 0], acc);
+        acc = mfma16(a4.y, w2b[4 * tt + 1], acc);
+        acc = mfma16(a4.z, w2b[4 * tt + 2], acc);
+        acc = mfma16(a4.w, w2b[4 * tt + 3], acc);
+      }
+      if (4 * g < kMR) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * g + r;
+          const float hv = H1s[rr * kMHP + i];
+          if (r0 + rr < B) xwg_store(p.dz1 + (int64_t)(r0 + rr) * kMH + i, acc[r] * (1.0f - hv * hv));
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0)
+      flag_raise(p.flag_own, o, epoch);
+    BSIG_MSTAMP(15);
+    if (o == 0 && w == 0) {
+      const float s = granule_gather(p.gran + 2 * kGranArr, p.n_owner, tag + 3, lane, flagp);
+      if (lane == 0) {
+        const float l = -s / (float)B;
+        p.train_loss[step] = l;
+        if (!isfinite(l)) atomicOr(flagp, 1);
+      }
+    }
+    // the evaluation due after the previous update: the tile workgroups formed its
+    // first-layer products while this update's rows were being finished
+    if (!WIDE && __builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
+      __syncthreads();
+      owner_eval(mdnn_evals_before(step, p.eval_every) - 1,
+                 rng_ctr0 + (uint64_t)t + (uint64_t)(mdnn_evals_before(step, p.eval_every) - ev0) - 1u, step, false);
+    }
+  }
+  if (!WIDE && p.do_eval && step0 + p.n_updates == p.n_total && (!DP || p.n_updates == 0) &&
+      !run_aborted(flagp, red, tid_0))
+    owner_eval(mdnn_evals_before(p.n_total - 1, p.eval_every),
+               rng_ctr0 + (uint64_t)p.n_updates +
+                   (uint64_t)(mdnn_evals_before(p.n_total - 1, p.eval_every) - ev0), p.n_total, true);
+}
+
+// fit_persistent_mdnn_stream.hip
+bool mdnn_stream_tile_geom(int FR, int chunks_per_wg, int S, int A, int* nip, int* pf, size_t* lds_bytes);
+int mdnn_stream_launch(const MdnnArgs& p, bool dp, bool wide, bool full, int grid, size_t lds, hipStream_t st);
+
+}  // namespace bsig

@@ -443,7 +443,7 @@ class MDNN(nn.Module):
         # a cross-correlation summary may arrive as factor rows (summarizers.CrossCorrFactors):
         # plans whose first layer lives in the persistent kernel consume them as they are
         factored = isinstance(x_data, CrossCorrFactors)
-        if factored and not lib.bsig_fit_accepts_factors(self._plan):
+        if factored and not lib.bsig_fit_accepts_factor_rows(self._plan, x_data.s_dim, x_data.a_dim):
             x_data, factored = x_data.materialize(), False
         ldy = _lib.round_up(d, 4)
         ys, ldy_src = _lib.as_f32_rows(y_data, dev)

@@ -335,6 +335,14 @@ int bsig_fit_flush(bsig_fit_plan* plan, bsig_stream_t stream);
 /* != 0: the plan's training rows may be cross-correlation factor rows (all its updates run
  * in the persistent kernel of the two-layer MDNN, whose first-layer tiles form the products). */
 int bsig_fit_accepts_factors(const bsig_fit_plan* plan);
+/* ... for S x A factor rows (x_kind BSIG_X_CROSSCORR_FACTORS with x_s = S, x_a = A).  A plan whose
+ * first layer does not fit the chip's LDS and registers (cfg/anymal.yaml:103-109, I = 56402;
+ * cfg/shadow_hand_more.yaml:73-81, I = 105002) STREAMS it through the tile workgroups of the
+ * persistent kernel and takes factor rows only (A % 4 == 0, the factor rows of two minibatches in
+ * one workgroup's LDS); bsig_fit_accepts_factors answers 0 for such a plan, this call decides.
+ * Summary rows of that width run the per-phase kernels.  (summarizers.py:112-119 into
+ * mdnn.py:71,108.) */
+int bsig_fit_accepts_factor_rows(const bsig_fit_plan* plan, int s_dim, int a_dim);
 /* 1: the plan's updates run in the persistent kernel for linear heads on cached
  * features (MDRFF), 2: in the one for the two-layer MDNN trunk (as bound), 0: as
  * per-phase kernels (diagnostics / tests). */
