@@ -52,6 +52,7 @@ struct MdnnGeom {
   int FR, Nh, Nh16, NhP, k_slices, G1, n_owner, n_small, x_floats;
   int wide;                     // head outputs formed by the head-block workgroups (see MdnnArgs)
   int stream, s_chunks;         // W1 streamed by G1 tile workgroups (fit_persistent_mdnn_stream.hip)
+  int mr;                       // minibatch rows per owner workgroup
   int eval_passes;              // 0: evaluations stay outside the launches
   size_t lds;
   size_t slab_floats, act_floats, dout_floats, eval_floats;
@@ -73,6 +74,7 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   g->NhP = (int)round_up(g->Nh, kMNB);
   g->k_slices = ceil_div(s.input_dim, kMC);
   g->G1 = (kMH / kMNB) * g->k_slices;
+  g->mr = kMR;
   g->n_owner = ceil_div(s.batch, kMR);
   g->n_small = kMH / kMNB + g->NhP / kMNB;
   g->stream = 0; g->s_chunks = 0;
@@ -82,16 +84,20 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
     // stream it (cross-correlation factor rows only; fit_persistent_mdnn_stream.hip)
     if (no_stream && no_stream[0] == '1') return false;
     g->stream = 1;
-    g->G1 = kXwgMax - g->n_owner - g->n_small;
-    g->s_chunks = ceil_div(s.input_dim, 64);
+    // (the owners read ONE summed slab here: 8 rows each cost them nothing and free 12 CUs)
+    g->mr = kStreamMR;
+    g->n_owner = ceil_div(s.batch, g->mr);
+    g->G1 = (kXwgMax - g->n_owner - g->n_small) / 4 * 4;     // blocks of four (32 hidden units each)
+    g->s_chunks = mdnn_stream_chunks(s.input_dim);
+    if (s.input_dim % 2 != 0) return false;                  // rows of W1 as 8-byte aligned pairs
     if (g->G1 < 64) return false;
   }
   g->x_floats = (int)round_up(std::max(128 * kMPbuf, kMNB * (g->FR + 4)), 4);
   const size_t tile_lds = ((size_t)g->FR * kMPitch + (size_t)kMNB * kMPitch + g->x_floats + 64 + 96 +
                            (kMT / 32) * 32) * sizeof(float);
-  size_t owner_lds = ((size_t)g->Nh16 * kMH + 2 * kMR * kMHP + (size_t)kMR * (g->Nh16 + 4) + kMH +
-                      g->Nh16 + (size_t)kMR * (s.out_dim + 3 * s.n_comp + (full ? 3 * s.out_dim * s.n_comp : 0)) +
-                      64 + (kSumSub - 1) * kSumItems * 4) * sizeof(float);
+  size_t owner_lds = ((size_t)g->Nh16 * kMH + 2 * g->mr * kMHP + (size_t)g->mr * (g->Nh16 + 4) + kMH +
+                      g->Nh16 + (size_t)g->mr * (s.out_dim + 3 * s.n_comp + (full ? 3 * s.out_dim * s.n_comp : 0)) +
+                      64 + (g->stream ? 0 : (kSumSub - 1) * kSumItems * 4)) * sizeof(float);
   size_t small_lds = ((size_t)g->FR * kMHP + (size_t)kMNB * (g->FR + 4) + 64) * sizeof(float);
   g->wide = owner_lds > (size_t)kMLdsLimit ? 1 : 0;
   const char* force_wide = getenv("BSIG_MDNN_WIDE_HEADS");     // tests: the wide path on small heads
@@ -106,7 +112,7 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
                     std::max(owner_lds, small_lds));
   if (g->stream) g->lds = std::max(owner_lds, small_lds);   // + the tile workgroups' (S, A known at bind)
   if (g->lds > (size_t)kMLdsLimit) return false;
-  g->slab_floats = (size_t)(g->stream ? g->G1 : g->k_slices) * s.batch * kMH;
+  g->slab_floats = g->stream ? (size_t)g->G1 * s.batch * kMNB : (size_t)g->k_slices * s.batch * kMH;
   g->act_floats = (size_t)s.batch * kMH;
   g->dout_floats = (size_t)s.batch * g->NhP;
   // in-launch evaluations: slabs of both parities and the parked head outputs
@@ -135,7 +141,7 @@ int persist_mdnn_streams(const PersistMdnnShape& s) {
 }
 // the LDS of a streamed plan's tile workgroups for S x A cross-correlation factors
 static bool mdnn_stream_fits(const MdnnGeom& g, int S, int A, int* nip, int* pf, size_t* lds) {
-  return mdnn_stream_tile_geom(g.FR, ceil_div(g.s_chunks, g.G1), S, A, nip, pf, lds);
+  return mdnn_stream_tile_geom(g.FR, ceil_div(g.s_chunks, g.G1 / 4), S, A, nip, pf, lds);
 }
 bool persist_mdnn_accepts_factors(const PersistMdnnShape& s, int S, int A) {
   MdnnGeom g;
@@ -263,7 +269,7 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.wide = g.wide; p.n_hb = g.NhP / kMNB;
   p.o_wide = p.eval_out + (size_t)g.eval_passes * s.batch * g.NhP;
   p.dz2_part = p.o_wide + g.dout_floats;
-  p.hpre = p.dz2_part + (g.wide ? (size_t)(g.NhP / kMNB) * g.act_floats : 0);
+  p.hpre = g.wide ? p.dz2_part + (size_t)(g.NhP / kMNB) * g.act_floats : p.o_wide;   // (o_wide / dz2_part: wide plans only)
   p.stream = g.stream; p.s_chunks = g.s_chunks; p.s_nip = s_nip; p.s_pf = s_pf;
   char* sync = base + mdnn_data_bytes(g);
   p.flag_fwd = reinterpret_cast<unsigned*>(sync);

@@ -5,8 +5,9 @@
 // mdnn.py:219-233.  The row-owner and small-weight workgroups are those of the resident
 // kernel (persist_mdnn_device.h); the tile workgroups here STREAM W1 and its moments:
 //
-//  * tile workgroup g of T (= the CUs the owners and the small-weight workgroups leave) walks
-//    the 64-column chunks [g*C/T, (g+1)*C/T) of W1, all 128 rows.  The minibatch never
+//  * tile workgroup g of T (= the CUs the owners and the small-weight workgroups leave, a multiple
+//    of 4) owns 32 hidden units (g mod 4) and walks the 256-column chunks [q*C/G, (q+1)*C/G), q = g / 4,
+//    G = T / 4: 32 rows x 1 KB per chunk and array, 16-byte accesses.  The minibatch never
 //    exists as a [B, I] tile: its FACTOR rows (sf | af | mean std, 1.3-4.6 KB per row
 //    instead of 226-420 KB) sit in LDS -- row-major for the forward product's A operand,
 //    transposed for the weight gradient's B operand -- and both MFMA operand streams form
@@ -14,15 +15,15 @@
 //    itself does.
 //  * ONE pass over its chunks per update, taking Adam step t and the forward product of
 //    minibatch t+1 from the same read of W1 (the minibatch ids are known ahead):
-//        W, m, v (chunk) -> registers (fp32 MFMA accumulator layout)
-//        dW  = dz1_t^T X_t[:, chunk]          (MFMA 32x32x2; dz1_t in registers)
+//        W, m, v (chunk) -> registers (rows of 16-byte quads)
+//        dW  = dz1_t^T X_t[:, chunk]          (MFMA 32x32x2; dz1_t in registers) -> LDS
 //        Adam -> W', m', v' -> memory;  W' -> LDS
 //        P_{t+1} += X_{t+1}[:, chunk] W'^T    (MFMA 32x32x2; accumulators live over the pass)
 //    W1 crosses HBM 6 times per update (W, m, v in and out) instead of 7, the two products
 //    run in the shadow of that stream, and no [B, I] summary, staging copy or gather exists.
-//  * the T partial products [B, 128] are summed by the tile workgroups themselves (each owns
-//    B*128/T consecutive elements: T*51 KB read once in total instead of once per row owner)
-//    and reach the owners as one slab, bias included.
+//  * the G partial products [B, 32] of a block of hidden units are summed by that block's tile
+//    workgroups themselves (each owns B*32/G consecutive elements) and reach the owners as one
+//    slab [B, 128], bias included.
 //
 // Per update: pass -> slabs -> sum -> owners (h1 .. NLL .. dz1) -> pass.  Every sum is taken
 // in a fixed order: runs are bitwise reproducible.  Data-parallel ranks (one update per
@@ -32,12 +33,25 @@
 
 namespace bsig {
 
-constexpr int kSC = 64;               // columns of W1 per chunk
-constexpr int kSPitch = kSC + 4;      // LDS pitch of the chunk's weights (forward B operand)
-constexpr int kSZRows = 56;           // dz1 rows per staging pass (two passes: 7 + 6 groups of 8)
-constexpr int kSZPitch = kMH + 4;
-constexpr int kSRedGroups = 32;       // slab groups of the cross-workgroup sum
+constexpr int kSC = 256;              // columns of W1 per chunk (1 KB of a row: what the HBM likes)
+constexpr int kSPitch = kSC + 4;      // LDS pitch of the chunk's 32 weight rows (forward B operand)
 constexpr int kSTP = 108;             // LDS pitch of a transposed factor column (104 rows + 4)
+constexpr int kSBP = 36;              // LDS pitch of a [rows][32] block (dz1 staging, slab staging)
+constexpr int kSRedGroups = 32;       // slab groups of the cross-workgroup sum
+typedef f32x4 __attribute__((aligned(4))) f32x4u;   // rows of W1 are only 8-byte aligned (I = S*A + 2)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
+// load and store of the wavefront (s_waitcnt vmcnt(0)): inside the pass that would expose the full
+// memory latency of the next chunk's loads at every barrier instead of hiding it behind the MFMAs.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// LDS hand-over inside one wavefront (its own stores before its own loads of other lanes' data)
+__device__ __forceinline__ void lds_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // k / a for 0 <= k < 2^24 without an integer division
 __device__ __forceinline__ int div_small(int k, int a, float ra) {
@@ -47,19 +61,34 @@ __device__ __forceinline__ int div_small(int k, int a, float ra) {
   return i;
 }
 
+// (diagnostics) per-wavefront stamps of tile workgroup 3 in update 4, second chunk: row 254 of the
+// profile buffer (no workgroup 254 exists on a 256-CU chip with owners and small-weight workgroups)
+#define BSIG_WSTAMP(k)                                                                      \
+  do {                                                                                      \
+    if (p.prof && g == 3 && t == 4 && c == c_lo + 1 && (threadIdx.x & 63) == 0)             \
+      p.prof[((int64_t)254 * kMProfUpdates + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); \
+  } while (0)
+
 template <bool DP>
 __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, float* smem) {
   const int PF = p.s_pf, NIP = p.s_nip, FR = p.FR, B = p.B;
   float* Fr = smem;                          // [FR][PF] factor rows of the minibatch of the forward product
-  float* Ft = Fr + FR * PF;                  // [NIP + A + 8][kSTP] factor columns of the minibatch of dW
-  float* Wc = Ft + (NIP + p.xA + 8) * kSTP;  // [128][kSPitch] this chunk's weights; also the
-                                             // dz1 staging [56][132] and the partial sums [32][16][4]
-  float* red = Wc + kMH * kSPitch;           // [64]
-  float* b1s = red + 64;                     // [128] b1 as of the forward product being summed
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int g = blockIdx.x, T = p.G1;
-  const int c_lo = (int)((int64_t)g * p.s_chunks / T), c_hi = (int)((int64_t)(g + 1) * p.s_chunks / T);
+  float* Ft = Fr + FR * PF;                  // [NIP + A + 8][kSTP] factor columns of the minibatch of dW;
+                                             // after the pass: the [B][kSBP] block of partial products
+  float* Wc = Ft + (NIP + p.xA + 8) * kSTP;  // [32][kSPitch] this chunk: dW, then the new weights; also
+                                             // the dz1 block [FR][kSBP], the k-half exchange, partial sums
+  float* red = Wc + kMNB * kSPitch;          // [64]
+  float* b1s = red + 64;                     // [32] b1 of this block as of the forward product being summed
+  // (lane-derived indices are laundered once per update -- below -- so that the address arithmetic
+  // built on them is recomputed where it is used instead of being kept live, and spilled, across
+  // the update loop: a spilled address comes back as scratch_load + s_waitcnt vmcnt(0) in front of
+  // its load, which serialises every batch of loads -- 17 us for the 39 loads of the factor rows)
+  int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int h = lane >> 5, l31 = lane & 31;
+  // workgroup g: hidden units [32 nb, 32 nb + 32), column chunks [c_lo, c_hi) of 256
+  const int g = blockIdx.x, T = p.G1, G = T >> 2;
+  const int nb = g & 3, gq = g >> 2;
+  const int c_lo = (int)((int64_t)gq * p.s_chunks / G), c_hi = (int)((int64_t)(gq + 1) * p.s_chunks / G);
   const int S = p.xS, A = p.xA, SA = S * A, I = p.I;
   const float rA = __builtin_amdgcn_rcpf((float)A);
   const int i_lo = (c_lo * kSC) / A;
@@ -70,147 +99,247 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
   float a0 = 0.f, a1 = 0.f;
   const AdamK ak{1.0f - (float)p.beta1, (float)p.beta2, 1.0f - (float)p.beta2, p.adam_eps};
   const bool fresh = !DP && step0 == 0;      // fresh optimizer (mdnn.py:203): moments start at zero
-  // roles: weight-gradient tile (nb, kt) = 32 rows x 32 columns of the chunk;
-  //        forward tiles (mt; 2 nbh, 2 nbh + 1) = 32 minibatch rows x 2 x 32 hidden units
-  const int nb = w & 3, kt = w >> 2, mt = w & 3, nbh = w >> 2;
+  // roles of wavefront w: weight-gradient tile = columns [32 w, 32 w + 32) of the chunk;
+  // forward tile = minibatch rows [32 mt, 32 mt + 32) over the k-half kh of the chunk
+  int mt = w & 3, kh = w >> 2;
+  // quad layout of the chunk for loads / Adam / stores: a WAVEFRONT owns the 32 x 32 block it
+  // computes the gradient of (columns 32 w ..): lane <-> rows (lane >> 3) + 8u, columns cl .. cl + 3 --
+  // gradient and weights change hands inside the wavefront, no workgroup barrier in between
+  int rl = lane >> 3, cl = w * 32 + (lane & 7) * 4;
+  auto relaunder = [&]() {
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63; w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    h = lane >> 5; l31 = lane & 31; mt = w & 3; kh = w >> 2;
+    rl = lane >> 3; cl = w * 32 + (lane & 7) * 4;
+  };
 
-  // b1 (128 values): lanes 0-31 of wavefronts 0-3 own b1[32 w + l31] in registers; every tile
-  // workgroup takes the same Adam steps (same values, same order), workgroup 0 writes back
-  const bool bias_lane = w < 4 && lane < 32;
+  // b1 of this block: lanes 0-31 of wavefront 0; every workgroup of the block takes the same Adam
+  // steps (same values, same order), the first one (gq == 0) writes back
+  const bool bias_lane = tid < kMNB;
   float bw = 0.f, bm = 0.f, bv = 0.f;
   if (bias_lane) {
-    const int64_t off = p.b1_off + 32 * w + lane;
+    const int64_t off = p.b1_off + nb * kMNB + tid;
     bw = p.params[off];
     if (!fresh && !DP) { bm = p.m1[off]; bv = p.m2[off]; }
-    b1s[32 * w + lane] = bw;
+    b1s[tid] = bw;
   }
 
-  // ---- factor rows of the minibatch starting at id-table row `row0`: slots [0, NIP) hold
-  //      sf[i_lo ..] (i == S: the "1" beside mean / std), then af | mean | std | zeros.
-  //      Row-major into Fr (transposed == false) or column-major into Ft
-  auto load_factors = [&](bool transposed, int64_t row0) {
+  // ---- factor rows of the minibatch starting at id-table row `row0` -> Fr (row-major): slots
+  //      [0, NIP) hold sf[i_lo ..] (i == S: the "1" beside mean / std), then af | mean | std | zeros.
+  //      All loads of a wavefront's 13 rows are in flight together.
+  auto load_factor_rows = [&](int64_t row0) {
     const int per_row = NIP + A + 8;
-    for (int b = w; b < (transposed ? kSTP : FR); b += kMT / 64) {
-      const float* src = b < B ? p.x + (int64_t)p.ids[row0 + b] * p.ldx : nullptr;
-      for (int c = lane; c < per_row; c += 64) {
-        float v = 0.f;
-        if (src) {
-          if (c < NIP) {
-            const int i = i_lo + c;
-            v = i < S ? src[i] : (i == S ? 1.0f : 0.f);
-          } else {
-            const int j = c - NIP;
-            v = j < A + 2 ? src[S + j] : 0.f;
-          }
-        }
-        if (transposed) Ft[c * kSTP + b] = v;
-        else Fr[b * PF + c] = v;
+    constexpr int kRows = 13, kCols = 3;                    // rows per wavefront, 64-column groups
+    float v[kRows][kCols];
+    int fr[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) fr[r] = p.ids[row0 + min(w + 8 * r, B - 1)];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) asm volatile("" : "+v"(fr[r]));
+    // (unconditional loads from clamped addresses, the selects afterwards: a load under a branch
+    // whose other side writes the same register is waited for on the spot)
+    int ofs[kCols];
+    bool live[kCols];
+#pragma unroll
+    for (int u = 0; u < kCols; ++u) {
+      const int c = lane + 64 * u;
+      const int i = i_lo + c, j = c - NIP;
+      // i == S: the "1" the summarizer stores behind mean and std (index S + A + 2)
+      ofs[u] = c < NIP ? (i < S ? i : S + A + 2) : S + min(j, A + 1);
+      live[u] = c < NIP ? i <= S : j < A + 2;
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const float* src = p.x + (int64_t)fr[r] * p.ldx;
+#pragma unroll
+      for (int u = 0; u < kCols; ++u) v[r][u] = src[ofs[u]];
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const int b = w + 8 * r;
+#pragma unroll
+      for (int u = 0; u < kCols; ++u) {
+        const int c = lane + 64 * u;
+        if (b < FR && c < per_row) Fr[b * PF + c] = (b < B && live[u]) ? v[r][u] : 0.f;
       }
     }
   };
-
-  // ---- the chunk's tile in the accumulator layout ------------------------------------------
-  // (buffer addressing: one lane offset per chunk, the 16 row offsets of the accumulator layout
-  // are wavefront-uniform -- no per-element 64-bit addresses kept in registers)
-  float Wv[16], Mv[16], Vv[16];
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(p.params + p.w1_off, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(p.m1 + p.w1_off, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(p.m2 + p.w1_off, 0, 0x7fffffff, 0x00020000);
-  const int lane_off = ((nb * 32 + 4 * h) * I + kt * 32 + l31) * 4;     // bytes; + chunk column, + row(i)
-  auto bld = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  // Fr (row-major, minibatch t) -> Ft (column-major: the B operand of dW reads 4 rows per load)
+  auto transpose_factors = [&]() {
+    const int per_row = NIP + A + 8;
+    for (int c = w; c < per_row; c += kMT / 64) {
+      for (int b = lane; b < kSTP; b += 64) Ft[c * kSTP + b] = b < FR ? Fr[b * PF + c] : 0.f;
+    }
   };
-  auto bst = [](__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+
+  // ---- the chunk's 32 x 256 block in quads (16-byte loads and stores, 8 rows x 128 B per wavefront
+  //      instruction, the eight wavefronts side by side on 1 KB of each row)
+  float W4[4][4], M4[4][4], V4[4][4];
+  auto chunk_ptr = [&](float* base, int c, int u) {
+    return base + p.w1_off + (int64_t)(nb * kMNB + rl + 8 * u) * I + (int64_t)c * kSC + cl;
+  };
+  // valid columns of my quad in chunk c: 4, 2 (I = S*A + 2 ends in the middle of a quad) or 0
+  auto quad_valid = [&](int c) { return min(max(I - (c * kSC + cl), 0), 4); };
+  auto ld4 = [&](const float* q, int nv, float (&r)[4]) {
+    r[0] = r[1] = r[2] = r[3] = 0.f;
+    if (nv == 4) { const f32x4 t4 = *reinterpret_cast<const f32x4u*>(q); r[0] = t4.x; r[1] = t4.y; r[2] = t4.z; r[3] = t4.w; }
+    else if (nv >= 2) { const float2 t2 = *reinterpret_cast<const float2*>(q); r[0] = t2.x; r[1] = t2.y; }
+  };
+  auto st4 = [&](float* q, int nv, const float (&r)[4]) {
+    if (nv == 4) { const f32x4 t4 = {r[0], r[1], r[2], r[3]}; *reinterpret_cast<f32x4u*>(q) = t4; }
+    else if (nv >= 2) *reinterpret_cast<float2*>(q) = make_float2(r[0], r[1]);
   };
   auto load_chunk = [&](int c, bool moments) {
-    const bool ok = c * kSC + kt * 32 + l31 < I;
-    const int voff = lane_off + c * kSC * 4;
+    const int nv = quad_valid(c);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int soff = acc_row0(i) * I * 4;
-      Wv[i] = 0.f; Mv[i] = 0.f; Vv[i] = 0.f;
-      if (ok) {
-        Wv[i] = bld(rW, voff, soff);
-        if (moments) { Mv[i] = bld(rM, voff, soff); Vv[i] = bld(rV, voff, soff); }
-      }
+    for (int u = 0; u < 4; ++u) {
+      ld4(chunk_ptr(p.params, c, u), nv, W4[u]);
+      ld4(chunk_ptr(p.m1, c, u), moments ? nv : 0, M4[u]);
+      ld4(chunk_ptr(p.m2, c, u), moments ? nv : 0, V4[u]);
+    }
+  };
+  auto store_quad = [&](int c, int u) {
+    const int nv = quad_valid(c);
+    st4(chunk_ptr(p.params, c, u), nv, W4[u]);
+    st4(chunk_ptr(p.m1, c, u), nv, M4[u]);
+    st4(chunk_ptr(p.m2, c, u), nv, V4[u]);
+  };
+  auto load_quad = [&](int c, int u, bool moments) {
+    const int nv = quad_valid(c);
+    ld4(chunk_ptr(p.params, c, u), nv, W4[u]);
+    ld4(chunk_ptr(p.m1, c, u), moments ? nv : 0, M4[u]);
+    ld4(chunk_ptr(p.m2, c, u), moments ? nv : 0, V4[u]);
+  };
+  auto store_chunk = [&](int c) {
+    const int nv = quad_valid(c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      st4(chunk_ptr(p.params, c, u), nv, W4[u]);
+      st4(chunk_ptr(p.m1, c, u), nv, M4[u]);
+      st4(chunk_ptr(p.m2, c, u), nv, V4[u]);
+    }
+  };
+  auto weights_to_lds = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4 t4 = {W4[u][0], W4[u][1], W4[u][2], W4[u][3]};
+      *reinterpret_cast<f32x4*>(Wc + (rl + 8 * u) * kSPitch + cl) = t4;
     }
   };
 
-  f32x16 facc[2];
-  // forward product of one chunk: rows mt, hidden blocks 2 nbh / 2 nbh + 1, weights in Wc
-  auto forward_chunk = [&](int c) {
+  // ---- forward product of one chunk (weights in Wc): rows mt, columns [128 kh + kk_lo, 128 kh + kk_hi).
+  //      Operands of step kk are fetched from LDS while the MFMAs of step kk - 8 run (the two
+  //      wavefronts of a SIMD execute this in lock-step behind the barrier).
+  f32x16 facc;
+  struct FwdOps { float sfv; float4 af4, b4; };
+  // position of a quad of columns k4 = i*A + ai (i <= S; i == S: the mean / std tail, ai = k4 - S*A)
+  struct FwdPos { int i, ai; };
+  auto forward_pos = [&](int k4) {
+    FwdPos q;
+    if (k4 >= SA) { q.i = S; q.ai = k4 - SA; }
+    else { q.i = div_small(k4, A, rA); q.ai = k4 - q.i * A; }
+    return q;
+  };
+  auto forward_fetch = [&](const FwdPos& q, int kc, FwdOps& o) {
     const float* frow = Fr + min(mt * 32 + l31, FR - 1) * PF;
-    const float* wrow = Wc + (2 * nbh * 32 + l31) * kSPitch + 4 * h;
-#pragma unroll 2
-    for (int kk = 0; kk < kSC; kk += 8) {
-      const int k4 = c * kSC + kk + 4 * h;
-      int si, ai;
-      if (k4 >= SA) { si = S - i_lo; ai = A + min(k4 - SA, 4); }
-      else { const int i = div_small(k4, A, rA); si = i - i_lo; ai = k4 - i * A; }
-      const float sfv = frow[si];
-      const float4 af4 = *reinterpret_cast<const float4*>(frow + NIP + ai);
-      const float ax = sfv * af4.x, ay = sfv * af4.y, az = sfv * af4.z, aw = sfv * af4.w;
+    o.sfv = frow[q.i - i_lo];
+    o.af4 = *reinterpret_cast<const float4*>(frow + NIP + (q.i >= S ? A + min(q.ai, 4) : q.ai));
+    o.b4 = *reinterpret_cast<const float4*>(Wc + l31 * kSPitch + kc);
+  };
+  // c_st >= 0: that chunk's block (in W4 / M4 / V4) is stored quad by quad behind steps 1..4;
+  // c_ld >= 0: the next chunk's block is loaded quad by quad behind steps 6..9 -- the memory
+  // instructions of a chunk are spread over the forward product instead of going out in two bursts
+  // (every CU of the chip runs the same phase at the same time: bursts saturate the write path)
+  auto forward_chunk = [&](int c, int kk_lo, int kk_hi, int c_st, int c_ld, bool moments) {
+    int kc = kh * (kSC / 2) + kk_lo + 4 * h;
+    FwdPos pos = forward_pos(c * kSC + kc);
+    FwdOps cur;
+    forward_fetch(pos, kc, cur);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(wrow + q * 32 * kSPitch + kk);
-        facc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, b4.x, facc[q], 0, 0, 0);
-        facc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, b4.y, facc[q], 0, 0, 0);
-        facc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(az, b4.z, facc[q], 0, 0, 0);
-        facc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, b4.w, facc[q], 0, 0, 0);
+    for (int kk = kk_lo; kk < kk_hi; kk += 8) {
+      FwdOps nxt = cur;
+      if (kk + 8 < kk_hi) {
+        kc += 8; pos.ai += 8;
+        if (pos.i < S && pos.ai >= A) { pos.ai -= A; ++pos.i; }     // (A >= 8)
+        forward_fetch(pos, kc, nxt);
       }
+      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.sfv * cur.af4.x, cur.b4.x, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.sfv * cur.af4.y, cur.b4.y, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.sfv * cur.af4.z, cur.b4.z, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.sfv * cur.af4.w, cur.b4.w, facc, 0, 0, 0);
+      const int step = kk / 8;
+      if (c_st >= 0 && step >= 1 && step <= 4) store_quad(c_st, step - 1);
+      if (c_ld >= 0 && step >= 6 && step <= 9) load_quad(c_ld, step - 6, moments);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
   };
-  auto chunk_to_lds = [&]() {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) Wc[(nb * 32 + acc_row(i, h)) * kSPitch + kt * 32 + l31] = Wv[i];
-  };
+  constexpr int kHalf = kSC / 4;             // a wavefront's 128 columns in two halves of 64
 
-  // ---- partial products of this workgroup -> slab; the sum over the workgroups ---------------
+  // ---- partial products of this workgroup -> slab; the sum over the workgroups of the block ----
+  auto stamp_sum = [&](unsigned epoch, int slot) {
+    if (p.prof && tid == 0 && epoch >= (unsigned)step0 + 2u && epoch - (unsigned)step0 - 2u < kMProfUpdates)
+      p.prof[((int64_t)blockIdx.x * kMProfUpdates + (epoch - step0 - 2u)) * 16 + slot] = wall_clock64();
+  };
   auto publish_and_sum = [&](unsigned epoch) {
     {
-      float* dst = fresh_ptr(p.slabs + ((int64_t)g * B + mt * 32 + 4 * h) * kMH + 2 * nbh * 32 + l31);
+      // the two k-halves meet in LDS; the [B][32] block goes out as 16-byte write-through stores
+      float* X = Wc;                                       // [4][32][33]
+      float* stage = Ft;                                   // [B][kSBP]
+      if (kh == 1) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+        for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h)) * kMPbuf + l31] = facc[i];
+      }
+      __syncthreads();
+      if (kh == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = mt * 32 + acc_row(i, h);
-          if (row < B) xwg_store(dst + acc_row0(i) * kMH + q * 32, facc[q][i]);
+          if (row < B) stage[row * kSBP + l31] = facc[i] + X[row * kMPbuf + l31];
         }
+      }
+      __syncthreads();
+      const __amdgpu_buffer_rsrc_t dr = xwg_buffer(p.slabs + (int64_t)g * B * kMNB);
+      for (int idx = tid; idx < B * (kMNB / 4); idx += kMT) {
+        const float4 v = *reinterpret_cast<const float4*>(stage + (idx >> 3) * kSBP + (idx & 7) * 4);
+        xwg_store4(dr, idx * 4, v.x, v.y, v.z, v.w);
       }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (tid == 0) flag_raise(p.flag_fwd, g, epoch);
+    stamp_sum(epoch, 14);
     if (w == 0) flags_wait(p.flag_fwd, T, epoch, lane, flagp);
     __syncthreads();
-    // my share of the B*32 quads of the [B, 128] block; 32 groups of slabs per quad, partial sums
-    // combined in group order
-    const int nq = B * (kMH / 4);
-    const int q_lo = (int)((int64_t)g * nq / T), q_hi = (int)((int64_t)(g + 1) * nq / T);
+    stamp_sum(epoch, 15);
+    // my share of the B*8 quads of the block's [B, 32] columns; 32 groups of slabs per quad, partial
+    // sums combined in group order
+    const int nq = B * (kMNB / 4);
+    const int q_lo = (int)((int64_t)gq * nq / G), q_hi = (int)((int64_t)(gq + 1) * nq / G);
     const __amdgpu_buffer_rsrc_t sr = xwg_buffer(p.slabs);
-    const int zs = B * kMH;
+    const int zs = 4 * B * kMNB;                           // from one workgroup of the block to the next
     float* part = Wc;
     for (int qb = q_lo; qb < q_hi; qb += 16) {
       const int qi = tid & 15, sg = tid >> 4;
       const int q = min(qb + qi, q_hi - 1);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      for (int z = sg; z < T; z += kSRedGroups * 8) {
-        f32x4 ld[8];
+      for (int z = sg; z < G; z += kSRedGroups * 2) {
+        f32x4 ld[2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ld[u] = xwg_load4(sr, min(z + u * kSRedGroups, T - 1) * zs + q * 4);
+        for (int u = 0; u < 2; ++u)
+          ld[u] = xwg_load4(sr, min(z + u * kSRedGroups, G - 1) * zs + nb * B * kMNB + q * 4);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (z + u * kSRedGroups < T) v += ld[u];
+        for (int u = 0; u < 2; ++u)
+          if (z + u * kSRedGroups < G) v += ld[u];
       }
       *reinterpret_cast<f32x4*>(part + (sg * 16 + qi) * 4) = v;
       __syncthreads();
       if (tid < 16 && qb + tid < q_hi) {
         f32x4 s = *reinterpret_cast<const f32x4*>(part + tid * 4);
         for (int u = 1; u < kSRedGroups; ++u) s += *reinterpret_cast<const f32x4*>(part + (u * 16 + tid) * 4);
-        const int n = ((qb + tid) * 4) & (kMH - 1);
-        xwg_store4(xwg_buffer(p.hpre), (qb + tid) * 4, s.x + b1s[n], s.y + b1s[n + 1], s.z + b1s[n + 2],
-                   s.w + b1s[n + 3]);
+        const int qd = qb + tid, b = qd >> 3, n = (qd & 7) * 4;
+        xwg_store4(xwg_buffer(p.hpre), b * kMH + nb * kMNB + n, s.x + b1s[n], s.y + b1s[n + 1],
+                   s.z + b1s[n + 2], s.w + b1s[n + 3]);
       }
       __syncthreads();
     }
@@ -221,19 +350,16 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
 
   // ---- prologue: the forward product of the launch's first minibatch --------------------------
   if (p.n_updates > 0) {
-    load_factors(false, (int64_t)step0 * B);
+    load_factor_rows((int64_t)step0 * B);
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) facc[q][i] = 0.f;
+    for (int i = 0; i < 16; ++i) facc[i] = 0.f;
     if (c_lo < c_hi) load_chunk(c_lo, false);
     __syncthreads();
     for (int c = c_lo; c < c_hi; ++c) {
-      chunk_to_lds();
-      if (c + 1 < c_hi) load_chunk(c + 1, false);
-      __syncthreads();
-      forward_chunk(c);
-      __syncthreads();
+      weights_to_lds();
+      lds_barrier();
+      forward_chunk(c, 0, 2 * kHalf, -1, c + 1 < c_hi ? c + 1 : -1, false);
+      lds_barrier();
     }
     publish_and_sum((unsigned)step0 + 1u);
   }
@@ -242,56 +368,51 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     const int step = step0 + t;
     const unsigned epoch = (unsigned)step + 1u;
     const bool has_next = !DP && t + 1 < p.n_updates;
+    const bool moments = !(fresh && t == 0);
+    relaunder();
     if (run_aborted(flagp, red, tid)) break;
     BSIG_MSTAMP(0);
-    // ---- while the owners work: this minibatch's factor columns (dW), the next minibatch's
-    //      factor rows (forward), the first chunk, Adam scalars
-    load_factors(true, (int64_t)step * B);
-    if (has_next) load_factors(false, (int64_t)(step + 1) * B);
-    if (!DP && c_lo < c_hi) load_chunk(c_lo, !(fresh && t == 0));
+    // ---- while the owners work: the first chunk (the long fetch first), this minibatch's factor
+    //      columns (dW), the next minibatch's factor rows (forward), Adam scalars
+    if (!DP && c_lo < c_hi) load_chunk(c_lo, moments);
+    transpose_factors();
+    __syncthreads();
+    BSIG_MSTAMP(1);
+    if (has_next) load_factor_rows((int64_t)(step + 1) * B);
+    BSIG_MSTAMP(6);
     b1t *= p.beta1; b2t *= p.beta2;
     a0 = (float)(p.lr / (1.0 - b1t));
     a1 = (float)(1.0 / sqrt(1.0 - b2t));
-    BSIG_MSTAMP(1);
     if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
     __syncthreads();
     BSIG_MSTAMP(2);
-    // ---- dz1 [B, 128] -> the A operand registers of this wavefront's 32 hidden units -------
+    // ---- dz1[:, block] -> the A operand registers (the same in every wavefront) ---------------
     float za[52];
     {
       const __amdgpu_buffer_rsrc_t zr = xwg_buffer(p.dz1);
-      float* Zs = Wc;
+      float* Zs = Wc;                                      // [FR][kSBP]
+      f32x4 q[2];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int b0 = half * kSZRows, nrow = half == 0 ? kSZRows : FR - kSZRows;
-        for (int base = 0; base < nrow * 32; base += kMT * 4) {
-          f32x4 q[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * kMT + tid;
-            const int b = b0 + (idx >> 5);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            q[u] = (idx < nrow * 32 && b < B) ? xwg_load4(zr, b * kMH + (idx & 31) * 4) : zero;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * kMT + tid;
-            if (idx < nrow * 32) *reinterpret_cast<f32x4*>(Zs + (idx >> 5) * kSZPitch + (idx & 31) * 4) = q[u];
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int gq = 0; gq < 13; ++gq) {
-          if ((gq < 7) == (half == 0)) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int b = 8 * gq + 4 * h + e;
-              za[4 * gq + e] = b < FR ? Zs[(b - b0) * kSZPitch + nb * 32 + l31] : 0.f;
-            }
-          }
-        }
-        __syncthreads();
+      for (int u = 0; u < 2; ++u) {
+        const int idx = u * kMT + tid;
+        q[u] = xwg_load4(zr, min(idx >> 3, B - 1) * kMH + nb * kMNB + (idx & 7) * 4);
       }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = u * kMT + tid, b = idx >> 3;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (b < FR) *reinterpret_cast<f32x4*>(Zs + b * kSBP + (idx & 7) * 4) = b < B ? q[u] : zero;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int gq8 = 0; gq8 < 13; ++gq8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int b = 8 * gq8 + 4 * h + e;
+          za[4 * gq8 + e] = b < FR ? Zs[b * kSBP + l31] : 0.f;
+        }
+      }
+      __syncthreads();
     }
     // ---- b1: column sums of dz1 (fixed order: lane half 0 then 1), Adam -------------------------
     {
@@ -300,77 +421,151 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
       for (int q = 0; q < 52; ++q) gs += za[q];
       gs += __shfl_xor(gs, 32, 64);
       if (bias_lane) {
-        if (DP) { if (g == 0) p.grads[p.b1_off + 32 * w + lane] = gs; }
+        if (DP) { if (gq == 0) p.grads[p.b1_off + nb * kMNB + tid] = gs; }
         else bw = adam_bias(gs, bm, bv, bw, a0, a1, ak);
+        b1s[tid] = bw;                                     // (the previous sum's readers are long done)
       }
     }
-    __syncthreads();                         // (b1s readers of the previous sum are done)
-    if (bias_lane) b1s[32 * w + lane] = bw;
     BSIG_MSTAMP(3);
 
     // ---- the pass --------------------------------------------------------------------------
+    // dW tile of chunk c = dz1^T X_t[:, 32 columns]: lane <-> column k = i*A + j, its two factors
+    // down the minibatch rows; 13 groups of 4 MFMAs
+    const float* sfp = Ft;
+    const float* afp = Ft;
+    auto dw_setup = [&](int c) {
+      const int k = c * kSC + w * 32 + l31;
+      int si, ai;
+      if (k >= SA) { si = S - i_lo; ai = A + min(k - SA, 2); }
+      else { const int i = div_small(k, A, rA); si = i - i_lo; ai = k - i * A; }
+      sfp = Ft + si * kSTP + 4 * h;
+      afp = Ft + (NIP + ai) * kSTP + 4 * h;
+    };
+    f32x16 acc;
+    // (operands of group gq8 + 1 are fetched while the MFMAs of group gq8 run; the scheduling
+    // barrier keeps the compiler from hoisting all 26 fetches of a tile to its top -- 104 registers)
+    float4 dw_s, dw_f;
+    auto dw_fetch = [&](int gq8) {
+      dw_s = *reinterpret_cast<const float4*>(sfp + 8 * gq8);
+      dw_f = *reinterpret_cast<const float4*>(afp + 8 * gq8);
+    };
+    auto dw_group = [&](int gq8) {
+      if (8 * gq8 < FR) {
+        const float4 s4 = dw_s, f4 = dw_f;
+        if (gq8 + 1 < 13 && 8 * (gq8 + 1) < FR) dw_fetch(gq8 + 1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 0], s4.x * f4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 1], s4.y * f4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 2], s4.z * f4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 3], s4.w * f4.w, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto dw_to_lds = [&]() {
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+      for (int i = 0; i < 16; ++i) Wc[acc_row(i, h) * kSPitch + w * 32 + l31] = acc[i];
+    };
+    // Adam on quad u of the chunk in W4 / M4 / V4: its gradient sits in Wc, the new weights replace it
+    auto adam_quad = [&](int u) {
+      float* gp = Wc + (rl + 8 * u) * kSPitch + cl;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gp);
+      W4[u][0] = adam_weight(g4.x, M4[u][0], V4[u][0], W4[u][0], a0, a1, ak);
+      W4[u][1] = adam_weight(g4.y, M4[u][1], V4[u][1], W4[u][1], a0, a1, ak);
+      W4[u][2] = adam_weight(g4.z, M4[u][2], V4[u][2], W4[u][2], a0, a1, ak);
+      W4[u][3] = adam_weight(g4.w, M4[u][3], V4[u][3], W4[u][3], a0, a1, ak);
+      const f32x4 t4 = {W4[u][0], W4[u][1], W4[u][2], W4[u][3]};
+      *reinterpret_cast<f32x4*>(gp) = t4;                  // (same thread, same spot)
+    };
 #pragma unroll
-      for (int i = 0; i < 16; ++i) facc[q][i] = 0.f;
-    for (int c = c_lo; c < c_hi; ++c) {
-      const int k = c * kSC + kt * 32 + l31;
-      // dW tile = dz1^T X_t[:, chunk]: lane <-> column k = i*A + j, its two factors down the rows
-      f32x16 acc;
+    for (int i = 0; i < 16; ++i) facc[i] = 0.f;
+    if (DP) {
+      // this rank's share of the gradient, summed over the ranks by the caller
+      for (int c = c_lo; c < c_hi; ++c) {
+        const int k = c * kSC + w * 32 + l31;
+        dw_setup(c);
+        dw_fetch(0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-      {
-        int si, ai;
-        if (k >= SA) { si = S - i_lo; ai = A + min(k - SA, 2); }
-        else { const int i = div_small(k, A, rA); si = i - i_lo; ai = k - i * A; }
-        const float* sfp = Ft + si * kSTP + 4 * h;
-        const float* afp = Ft + (NIP + ai) * kSTP + 4 * h;
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int gq = 0; gq < 13; ++gq) {
-          if (8 * gq < FR) {
-            const float4 s4 = *reinterpret_cast<const float4*>(sfp + 8 * gq);
-            const float4 f4 = *reinterpret_cast<const float4*>(afp + 8 * gq);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq + 0], s4.x * f4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq + 1], s4.y * f4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq + 2], s4.z * f4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq + 3], s4.w * f4.w, acc, 0, 0, 0);
-          }
+        for (int gq8 = 0; gq8 < 13; ++gq8) dw_group(gq8);
+        if (k < I) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            p.grads[p.w1_off + (int64_t)(nb * kMNB + acc_row(i, h)) * I + k] = acc[i];
         }
       }
-      const int voff = lane_off + c * kSC * 4;
-      if (DP) {
-        if (k < I) {
-          const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(p.grads + p.w1_off, 0, 0x7fffffff, 0x00020000);
+    } else if (c_lo < c_hi) {
+      // The Adam arithmetic of chunk c (VALU) runs in the shadow of the MFMAs of chunk c + 1's
+      // gradient: chunk c's gradient is already in LDS when its Adam step starts.
+      dw_setup(c_lo);
+      dw_fetch(0);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) bst(rG, voff, acc_row0(i) * I * 4, acc[i]);
-        }
-      } else {
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) Wv[i] = adam_weight(acc[i], Mv[i], Vv[i], Wv[i], a0, a1, ak);
-        if (k < I) {
+      for (int gq8 = 0; gq8 < 13; ++gq8) dw_group(gq8);
+      dw_to_lds();
+      lds_wave_sync();
+      for (int c = c_lo; c < c_hi; ++c) {
+        const bool more = c + 1 < c_hi;
+        relaunder();                                       // (nothing lane-derived stays live across chunks)
+        if (c == c_lo + 1) BSIG_MSTAMP(8);
+        BSIG_WSTAMP(0);
+        if (more) {
+          dw_setup(c + 1);
+          dw_fetch(0);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int soff = acc_row0(i) * I * 4;
-            bst(rW, voff, soff, Wv[i]); bst(rM, voff, soff, Mv[i]); bst(rV, voff, soff, Vv[i]);
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+          for (int gq8 = 0; gq8 < 13; ++gq8) {
+            dw_group(gq8);
+            if (gq8 % 3 == 1) { adam_quad(gq8 / 3); __builtin_amdgcn_sched_barrier(0); }   // after groups 1, 4, 7, 10
           }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) adam_quad(u);
         }
-        if (has_next) chunk_to_lds();
-        if (c + 1 < c_hi) load_chunk(c + 1, !(fresh && t == 0));
+        if (c == c_lo + 1) { asm volatile("" :: "v"(acc[0])); BSIG_MSTAMP(9); }
+        asm volatile("" :: "v"(acc[0])); BSIG_WSTAMP(1);
+        // (the LAST chunk of a pass that is followed by a forward sum keeps its block in registers
+        // until the sum is out: these stores would otherwise sit in front of the slab stores and
+        // their flag on the chip's write path)
+        const bool defer = has_next && !more;
+        if (c == c_lo + 1) BSIG_MSTAMP(10);
         if (has_next) {
-          __syncthreads();
-          forward_chunk(c);
-          __syncthreads();
+          lds_barrier();                                   // every block of the chunk holds its new weights
+          if (c == c_lo + 1) BSIG_MSTAMP(11);
+          BSIG_WSTAMP(2);
+          // the block's 12 stores and the next chunk's 12 loads go out between the quarters of the
+          // forward product: their issue (1 KB per instruction through the CU's 64 B/clk path) runs
+          // in the shadow of the MFMAs instead of in front of a barrier
+          forward_chunk(c, 0, 2 * kHalf, defer ? -1 : c, more ? c + 1 : -1, moments);
+          asm volatile("" :: "v"(facc[0])); BSIG_WSTAMP(7);
+          if (c == c_lo + 1) { asm volatile("" :: "v"(facc[0])); BSIG_MSTAMP(12); }
+          lds_barrier();                                   // the chunk's weights are read: Wc is free
+          BSIG_WSTAMP(8);
+        } else {
+          store_chunk(c);
+          if (more) load_chunk(c + 1, moments);
         }
+        if (more) {
+          dw_to_lds();
+          lds_wave_sync();
+        }
+        BSIG_WSTAMP(9);
+        if (c == c_lo + 1) BSIG_MSTAMP(13);
+        if (c == c_lo) BSIG_MSTAMP(7);
       }
     }
     BSIG_MSTAMP(4);
-    if (has_next) publish_and_sum(epoch + 1u);
+    if (has_next) {
+      publish_and_sum(epoch + 1u);
+      if (c_lo < c_hi) store_chunk(c_hi - 1);              // the deferred block of the last chunk
+    }
     BSIG_MSTAMP(5);
   }
 
   // ---- write b1 back, advance the engine state -------------------------------------------------
-  if (!DP && g == 0 && bias_lane) {
-    const int64_t off = p.b1_off + 32 * w + lane;
+  if (!DP && gq == 0 && bias_lane) {
+    const int64_t off = p.b1_off + nb * kMNB + tid;
     p.params[off] = bw; p.m1[off] = bm; p.m2[off] = bv;
   }
   if (g == 0 && tid == 0 && p.n_updates > 0) {
@@ -391,7 +586,7 @@ __global__ __launch_bounds__(kMT) void mdnn_stream_updates_kernel(MdnnArgs p) {
   const int wg = blockIdx.x;
   if (wg < p.G1) mdnn_stream_tile_workgroup<DP>(p, smem);
 #ifndef BSIG_STREAM_TILE_ONLY   // (resource usage of the tile body alone)
-  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP, WIDE, FULL>(p, smem);
+  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP, WIDE, FULL, kStreamMR>(p, smem);
   else mdnn_small_workgroup<DP, WIDE>(p, smem);
 #endif
 }
@@ -399,18 +594,25 @@ __global__ __launch_bounds__(kMT) void mdnn_stream_updates_kernel(MdnnArgs p) {
 // ---------------------------------------------------------------- host side
 // LDS floats of a tile workgroup; false when the factor rows of two minibatches do not fit
 bool mdnn_stream_tile_geom(int FR, int chunks_per_wg, int S, int A, int* nip, int* pf, size_t* lds_bytes) {
-  if (S < 1 || A < 4 || A % 4 != 0) return false;
+  if (S < 1 || A < 8 || A % 4 != 0) return false;
   const int cols = chunks_per_wg * kSC;
   const int ni = (cols - 1) / A + 2;            // distinct i = k / A over `cols` columns (i = S: the tail)
   *nip = (int)round_up(ni, 4);
   int pitch = *nip + A + 8;
   while (pitch % 8 != 4) pitch += 4;            // 16-byte reads down the rows: conflict-free
   *pf = pitch;
-  const size_t floats = (size_t)FR * pitch + (size_t)(*nip + A + 8) * kSTP + (size_t)kMH * kSPitch + 64 + kMH;
+  const size_t floats = (size_t)FR * pitch + (size_t)(*nip + A + 8) * kSTP + (size_t)kMNB * kSPitch + 64 + kMNB;
   *lds_bytes = floats * sizeof(float);
-  return *lds_bytes <= (size_t)kMLdsLimit && (size_t)kSZRows * kSZPitch <= (size_t)kMH * kSPitch &&
-         FR - kSZRows <= kSZRows && FR <= 104;
+  // (the chunk region also stages dz1 [FR][36], the k-half exchange [128][33] and the partial
+  // sums [32][16][4]; the factor columns the [B][36] block of partial products; a factor row is
+  // loaded as at most three 64-column groups)
+  return *lds_bytes <= (size_t)kMLdsLimit && FR <= 104 && *nip + A + 8 <= 192 &&
+         (size_t)kMNB * kSPitch >= (size_t)128 * kMPbuf && (size_t)kMNB * kSPitch >= (size_t)FR * kSBP &&
+         (size_t)(*nip + A + 8) * kSTP >= (size_t)FR * kSBP;
 }
+
+// chunks of 256 columns; the tile workgroups come in blocks of four (one per 32 hidden units)
+int mdnn_stream_chunks(int input_dim) { return ceil_div(input_dim, kSC); }
 
 int mdnn_stream_launch(const MdnnArgs& p, bool dp, bool wide, bool full, int grid, size_t lds, hipStream_t st) {
   static bool attr_set_dev[64] = {};

@@ -22,6 +22,7 @@ constexpr int kMNB = 32;            // weight rows per tile / small-weight workg
 constexpr int kMH = 128;            // hidden width (both layers)
 constexpr int kMHP = kMH + 4;       // LDS pitch of a 128-wide activation row
 constexpr int kMR = 4;              // minibatch rows per owner workgroup (power of two <= 8)
+constexpr int kStreamMR = 8;        // ... of a plan with a streamed first layer
 constexpr int kMPbuf = 33;
 constexpr int kMLdsLimit = 160 * 1024;
 
@@ -91,7 +92,8 @@ struct MdnnArgs {
   const float* o_slabs; int o_k_slices; unsigned* o_flags;
   // ---- streamed first layer (fit_persistent_mdnn_stream.hip): W1 does not fit the chip
   //      (cfg/anymal.yaml I = 56402, cfg/shadow_hand_more.yaml I = 105002); tile workgroup g
-  //      walks the 64-column chunks [g*s_chunks/G1, (g+1)*s_chunks/G1) of W1, all 128 rows
+  //      owns hidden units [32 (g % 4), +32) and walks the 256-column chunks
+  //      [q*s_chunks/G, (q+1)*s_chunks/G), q = g / 4, G = G1 / 4
   int stream, s_chunks;
   int s_nip, s_pf;     // factor rows in LDS: sf slots [0, s_nip), af | mean std 0.. at s_nip, pitch s_pf
   float* hpre;         // [B][128] layer-1 pre-activations summed over the tile workgroups (+ b1)
@@ -866,13 +868,23 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
 // item = (row, column quad), kSumSub threads share an item's slices (16-byte loads, all in flight),
 // their partial sums meet in a fixed order through `part` ([kSumSub - 1][kSumItems] quads of LDS).
 // Returns the item's sum to the threads tid < kSumItems.  Ends on a workgroup barrier.
-constexpr int kSumItems = kMR * (kMH / 4), kSumSub = kMT / kSumItems, kSumFlight = 12;
+constexpr int kSumFlight = 12;
+constexpr int sum_items(int mr) { return mr * (kMH / 4); }
+constexpr int sum_sub(int mr) { return kMT / sum_items(mr); }
+constexpr int kSumItems = sum_items(kMR), kSumSub = sum_sub(kMR);   // (host-side LDS sizing of the default)
+template <int MR>
 __device__ __forceinline__ f32x4 slab_quads_sum(const float* slabs, int k_slices, int zs, int row, int tid,
                                                 float* part) {
-  const int item = tid & (kSumItems - 1), sub = tid / kSumItems;
+  const int item = tid & ((MR * (kMH / 4)) - 1), sub = tid / (MR * (kMH / 4));
   const int c4 = (item & 31) * 4;
   const __amdgpu_buffer_rsrc_t sr = xwg_buffer(slabs);
-  const int per = ceil_div(k_slices, kSumSub);
+  if (k_slices == 1) {     // (streamed first layer: already summed; `part` is not used -- nor allocated)
+    f32x4 one = {0.f, 0.f, 0.f, 0.f};
+    if (sub == 0) one = xwg_load4(sr, row * kMH + c4);
+    __syncthreads();
+    return one;
+  }
+  const int per = ceil_div(k_slices, (kMT / (MR * (kMH / 4))));
   const int z_lo = sub * per, z_hi = min(z_lo + per, k_slices);
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   for (int z = z_lo; z < z_hi; z += kSumFlight) {
@@ -883,33 +895,33 @@ __device__ __forceinline__ f32x4 slab_quads_sum(const float* slabs, int k_slices
     for (int u = 0; u < kSumFlight; ++u)
       if (z + u < z_hi) v += q[u];
   }
-  if (sub > 0) *reinterpret_cast<f32x4*>(part + ((sub - 1) * kSumItems + item) * 4) = v;
+  if (sub > 0) *reinterpret_cast<f32x4*>(part + ((sub - 1) * (MR * (kMH / 4)) + item) * 4) = v;
   __syncthreads();
   if (sub == 0) {
 #pragma unroll
-    for (int q = 1; q < kSumSub; ++q) v += *reinterpret_cast<const f32x4*>(part + ((q - 1) * kSumItems + item) * 4);
+    for (int q = 1; q < (kMT / (MR * (kMH / 4))); ++q) v += *reinterpret_cast<const f32x4*>(part + ((q - 1) * (MR * (kMH / 4)) + item) * 4);
   }
   return v;
 }
 
-template <bool DP, bool WIDE, bool FULL>
+template <bool DP, bool WIDE, bool FULL, int MR = kMR>
 __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
   const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
   const int po = Nh16 + 4;                   // pitch of a head-output row
   const int per_wave = D + 3 * K + (FULL ? 3 * DK : 0);
   float* Whs = smem;                         // [Nh16][128], element (n, i) at n*128 + (i ^ 4(n & 15))
-  float* H1s = Whs + (WIDE ? 0 : Nh16 * kMH);   // [kMR][kMHP]  (wide heads: no head matrix here)
-  float* H2s = H1s + kMR * kMHP;             // [kMR][kMHP]  h2, later dz2 in place
-  float* Os = H2s + kMR * kMHP;              // [kMR][po]    head outputs, later d_out in place
-  float* b2s = Os + kMR * po;                // [128]
+  float* H1s = Whs + (WIDE ? 0 : Nh16 * kMH);   // [MR][kMHP]  (wide heads: no head matrix here)
+  float* H2s = H1s + MR * kMHP;             // [MR][kMHP]  h2, later dz2 in place
+  float* Os = H2s + MR * kMHP;              // [MR][po]    head outputs, later d_out in place
+  float* b2s = Os + MR * po;                // [128]
   float* bhs = b2s + kMH;                    // [Nh16]
-  float* wsc = bhs + Nh16;                   // [kMR][D + 3K] per-row scratch of diag_row
-  float* red = wsc + kMR * per_wave;         // [64]
-  float* part4 = red + 64;                   // [(kSumSub - 1) * kSumItems * 4]  partial k-slice sums
+  float* wsc = bhs + Nh16;                   // [MR][D + 3K] per-row scratch of diag_row
+  float* red = wsc + MR * per_wave;         // [64]
+  float* part4 = red + 64;                   // [((kMT / (MR * (kMH / 4))) - 1) * (MR * (kMH / 4)) * 4]  partial k-slice sums
   const int tid_0 = threadIdx.x, w_0 = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
   const int c16_0 = tid_0 & 15, g_0 = (tid_0 & 63) >> 4;
   const int o = blockIdx.x - p.G1;
-  const int r0 = o * kMR;
+  const int r0 = o * MR;
   int32_t* flagp = p.state + 2;
   const int step0 = p.state[0];
   const uint64_t rng_seed = reinterpret_cast<const uint64_t*>(p.state + 8)[0];
@@ -937,10 +949,10 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     int c16 = c16_0, g = g_0, tid = tid_0;
     const int w = w_0;
     asm volatile("" : "+v"(c16), "+v"(g), "+v"(tid));
-    const int lane = tid & 63, rowA = c16 & (kMR - 1);
+    const int lane = tid & 63, rowA = c16 & (MR - 1);
     const unsigned etag = (unsigned)eidx + 1u;
-    float* tile = Os + (w & (kMR - 1)) * po;
-    float* yv = wsc + (w & (kMR - 1)) * per_wave;
+    float* tile = Os + (w & (MR - 1)) * po;
+    float* yv = wsc + (w & (MR - 1)) * per_wave;
     float* rk = yv + D;
     float* lpk = rk + K;
     float* dlg = lpk + K;
@@ -972,8 +984,8 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     for (int gp = 0; gp < p.eval_passes; ++gp) {
       const float* slabs = p.eval_slabs + (((int64_t)(eidx & 1) * p.eval_passes + gp) * p.k_slices) * zs;
       {
-        const f32x4 v = slab_quads_sum(slabs, p.k_slices, (int)zs, min(r0 + (tid >> 5 & (kMR - 1)), B - 1), tid, part4);
-        if (tid < kSumItems) {
+        const f32x4 v = slab_quads_sum<MR>(slabs, p.k_slices, (int)zs, min(r0 + (tid >> 5 & (MR - 1)), B - 1), tid, part4);
+        if (tid < (MR * (kMH / 4))) {
           const int r = tid >> 5, c4 = (tid & 31) * 4;
           const bool ok = r0 + r < B && gp * B + r0 + r < p.n_test;
           float* hl = H1s + r * kMHP + c4;
@@ -993,7 +1005,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
           acc = mfma16(a4.z, w2f[4 * tt + 2], acc);
           acc = mfma16(a4.w, w2f[4 * tt + 3], acc);
         }
-        if (4 * g < kMR) {
+        if (4 * g < MR) {
           const int n = 16 * w + c16;
           const float bias = b2s[n];
 #pragma unroll
@@ -1016,7 +1028,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
           acc = mfma16(a4.z, b4.z, acc);
           acc = mfma16(a4.w, b4.w, acc);
         }
-        if (4 * g < kMR) {
+        if (4 * g < MR) {
           const float bias = bhs[n];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -1028,7 +1040,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         }
       }
       __syncthreads();
-      for (int idx = tid; idx < kMR * Nh; idx += kMT) {
+      for (int idx = tid; idx < MR * Nh; idx += kMT) {
         const int r = idx / Nh, j = idx - r * Nh;
         const int erow = gp * B + r0 + r;
         if (r0 + r < B && erow < p.n_test) xwg_store(p.eval_out + (int64_t)erow * p.NhP + j, Os[r * po + j]);
@@ -1051,17 +1063,17 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     float lse_acc = 0.f;
     bool bad = false;
     for (int gp = 0; gp < p.eval_passes; ++gp) {
-      for (int idx = tid; idx < kMR * Nh; idx += kMT) {
+      for (int idx = tid; idx < MR * Nh; idx += kMT) {
         const int r = idx / Nh, j = idx - r * Nh;
         const int erow = gp * B + r0 + r;
         Os[r * po + j] = (r0 + r < B && erow < p.n_test) ? xwg_load(p.eval_out + (int64_t)erow * p.NhP + j) : 0.f;
       }
       const int erow = gp * B + r0 + w;
-      const bool act = w < kMR && r0 + w < B && erow < p.n_test;
+      const bool act = w < MR && r0 + w < B && erow < p.n_test;
       if (act)
         for (int j = lane; j < D; j += 64) yv[j] = p.y_test[(int64_t)erow * p.ldy_test + j];
       __syncthreads();
-      if (w < kMR) {
+      if (w < MR) {
         RowOut ro;
         ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
 #pragma unroll
@@ -1083,7 +1095,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     __syncthreads();
     if (tid == 0) {
       float sl = 0.f;
-      for (int q = 0; q < kMR; ++q) sl += red[16 + q];
+      for (int q = 0; q < MR; ++q) sl += red[16 + q];
       granule_publish(p.gran_eval + kGranArr, o, etag, sl);
     }
     if (o == 0 && w == 0) {
@@ -1108,11 +1120,11 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     int c16 = c16_0, g = g_0, w = w_0, tid = tid_0;
     asm volatile("" : "+v"(c16), "+v"(g), "+v"(tid));
     asm volatile("" : "+s"(w));
-    const int lane = tid & 63, rowA = c16 & (kMR - 1);
+    const int lane = tid & 63, rowA = c16 & (MR - 1);
     const int row = r0 + w;
-    const bool active = w < kMR && row < B;
-    float* tile = Os + (w & (kMR - 1)) * po;
-    float* yv = wsc + (w & (kMR - 1)) * per_wave;
+    const bool active = w < MR && row < B;
+    float* tile = Os + (w & (MR - 1)) * po;
+    float* yv = wsc + (w & (MR - 1)) * per_wave;
     float* rk = yv + D;
     float* lpk = rk + K;
     float* dlg = lpk + K;
@@ -1178,8 +1190,8 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     {
       // (row, column pair) items; kSub threads share an item's k-slices, their partial
       // sums are combined in a fixed order through LDS
-      const f32x4 v = slab_quads_sum(p.o_slabs, p.o_k_slices, (int)zs, min(r0 + (tid >> 5 & (kMR - 1)), B - 1), tid, part4);
-      if (tid < kSumItems) {
+      const f32x4 v = slab_quads_sum<MR>(p.o_slabs, p.o_k_slices, (int)zs, min(r0 + (tid >> 5 & (MR - 1)), B - 1), tid, part4);
+      if (tid < (MR * (kMH / 4))) {
         const int r = tid >> 5, c4 = (tid & 31) * 4;
         const bool ok = r0 + r < B;
         const float h0 = ok ? tanhf(v.x) : 0.f, h1v = ok ? tanhf(v.y) : 0.f;
@@ -1203,7 +1215,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         acc = mfma16(a4.z, w2f[4 * tt + 2], acc);
         acc = mfma16(a4.w, w2f[4 * tt + 3], acc);
       }
-      if (4 * g < kMR) {
+      if (4 * g < MR) {
         const int n = 16 * w + c16;
         const float bias = b2s[n];
 #pragma unroll
@@ -1224,7 +1236,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       if (tid == 0) flag_raise(p.flag_h2, o, epoch);
       if (w == 0) flags_wait(p.flag_o, p.n_hb, epoch, lane, flagp);
       __syncthreads();
-      for (int idx = tid; idx < kMR * Nh16; idx += kMT) {
+      for (int idx = tid; idx < MR * Nh16; idx += kMT) {
         const int r = idx / Nh16, j = idx - r * Nh16;
         const bool ok = j < Nh && r0 + r < B;
         const float v = ok ? xwg_load(p.o_wide + ((int64_t)(j >> 5) * B + r0 + r) * kMNB + (j & 31)) : 0.f;
@@ -1248,7 +1260,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         acc = mfma16(a4.z, b4.z, acc);
         acc = mfma16(a4.w, b4.w, acc);
       }
-      if (4 * g < kMR) {
+      if (4 * g < MR) {
         const float bias = bhs[n];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1292,7 +1304,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     __syncthreads();
     if (tid == 0) {
       float sl = 0.f, su = 0.f;
-      for (int q = 0; q < kMR; ++q) { sl += red[16 + q]; su += red[32 + q]; }
+      for (int q = 0; q < MR; ++q) { sl += red[16 + q]; su += red[32 + q]; }
       granule_publish(p.gran + kGranArr, o, tag + 2, su);
       granule_publish(p.gran + 2 * kGranArr, o, tag + 3, sl);
     }
@@ -1343,7 +1355,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       if (tid == 0) flag_raise(p.flag_dout, o, epoch);
       if (w == 0) flags_wait(p.flag_dz2, p.n_hb, epoch, lane, flagp);
       __syncthreads();
-      if (tid < kMR * 64) {
+      if (tid < MR * 64) {
         const int r = tid >> 6, c2 = (tid & 63) * 2;
         const float* src = p.dz2_part + (int64_t)min(r0 + r, B - 1) * kMH + c2;
         float vx = 0.f, vy = 0.f;
@@ -1382,7 +1394,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         acc = mfma16(a4.z, f2, acc);
         acc = mfma16(a4.w, f3, acc);
       }
-      if (4 * g < kMR) {
+      if (4 * g < MR) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rr = 4 * g + r;
@@ -1407,7 +1419,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         acc = mfma16(a4.z, w2b[4 * tt + 2], acc);
         acc = mfma16(a4.w, w2b[4 * tt + 3], acc);
       }
-      if (4 * g < kMR) {
+      if (4 * g < MR) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rr = 4 * g + r;
@@ -1446,6 +1458,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
 
 // fit_persistent_mdnn_stream.hip
 bool mdnn_stream_tile_geom(int FR, int chunks_per_wg, int S, int A, int* nip, int* pf, size_t* lds_bytes);
+int mdnn_stream_chunks(int input_dim);
 int mdnn_stream_launch(const MdnnArgs& p, bool dp, bool wide, bool full, int grid, size_t lds, hipStream_t st);
 
 }  // namespace bsig

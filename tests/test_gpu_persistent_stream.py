@@ -60,46 +60,70 @@ def _chunk(B, cfg, n=1000, batch=100, n_updates=100, seed=3, eps=0.0, env=None, 
 
 def _streams(B, bs):
     lib = B._lib.load()
-    return lib.bsig_fit_is_persistent(bs.model._plan) == 2 and lib.bsig_fit_accepts_factors(bs.model._plan) == 0
+    got = (lib.bsig_fit_is_persistent(bs.model._plan), lib.bsig_fit_accepts_factors(bs.model._plan))
+    assert got == (2, 0), got
+    return True
+
+
+def _oracles(bench, cfg, in_dim, w0, summ_cpu, theta, n_updates, ids, double):
+    o = bench.build_oracle(cfg, in_dim, 77, 0.0)
+    x, y = summ_cpu, theta.cpu()
+    if double:
+        o = o.double()
+        o.output_lows, o.output_highs = o.output_lows.double(), o.output_highs.double()
+        x, y = x.double(), y.double()
+    o.load_state_dict({k: (v.double() if double else v) for k, v in w0.items()})
+    return o.run_training(x, y, n_updates, 100, ids_table=ids), o
 
 
 def test_streamed_chunk_matches_oracle(B):
-    """Teacher-forced chunk (EPS_NOISE = 0, same start weights, same ids) from factor rows
-    against the fp32 oracle on the materialised summaries: all 6+6 losses within 1e-4."""
+    """Teacher-forced chunks (EPS_NOISE = 0, same start weights, same ids) from factor rows
+    against the fp32 oracle on the materialised summaries.  40 updates: every logged loss within
+    the north-star 1e-4, the weights within Adam-step noise.  100 updates: the first layer sums
+    15362 fp32 products per unit and two fp32 evaluation orders of this chunk part by ~1e-4 at
+    the end (like cfg3, tests/test_gpu_fit.py) -- there the yardstick is the chunk in fp64:
+    |hip - f64| <= |cpu_f32 - f64| + 1e-4 |f64| at every logging point."""
     import bench
     from oracle import summarize as osum
     cfg = _cfg(**SMALL)
     torch.set_num_threads(8)
-    logs, flat, bs, (theta, states, actions, ids) = _chunk(B, cfg)
-    assert _streams(B, bs)
-    ora = bench.build_oracle(cfg, bs.model.input_dim, 77, 0.0)
     bs0 = bench.build_gpu_model(B, cfg, DEV, 77)
-    ora.load_state_dict({kk: v.cpu() for kk, v in bs0.model.state_dict().items()})
-    ref = ora.run_training(osum.SUMMARIZERS[cfg['summarizer']](states.cpu(), actions.cpu()),
-                           theta.cpu(), 100, 100, ids_table=ids)
-    for key in ('train_loss', 'test_loss'):
-        got, exp = np.array(logs[key]), np.array(ref[key])
-        assert got.shape == exp.shape == (6,)
-        assert np.all(np.abs(got - exp) <= 1e-4 * np.maximum(np.abs(exp), 1.0)), (key, got, exp)
-    sd_ = bs.model.state_dict()
-    for name, v in ora.state_dict().items():
-        diff = (sd_[name].cpu() - v).abs()
-        assert int((diff > 2e-4 + 1e-3 * v.abs()).sum()) <= 30 and float(diff.max()) < 2.5e-3, name
+    w0 = {kk: v.cpu().clone() for kk, v in bs0.model.state_dict().items()}
+    for n_updates in (40, 100):
+        logs, flat, bs, (theta, states, actions, ids) = _chunk(B, cfg, n_updates=n_updates)
+        assert _streams(B, bs)
+        s_cpu = osum.SUMMARIZERS[cfg['summarizer']](states.cpu(), actions.cpu())
+        ref, ora = _oracles(bench, cfg, bs.model.input_dim, w0, s_cpu, theta, n_updates, ids, False)
+        if n_updates == 40:
+            for key in ('train_loss', 'test_loss'):
+                got, exp = np.array(logs[key]), np.array(ref[key])
+                assert got.shape == exp.shape == (6,)
+                assert np.all(np.abs(got - exp) <= 1e-4 * np.maximum(np.abs(exp), 1.0)), (key, got, exp)
+            sd_ = bs.model.state_dict()
+            for name, v in ora.state_dict().items():
+                diff = (sd_[name].cpu() - v).abs()
+                assert float(diff.mean()) < 2e-6 and float(diff.max()) < 2.5e-3, (name, diff.mean(), diff.max())
+        else:
+            r64, _ = _oracles(bench, cfg, bs.model.input_dim, w0, s_cpu, theta, n_updates, ids, True)
+            for key in ('train_loss', 'test_loss'):
+                h, a, r = (np.asarray(v[key], dtype=np.float64) for v in (logs, ref, r64))
+                assert (np.abs(h - r) <= np.abs(a - r) + 1e-4 * np.abs(r) + 1e-6).all(), (key, h - r, a - r)
 
 
 @pytest.mark.parametrize('eps', [0.0, 1e-5])
 def test_streamed_equals_phase_kernels(B, eps):
     """The same chunk through the streamed kernel (factor rows) and through the per-phase
-    kernels (materialised rows): same jitter streams, summation order differs."""
+    kernels (materialised rows): same jitter streams, summation order differs (40 updates:
+    before the two fp32 orders part)."""
     cfg = _cfg(**SMALL)
-    logs_s, flat_s, bs_s, _ = _chunk(B, cfg, eps=eps)
-    logs_k, flat_k, bs_k, _ = _chunk(B, cfg, eps=eps, env={'BSIG_NO_STREAMED_W1': '1'})
+    logs_s, flat_s, bs_s, _ = _chunk(B, cfg, eps=eps, n_updates=40)
+    logs_k, flat_k, bs_k, _ = _chunk(B, cfg, eps=eps, n_updates=40, env={'BSIG_NO_STREAMED_W1': '1'})
     assert _streams(B, bs_s)
     assert B._lib.load().bsig_fit_is_persistent(bs_k.model._plan) == 0
     for key in ('train_loss', 'test_loss'):
-        assert np.allclose(logs_s[key], logs_k[key], rtol=1e-4, atol=1e-4), (key, logs_s, logs_k)
+        assert np.allclose(logs_s[key], logs_k[key], rtol=2e-5, atol=2e-5), (key, logs_s, logs_k)
     assert torch.allclose(flat_s, flat_k, atol=2.5e-3, rtol=1e-2)
-    assert float((flat_s - flat_k).abs().mean()) < 1e-5
+    assert float((flat_s - flat_k).abs().mean()) < 2e-6
 
 
 def test_streamed_reruns_are_bitwise(B):
@@ -110,7 +134,7 @@ def test_streamed_reruns_are_bitwise(B):
     assert torch.equal(a[1], b[1])
 
 
-@pytest.mark.parametrize('n,batch,n_updates', [(1000, 64, 13), (1000, 7, 6), (60, 100, 5), (1000, 104, 7)])
+@pytest.mark.parametrize('n,batch,n_updates', [(1000, 64, 13), (1000, 33, 6), (60, 100, 5), (1000, 104, 7)])
 def test_streamed_ragged_shapes_match_phase_kernels(B, n, batch, n_updates):
     cfg = _cfg(**SMALL)
     logs_s, flat_s, bs_s, _ = _chunk(B, cfg, n=n, batch=batch, n_updates=n_updates)
@@ -119,7 +143,7 @@ def test_streamed_ragged_shapes_match_phase_kernels(B, n, batch, n_updates):
     assert _streams(B, bs_s)
     for key in ('train_loss', 'test_loss'):
         assert np.allclose(logs_s[key], logs_k[key], rtol=1e-4, atol=1e-4), (key, logs_s, logs_k)
-    assert float((flat_s - flat_k).abs().mean()) < 1e-5
+    assert float((flat_s - flat_k).abs().mean()) < 2e-6
 
 
 def test_streamed_wide_heads_match_phase_kernels(B):
@@ -130,7 +154,7 @@ def test_streamed_wide_heads_match_phase_kernels(B):
     assert _streams(B, bs_s)
     for key in ('train_loss', 'test_loss'):
         assert np.allclose(logs_s[key], logs_k[key], rtol=1e-4, atol=1e-4), (key, logs_s, logs_k)
-    assert float((flat_s - flat_k).abs().mean()) < 1e-5
+    assert float((flat_s - flat_k).abs().mean()) < 2e-6
 
 
 def test_streamed_plan_runs_summary_rows_through_phase_kernels(B):
@@ -187,7 +211,7 @@ def test_streamed_data_parallel_rank_matches_resident(B):
         assert _streams(B, bs)
         for key in ('train_loss', 'test_loss'):
             assert np.allclose(logs_s[key], logs_d[key], rtol=1e-4, atol=1e-4), (key, logs_s, logs_d)
-        assert float((flat_s - bs.model._flat).abs().mean()) < 1e-5
+        assert float((flat_s - bs.model._flat).abs().mean()) < 2e-6
     finally:
         if created:
             dist.destroy_process_group()
