@@ -199,6 +199,81 @@ def nll_check(pkg, cfg, theta, states, actions, device, lazy=True):
         pkg.MDNN.EPS_NOISE = old
 
 
+def nll_check_dp(pkg, cfg, theta, states, actions, device, dist, rank, world):
+    """COLLECTIVE (every rank calls it): the held-out NLL match of a data-parallel group.  Every
+    rank runs the first 1000-pair chunk of ITS pairs teacher-forced (EPS_NOISE = 0, its own id
+    table) through the data-parallel fit -- minibatch 100 per rank, gradient all-reduce through
+    the C ABI's RCCL communicator per update -- and rank 0 runs the oracle on the UNION: all
+    ranks' training rows, then all ranks' held-out rows, minibatch 100 x world from the
+    concatenated id tables (mdnn.py:204-242 with the exchange between :233 and :234)."""
+    from oracle import summarize as osum
+    old = pkg.MDNN.EPS_NOISE
+    pkg.MDNN.EPS_NOISE = 0.0
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    try:
+        m = min(1000, theta.shape[0])
+        n_train = max(int(m * 0.8), 1)
+        th, st, ac = theta[:m].contiguous(), states[:m].contiguous(), actions[:m].contiguous()
+        bs = build_gpu_model(pkg, cfg, device, 77)        # same seed on every rank: same start weights
+        w0 = {k: v.cpu().clone() for k, v in bs.model.state_dict().items()}
+        freqs = bs.model.rff.freqs.cpu().numpy() if cfg['model'] == 'MDRFF' else None
+        bs.model.enable_data_parallel()
+        ids = np.random.RandomState(5 + rank).randint(0, n_train, (100, 100))
+        got = bs.model.run_training(bs._summarize(st, ac, lazy=True), th, 100, 100, ids_table=ids)
+        parts = []
+        for t in (th, st, ac):
+            if dist.get_backend() != 'nccl':          # (gloo: the functional check on a shared GPU)
+                t = t.cpu()
+            buf = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(buf, t)
+            parts.append(buf)
+        if rank != 0:
+            return None
+        fn = osum.SUMMARIZERS[cfg['summarizer']]
+        summ = [fn(s_.cpu(), a_.cpu()) for s_, a_ in zip(parts[1], parts[2])]
+        ths = [t.cpu() for t in parts[0]]
+        x = torch.cat([s_[:n_train] for s_ in summ] + [s_[n_train:] for s_ in summ])
+        y = torch.cat([t[:n_train] for t in ths] + [t[n_train:] for t in ths])
+        ids_all = np.concatenate([np.random.RandomState(5 + r).randint(0, n_train, (100, 100)) + r * n_train
+                                  for r in range(world)], axis=1)
+        ora = build_oracle(cfg, x.shape[1], 77, 0.0, freqs=freqs)
+        ora.load_state_dict(w0)
+        if freqs is not None:
+            ora.rff.freqs = torch.from_numpy(freqs).to(ora.rff.freqs.dtype)
+        ref = ora.run_training(x, y, 100, 100 * world, ids_table=ids_all)
+        g, r = got['test_loss'][-1], ref['test_loss'][-1]
+        return {'heldout_nll_hip': g, 'heldout_nll_oracle': r,
+                'rel_diff': abs(g - r) / max(abs(r), 1e-12),
+                'max_rel_diff_all_logs': float(max(
+                    abs(a - b) / max(abs(b), 1e-12)
+                    for key in ('train_loss', 'test_loss') for a, b in zip(got[key], ref[key]))),
+                'protocol': 'first chunk of every rank (%d x %d pairs), 100 updates of minibatch 100 per rank '
+                            '(global %d) teacher-forced through the gradient all-reduce, EPS_NOISE=0; oracle on '
+                            'the union minibatch' % (world, m, 100 * world)}
+    finally:
+        pkg.MDNN.EPS_NOISE = old
+
+
+def largest_size_leg(pkg, cfg, device, n=1_000_000):
+    """BASELINE's largest size (config 5: 1M synthetic pairs) on ONE GPU: one BayesSim.fit over
+    n pairs of the bench config, timed like the headline (inputs resident, one fit)."""
+    theta, states, actions = synth_pairs(cfg, n, 4321, device)
+    bs = build_gpu_model(pkg, cfg, device, 1234)
+    np.random.seed(1234)
+    bs.fit(theta[:20_000], states[:20_000], actions[:20_000])         # plans, workspaces
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    logs = bs.fit(theta, states, actions)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {'pairs': n, 'seconds': dt, 'pairs_per_s': n / dt, 'chunks': len(logs),
+           'heldout_nll_last_chunk': float(logs[-1]['test_loss'][-1]),
+           'protocol': 'one BayesSim.fit over %d pairs of the bench config on one GPU (reference chunk protocol)' % n}
+    del bs, theta, states, actions
+    torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic(kernel_substr):
     """Per-launch HBM traffic of a kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_FETCH_SIZE.txt / *_pmc_WRITE_SIZE.txt, latest round):
@@ -661,6 +736,8 @@ def main():
     ap.add_argument('--no-scaled-batch', action='store_true')
     ap.add_argument('--only-scaled-batch', action='store_true',
                     help='run the scaled-batch mode alone (for profiling) and print its JSON')
+    ap.add_argument('--no-largest-size', action='store_true',
+                    help='skip the 1M-pair fit (BASELINE config 5 size) of the default 1-GPU line')
     ap.add_argument('--no-per-config', action='store_true',
                     help='skip the short fits of the other BASELINE-shaped configs')
     ap.add_argument('--variants', action='store_true',
@@ -752,6 +829,9 @@ def main():
     scaled_dp = None
     if dist is not None and not args.no_scaled_batch:
         scaled_dp = scaled_batch_dp(pkg, cfg, theta, states, actions, device, dist, world)
+    nll_dp = None
+    if dist is not None:
+        nll_dp = nll_check_dp(pkg, cfg, theta, states, actions, device, dist, rank, world)
     if rank == 0:
         out = {
             'metric': 'summary_vectors_per_sec_in_fit', 'value': value, 'unit': 'pairs/s',
@@ -783,6 +863,8 @@ def main():
         note('roofline done')
         if scaled_dp is not None:
             out['scaled_batch_mode'] = scaled_dp
+        if nll_dp is not None:
+            out['nll_match'] = nll_dp
         if world == 1:
             out['nll_match'] = nll_check(pkg, cfg, theta, states, actions, device)
             note('nll check done')
@@ -816,6 +898,12 @@ def main():
             if not args.no_per_config:
                 out['per_config'] = per_config_numbers(pkg, device, args.config)
                 note('per-config numbers done')
+            if not args.no_largest_size and not args.pairs and cfg['model'] == 'MDRFF':
+                del theta, states, actions
+                torch.cuda.empty_cache()
+                out['largest_size'] = largest_size_leg(pkg, cfg, device)
+                theta, states, actions = synth_pairs(cfg, 12000, 1234 + rank, device)
+                note('1M-pair fit done')
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(cfg, theta[:12000], states[:12000],
                                                    actions[:12000])

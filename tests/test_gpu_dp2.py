@@ -26,11 +26,11 @@ def _data(rank):
     return x, y, ids
 
 
-def _model(pkg, n_feat):
+def _model(pkg, n_feat, eps=0.0):
     torch.manual_seed(3)
     np.random.seed(3)
     pkg.MDNN.VERBOSE = False
-    pkg.MDNN.EPS_NOISE = 0.0
+    pkg.MDNN.EPS_NOISE = eps
     if n_feat == 'mdnn':
         return pkg.MDNN(input_dim=I, output_dim=D, output_lows=np.zeros(D),
                         output_highs=np.ones(D), n_gaussians=K, lr=2e-3,
@@ -41,13 +41,13 @@ def _model(pkg, n_feat):
                      n_feat=n_feat, sigma=3.0, device='cuda:0')
 
 
-def _worker(rank, world, port, out, n_feat):
+def _worker(rank, world, port, out, n_feat, eps=0.0):
     import sys
     sys.path.insert(0, ROOT)
     import bayes_sim_ig_amd as pkg
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    m = _model(pkg, n_feat).enable_data_parallel()
+    m = _model(pkg, n_feat, eps).enable_data_parallel()
     x, y, ids = _data(rank)
     logs = m.run_training(x.cuda(), y.cuda(), NU, B, test_frac=0.2, ids_table=ids)
     if rank == 0:
@@ -78,3 +78,28 @@ def test_two_rank_fit_equals_union_minibatch(tmp_path, n_feat):
     np.testing.assert_allclose(res['logs']['train_loss'], logs['train_loss'], rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(res['logs']['test_loss'], logs['test_loss'], rtol=2e-5, atol=1e-6)
     torch.testing.assert_close(res['flat'], m._flat.cpu(), rtol=1e-4, atol=1e-6)
+
+
+def test_two_rank_fit_with_rank_local_jitter_scale(tmp_path):
+    """EPS_NOISE = 1e-5 (the reference default): the jitter scale EPS_NOISE * mean(L_d) of mdnn.py:115
+    is taken over the rank's own 24 rows instead of the 48 of the union minibatch, and the ranks
+    draw their own noise.  Measured effect at R = 2 against the single-process fit on the union
+    minibatch (itself with jitter): every logged loss within the north-star 1e-4 (observed
+    ~1e-6: a 1e-5-relative perturbation of sigma either way)."""
+    import bayes_sim_ig_amd as pkg
+    out = str(tmp_path / 'dp2j.pt')
+    try:
+        mp.spawn(_worker, args=(2, 29700 + os.getpid() % 1000, out, 512, 1e-5), nprocs=2, join=True)
+        res = torch.load(out)
+        (x0, y0, i0), (x1, y1, i1) = _data(0), _data(1)
+        x = torch.cat([x0[:N_TRAIN], x1[:N_TRAIN], x0[N_TRAIN:], x1[N_TRAIN:]])
+        y = torch.cat([y0[:N_TRAIN], y1[:N_TRAIN], y0[N_TRAIN:], y1[N_TRAIN:]])
+        ids = np.concatenate([i0, i1 + N_TRAIN], axis=1)
+        m = _model(pkg, 512, 1e-5)
+        logs = m.run_training(x.cuda(), y.cuda(), NU, 2 * B, test_frac=0.2, ids_table=ids)
+    finally:
+        pkg.MDNN.EPS_NOISE = 1e-5
+    for key in ('train_loss', 'test_loss'):
+        got, exp = np.asarray(res['logs'][key]), np.asarray(logs[key])
+        print(key, 'max rel effect of rank-local jitter:', float(np.max(np.abs(got - exp) / np.abs(exp))))
+        np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-6)
