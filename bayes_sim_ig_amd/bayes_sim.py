@@ -128,6 +128,21 @@ class BayesSim(object):
         pre-recorded pairs: consecutive chunks of at most
         NUM_TRAIN_TRAJ_PER_BATCH pairs, ``run_training`` on each.
         Returns the list of per-chunk log dicts."""
+        dp = getattr(self.model, '_dp', None)
+        if dp is None and self.model._flat.is_cuda and self.model._may_time_out():
+            # the chunks' logs are read after the last chunk is enqueued: if a persistent launch
+            # turns out not to have had the GPU to itself (its bounded polls gave up), the whole
+            # loop is repeated from here on the per-phase kernels
+            from .mdnn import PersistentTimeout
+            snap = self.model._snapshot()
+            try:
+                return self._fit_once(params, traj_states, traj_actions)
+            except PersistentTimeout:
+                self.model._restore(snap)
+                self.model._disable_persistent()
+        return self._fit_once(params, traj_states, traj_actions)
+
+    def _fit_once(self, params, traj_states, traj_actions):
         n, done, pending = params.shape[0], 0, []
         dp = getattr(self.model, '_dp', None)
         if dp is not None:

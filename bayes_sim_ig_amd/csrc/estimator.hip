@@ -1136,5 +1136,10 @@ extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_upda
   return BSIG_OK;
 }
 
+// tests: keep `blocks` CUs busy (workgroups holding lds_bytes of LDS) for `ms` milliseconds
+extern "C" int bsig_debug_spin(int blocks, size_t lds_bytes, int ms, bsig_stream_t stream) {
+  return debug_spin(blocks, lds_bytes, ms, as_stream(stream));
+}
+
 // diagnostics (tools/persist_prof.py): phase time stamps of the persistent kernel
 extern "C" void bsig_debug_persist_profile(void* buffer) { persist_set_profile_buffer(buffer); }

@@ -836,8 +836,36 @@ static bool device_can_host(const PersistGeom& g) {
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-  return prop.multiProcessorCount >= g.G + g.n_owner &&
-         (size_t)prop.maxSharedMemoryPerMultiProcessor >= g.lds;
+  if (prop.multiProcessorCount < g.G + g.n_owner || (size_t)prop.maxSharedMemoryPerMultiProcessor < g.lds)
+    return false;
+  // ... and the runtime's own occupancy answer for this kernel at this LDS size must admit a
+  // workgroup per CU (registers, LDS, wave slots): the workgroups wait for each other, a grid
+  // the device cannot hold at once never finishes
+  int per_cu = 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_head_updates_kernel<false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, linear_head_updates_kernel<false>, kPT, g.lds) != hipSuccess)
+    return false;
+  return per_cu >= 1;
+}
+
+// (diagnostics / tests) occupy `blocks` CUs for `ms` milliseconds with workgroups that hold
+// `lds_bytes` of LDS each: a persistent launch behind it does not get all its workgroups resident
+__global__ void spin_kernel(long long ticks, int* sink) {
+  extern __shared__ float spin_lds[];
+  spin_lds[threadIdx.x] = 1.f;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+  if (spin_lds[threadIdx.x] == 2.f) sink[0] = 1;
+}
+int debug_spin(int blocks, size_t lds_bytes, int ms, hipStream_t st) {
+  BSIG_REQUIRE(blocks >= 1 && ms >= 0 && lds_bytes <= (size_t)kLdsLimit, "debug_spin: bad args");
+  BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spin_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds_bytes, 1024), st,
+                     (long long)ms * 100000LL /* 100 MHz wall clock */, (int*)nullptr);
+  BSIG_CHECK_LAUNCH("debug_spin");
+  return BSIG_OK;
 }
 
 bool persist_supported(const PersistShape& s) {

@@ -127,8 +127,16 @@ static bool mdnn_device_can_host(const MdnnGeom& g) {
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-  return prop.multiProcessorCount >= g.G1 + g.n_owner + g.n_small &&
-         (size_t)prop.maxSharedMemoryPerMultiProcessor >= g.lds;
+  if (prop.multiProcessorCount < g.G1 + g.n_owner + g.n_small || (size_t)prop.maxSharedMemoryPerMultiProcessor < g.lds)
+    return false;
+  // the runtime's own occupancy answer (registers, LDS, wave slots) must admit a workgroup per CU
+  int per_cu = 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdnn_updates_kernel<false, false, false, false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mdnn_updates_kernel<false, false, false, false>, kMT,
+                                                   std::min(g.lds, (size_t)kMLdsLimit)) != hipSuccess)
+    return false;
+  return per_cu >= 1;
 }
 
 bool persist_mdnn_supported(const PersistMdnnShape& s) {

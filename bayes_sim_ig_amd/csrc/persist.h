@@ -59,6 +59,8 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
 // diagnostics: [256][8][16] int64 wall-clock stamps of the first 8 updates of every
 // following launch (null: off)
 void persist_set_profile_buffer(void* buf);
+// (tests) occupy `blocks` CUs (workgroups holding lds_bytes of LDS) for `ms` milliseconds
+int debug_spin(int blocks, size_t lds_bytes, int ms, hipStream_t st);
 void* persist_profile_buffer();
 
 }  // namespace bsig

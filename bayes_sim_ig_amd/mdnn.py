@@ -42,6 +42,13 @@ def _on_model_device(fn):
     return wrapped
 
 
+class PersistentTimeout(RuntimeError):
+    """A bounded cross-workgroup poll of a persistent update kernel gave up: its workgroups (one
+    per CU) were not all resident -- the GPU is shared or partitioned.  The call's parameters and
+    Adam moments are partially updated; MDNN.run_training / BayesSim.fit catch this, restore the
+    state they saved at the start and repeat the work on the per-phase kernels."""
+
+
 class PendingLogs:
     """The 6+6 losses and the non-finite flag of one run_training call, still on
     the device; ``result()`` is the call's single host read-back.  BayesSim.fit
@@ -64,11 +71,11 @@ class PendingLogs:
         else:
             train_list, test_list, bad = host[:n_e], host[n_e:2 * n_e], host[2 * n_e]
         if int(bad) & 2:      # a bounded cross-workgroup poll of the persistent kernel gave up
-            raise RuntimeError('persistent update kernel timed out waiting for another workgroup: its '
-                               'workgroups (one per CU) were not all resident -- is the GPU shared with '
-                               'another process or partitioned?  The parameters and Adam moments of this '
-                               'call are partially updated (reload them before training on); set '
-                               'BSIG_NO_PERSISTENT=1 to use the per-phase kernels')
+            raise PersistentTimeout('persistent update kernel timed out waiting for another workgroup: its '
+                                    'workgroups (one per CU) were not all resident -- is the GPU shared with '
+                                    'another process or partitioned?  The parameters and Adam moments of this '
+                                    'call are partially updated; set BSIG_NO_PERSISTENT=1 to use the '
+                                    'per-phase kernels')
         assert bad == 0, 'non-finite value in forward / loss (mdnn.py:120-124,162-174)'
         if self.n_test == 0:
             test_list = [float('nan')] * n_e   # mean over an empty test split
@@ -249,6 +256,23 @@ class MDNN(nn.Module):
         except Exception:
             pass
 
+    # ---- robustness of the persistent launches: every workgroup of such a launch must be resident
+    #      at once; when the GPU turns out to be shared, the bounded polls give up and the call is
+    #      repeated from a snapshot on the per-phase kernels
+    def _snapshot(self):
+        """(parameters, Adam moments, numpy / torch RNG states) as of now."""
+        return (self._flat.clone(), self._exp_avg.clone(), self._exp_avg_sq.clone(),
+                np.random.get_state(), torch.get_rng_state())
+
+    def _restore(self, snap):
+        self._flat.copy_(snap[0]); self._exp_avg.copy_(snap[1]); self._exp_avg_sq.copy_(snap[2])
+        np.random.set_state(snap[3]); torch.set_rng_state(snap[4])
+
+    def _disable_persistent(self):
+        """From now on this model's plans use the per-phase kernels."""
+        self._no_persistent = True
+        self._drop_plan()
+
     def _gpu(self):
         lib = _lib.require_gpu()
         if not self._flat.is_cuda:
@@ -412,13 +436,37 @@ class MDNN(nn.Module):
     def _dp_sync_extra(self):
         """Replica state outside the flat parameter buffer (MDRFF: the RFF frequencies)."""
 
-    @_on_model_device
     def run_training(self, x_data, y_data, n_updates, batch_size, test_frac=0.2,
                      ids_table=None, _defer=False, _feats=None):
         """Reference mdnn.py:180-243.  Returns {'train_loss': [...],
         'test_loss': [...]} with the same 6 logging points.  ``ids_table``
         [n_updates, batch] (optional) overrides the numpy-RNG minibatch draw
         (teacher forcing for parity tests)."""
+        if _defer or self._dp is not None or not self._flat.is_cuda:
+            # (deferred logs: the caller -- BayesSim.fit -- holds the snapshot and repeats its loop)
+            return self._run_training_once(x_data, y_data, n_updates, batch_size, test_frac,
+                                           ids_table, _defer, _feats)
+        snap = self._snapshot() if self._may_time_out() else None
+        try:
+            return self._run_training_once(x_data, y_data, n_updates, batch_size, test_frac,
+                                           ids_table, False, _feats)
+        except PersistentTimeout:
+            if snap is None:
+                raise
+            self._restore(snap)
+            self._disable_persistent()
+            return self._run_training_once(x_data, y_data, n_updates, batch_size, test_frac,
+                                           ids_table, False, _feats)
+
+    def _may_time_out(self):
+        """Could the next call run a persistent kernel?  (Unknown before the first plan exists.)"""
+        if getattr(self, '_no_persistent', False) or os.environ.get('BSIG_NO_PERSISTENT') == '1':
+            return False
+        return self._plan is None or bool(_lib.load().bsig_fit_is_persistent(self._plan))
+
+    @_on_model_device
+    def _run_training_once(self, x_data, y_data, n_updates, batch_size, test_frac=0.2,
+                           ids_table=None, _defer=False, _feats=None):
         assert x_data.shape[0] == y_data.shape[0]
         lib = self._gpu()
         self.train()
@@ -436,8 +484,18 @@ class MDNN(nn.Module):
             if self._plan:
                 lib.bsig_fit_destroy(self._plan)
             handle = C.c_void_p()
-            _lib.check(lib.bsig_fit_create_sized(C.byref(cfg), batch_size, key[7], key[1],
-                                                 n_updates, C.byref(handle)))
+            old_env = os.environ.get('BSIG_NO_PERSISTENT')
+            if getattr(self, '_no_persistent', False):
+                os.environ['BSIG_NO_PERSISTENT'] = '1'      # (read when the plan is created)
+            try:
+                _lib.check(lib.bsig_fit_create_sized(C.byref(cfg), batch_size, key[7], key[1],
+                                                     n_updates, C.byref(handle)))
+            finally:
+                if getattr(self, '_no_persistent', False):
+                    if old_env is None:
+                        os.environ.pop('BSIG_NO_PERSISTENT', None)
+                    else:
+                        os.environ['BSIG_NO_PERSISTENT'] = old_env
             self._plan, self._plan_key = handle, key
             self._bufs['cap_test'], self._bufs['cap_train'] = key[1], key[7]
         # a cross-correlation summary may arrive as factor rows (summarizers.CrossCorrFactors):

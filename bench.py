@@ -866,7 +866,8 @@ def main():
         if nll_dp is not None:
             out['nll_match'] = nll_dp
         if world == 1:
-            out['nll_match'] = nll_check(pkg, cfg, theta, states, actions, device)
+            if nll_dp is None:
+                out['nll_match'] = nll_check(pkg, cfg, theta, states, actions, device)
             note('nll check done')
             if not args.no_scaled_batch and scaled_dp is None:
                 out['scaled_batch_mode'] = scaled_batch(pkg, cfg, theta, states, actions, device)

@@ -401,6 +401,11 @@ int bsig_fit_run_dp(bsig_fit_plan* plan, bsig_comm* comm, int64_t n_updates,
  * persistent update kernel (first 8 updates of every later launch); NULL = off.
  * tools/persist_prof.py prints the phase breakdown. */
 void bsig_debug_persist_profile(void* device_buffer);
+/* Tests: occupy `blocks` CUs for `ms` milliseconds with workgroups that hold `lds_bytes` of LDS
+ * each, so that a persistent update launch behind it cannot get all its workgroups resident
+ * (its bounded polls then time out: bit 1 of the state block's flag word; the Python mirror
+ * restores the call's start state and repeats it on the per-phase kernels). */
+int bsig_debug_spin(int blocks, size_t lds_bytes, int ms, bsig_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -235,3 +235,41 @@ def test_in_launch_evaluations_equal_the_evaluation_graphs(B, eps, n, batch, n_u
     assert len(a[0]['test_loss']) == len(b[0]['test_loss'])
     assert np.allclose(a[0]['test_loss'], b[0]['test_loss'], rtol=2e-6, atol=2e-6), (a[0], b[0])
     assert torch.equal(a[1], b[1])
+
+
+def test_time_out_is_recovered_on_the_phase_kernels(B):
+    """A persistent launch needs every workgroup resident at once.  With 200 of the 256 CUs held by another
+    kernel (bsig_debug_spin on a side stream, 1.5 s) its bounded polls give up and raise bit 1 of
+    the flag word; BayesSim.fit then restores the parameters / Adam moments / RNG states it saved
+    at its start and repeats the loop on the per-phase kernels: the result is bit for bit the
+    per-phase fit (BSIG_NO_PERSISTENT=1), not a partially updated model."""
+    import os
+    import bench
+    cfg = dict(task='synthetic', model='MDRFF', summarizer='summary_start', t=11, sd=5, ad=2,
+               d=3, k=4, hidden=[], n_feat=512, pairs=2000)
+    theta, states, actions = bench.synth_pairs(cfg, 2000, 3, DEV)
+    lib = B._lib.load()
+    # reference: the per-phase kernels
+    os.environ['BSIG_NO_PERSISTENT'] = '1'
+    try:
+        ref = bench.build_gpu_model(B, cfg, DEV, 77)
+        np.random.seed(11); torch.manual_seed(11)
+        ref_logs = ref.fit(theta, states, actions)
+    finally:
+        os.environ.pop('BSIG_NO_PERSISTENT', None)
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    np.random.seed(11); torch.manual_seed(11)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    import ctypes as C
+    B._lib.check(lib.bsig_debug_spin(200, 120 * 1024, 1500, C.c_void_p(side.cuda_stream)))
+    logs = bs.fit(theta, states, actions)
+    torch.cuda.synchronize()
+    assert getattr(bs.model, '_no_persistent', False), 'the launch was expected to time out'
+    assert lib.bsig_fit_is_persistent(bs.model._plan) == 0
+    assert [lg['test_loss'] for lg in logs] == [lg['test_loss'] for lg in ref_logs]
+    assert torch.equal(bs.model._flat, ref.model._flat)
+    # and a model that is not disturbed keeps the persistent kernel
+    ok = bench.build_gpu_model(B, cfg, DEV, 77)
+    ok.fit(theta, states, actions)
+    assert lib.bsig_fit_is_persistent(ok.model._plan) == 1 and not getattr(ok.model, '_no_persistent', False)
