@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/bsig.h"
 
@@ -15,6 +16,42 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+}  // namespace bsig
+
+// ---- roctx ranges (the reference has no tracing; rocprofv3 --marker-trace
+//      shows these around the summarizer / projection / update-launch / all-reduce entry points).
+//      Bound at run time: rocprofiler-sdk's roctx when a profiler carries it, else roctracer's;
+//      without either the ranges are no-ops.
+#include <dlfcn.h>
+#include <mutex>
+namespace bsig {
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_push = nullptr;
+roctx_pop_fn g_pop = nullptr;
+std::once_flag g_roctx_once;
+void load_roctx() {
+  const char* off = getenv("BSIG_NO_ROCTX");
+  if (off && off[0] == '1') return;
+  const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+  for (const char* n : names) {
+    void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) continue;
+    g_push = reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA"));
+    g_pop = reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop"));
+    if (g_push && g_pop) return;
+    g_push = nullptr; g_pop = nullptr;
+  }
+}
+}  // namespace
+void range_push(const char* name) {
+  std::call_once(g_roctx_once, load_roctx);
+  if (g_push) (void)g_push(name);
+}
+void range_pop() {
+  if (g_pop) (void)g_pop();
 }
 }  // namespace bsig
 

@@ -168,6 +168,7 @@ extern "C" int bsig_comm_world(const bsig_comm* c) { return c ? c->world : 0; }
 extern "C" int bsig_comm_rank(const bsig_comm* c) { return c ? c->rank : -1; }
 
 extern "C" int bsig_comm_allreduce(bsig_comm* c, float* buf, int64_t n, bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_comm_allreduce");
   BSIG_REQUIRE(c && buf && n >= 0, "comm_allreduce: bad args");
   if (n == 0) return BSIG_OK;
   if (c->external) {

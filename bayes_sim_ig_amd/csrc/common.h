@@ -16,6 +16,16 @@ void set_error(const char* fmt, ...);
 
 inline hipStream_t as_stream(bsig_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// roctx range around a C-ABI entry point (api.cpp: bound at run time, a no-op without roctx)
+void range_push(const char* name);
+void range_pop();
+struct Range {
+  explicit Range(const char* name) { range_push(name); }
+  ~Range() { range_pop(); }
+  Range(const Range&) = delete;
+  Range& operator=(const Range&) = delete;
+};
+
 // Report a launch failure without synchronising (works under stream capture).
 #define BSIG_CHECK_LAUNCH(what)                                              \
   do {                                                                       \

@@ -872,6 +872,7 @@ extern "C" int bsig_fit_set_features(bsig_fit_plan* p, const float* feats, int64
 
 extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batch,
                               bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_fit_begin");
   BSIG_REQUIRE(p && p->bound, "fit_begin: plan not bound");
   BSIG_REQUIRE(norm_batch >= 1, "fit_begin: norm_batch must be >= 1");
   if (norm_batch != p->norm_batch) { drop_graphs(p); p->norm_batch = norm_batch; }
@@ -985,6 +986,7 @@ extern "C" int bsig_fit_flush(bsig_fit_plan* p, bsig_stream_t stream) {
 }
 
 extern "C" int bsig_fit_eval(bsig_fit_plan* p, bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_fit_eval");
   BSIG_REQUIRE(p && p->bound, "fit_eval: plan not bound");
   if (const int total = dp_eval_total(p)) {
     // evaluations inside the launches: all but the last are already under way
@@ -1029,6 +1031,7 @@ static int enqueue_updates(bsig_fit_plan* p, int64_t n, hipStream_t st) {
 }
 
 extern "C" int bsig_fit_updates(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_fit_updates");
   BSIG_REQUIRE(p && p->bound, "fit_updates: plan not bound");
   BSIG_REQUIRE(n_updates >= 0 && n_updates <= p->n_updates,
                "fit_updates: n_updates %lld exceeds the plan's %lld", (long long)n_updates,
@@ -1038,6 +1041,7 @@ extern "C" int bsig_fit_updates(bsig_fit_plan* p, int64_t n_updates, bsig_stream
 }
 
 extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_fit_run");
   BSIG_REQUIRE(p && p->bound, "fit_run: plan not bound");
   BSIG_REQUIRE(n_updates >= 0 && n_updates <= p->n_updates,
                "fit_run: n_updates %lld exceeds the plan's %lld", (long long)n_updates,
@@ -1108,6 +1112,7 @@ __global__ void pack_dp_logs_kernel(const float* train_loss, const float* test_l
 
 extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates,
                                float* reduced_logs, bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_fit_run_dp");
   BSIG_REQUIRE(p && p->bound && p->split_adam, "fit_run_dp: plan not bound with SPLIT_ADAM");
   BSIG_REQUIRE(comm, "fit_run_dp: null communicator");
   BSIG_REQUIRE(n_updates >= 0 && n_updates <= p->n_updates,

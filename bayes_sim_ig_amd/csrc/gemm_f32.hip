@@ -279,6 +279,7 @@ extern "C" int bsig_rff_project(const float* x, int64_t ldx, const int32_t* x_ro
                                 int64_t in_dim, int64_t m_feat, float a, int cos_only,
                                 void* workspace, size_t workspace_bytes,
                                 bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_rff_project");
   BSIG_REQUIRE(!(cos_only && !offset), "rff_project: cos-only features need an offset");
   return gemm_f32(x, ldx, 0, x_rows, coeff, ld_coeff, 0, nullptr, feats, ld_feats, batch,
                   m_feat, in_dim, cos_only ? BSIG_EPI_COS_OFF : BSIG_EPI_COS_SIN, 0, offset,

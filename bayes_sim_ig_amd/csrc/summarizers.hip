@@ -423,6 +423,7 @@ extern "C" int64_t bsig_summary_dim(int kind, int traj_len, int sd, int ad, int 
 extern "C" int bsig_summary_start(const float* states, const float* actions, float* out,
                                   int64_t n, int t_states, int t_actions, int sd, int ad,
                                   int max_t, int64_t ld_out, bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_summary_start");
   if (n == 0) return BSIG_OK;
   BSIG_REQUIRE(states && actions && out, "summary_start: null pointer");
   BSIG_REQUIRE(n >= 0 && t_states >= 1 && t_actions >= 1 && sd >= 1 && ad >= 1 && max_t >= 1,
@@ -504,6 +505,7 @@ extern "C" int bsig_crosscorr(const float* states, const float* actions, float* 
                               int64_t n, int t_states, int t_actions, int sd, int ad,
                               int use_state_diff, int64_t ld_out, int32_t* nonfinite,
                               bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_crosscorr");
   if (n == 0) return BSIG_OK;
   BSIG_REQUIRE(out, "crosscorr: null pointer");
   return crosscorr_launch(states, actions, out, ld_out, nullptr, 0, n, t_states, t_actions, sd, ad,
@@ -523,6 +525,7 @@ extern "C" int bsig_crosscorr_factors(const float* states, const float* actions,
                                       int64_t n, int t_states, int t_actions, int sd, int ad,
                                       int use_state_diff, int64_t ld_factors, int32_t* nonfinite,
                                       bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_crosscorr_factors");
   if (n == 0) return BSIG_OK;
   BSIG_REQUIRE(factors, "crosscorr_factors: null pointer");
   return crosscorr_launch(states, actions, nullptr, 0, factors, ld_factors, n, t_states, t_actions,
@@ -546,6 +549,7 @@ extern "C" int bsig_crosscorr_expand(const float* factors, int64_t ld_factors, i
 extern "C" int bsig_signature(const float* states, const float* actions, float* out,
                               int64_t n, int length, int sd, int ad, int depth,
                               int64_t ld_out, bsig_stream_t stream) {
+  bsig::Range roctx_range("bsig_signature");
   if (n == 0) return BSIG_OK;
   BSIG_REQUIRE(states && actions && out, "signature: null pointer");
   BSIG_REQUIRE(n >= 0 && length >= 2 && sd >= 1 && ad >= 1,
