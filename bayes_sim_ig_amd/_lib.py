@@ -112,7 +112,9 @@ _PROTOS = {
     'bsig_comm_unique_id': (C.c_int, [vp]),
     'bsig_comm_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     'bsig_comm_init_external': (C.c_int, [C.c_int, C.c_int, vp, vp, C.POINTER(vp)]),
+    'bsig_comm_transport': (C.c_int, [vp]),
     'bsig_comm_world': (C.c_int, [vp]),
+    'bsig_fit_dp_graph_status': (C.c_int, [vp, C.c_char_p, sz]),
     'bsig_comm_rank': (C.c_int, [vp]),
     'bsig_comm_allreduce': (C.c_int, [vp, vp, i64, vp]),
     'bsig_comm_broadcast': (C.c_int, [vp, vp, i64, C.c_int, vp]),

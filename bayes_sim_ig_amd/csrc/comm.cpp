@@ -164,6 +164,7 @@ extern "C" int bsig_comm_init_external(int world, int rank, bsig_exchange_fn exc
   return BSIG_OK;
 }
 
+extern "C" int bsig_comm_transport(const bsig_comm* c) { return !c ? 0 : (c->external ? 2 : 1); }
 extern "C" int bsig_comm_world(const bsig_comm* c) { return c ? c->world : 0; }
 extern "C" int bsig_comm_rank(const bsig_comm* c) { return c ? c->rank : -1; }
 

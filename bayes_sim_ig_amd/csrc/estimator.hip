@@ -380,6 +380,11 @@ struct bsig_fit_plan {
   hipStream_t cap_stream;
   hipGraphExec_t g_step, g_grad, g_apply, g_eval;
   const float* graph_feats;    // the feature block the captured graphs read (kernel argument)
+  // data-parallel rank in the persistent kernel of the linear heads: one steady-state update
+  // (launch with the pending Adam step -> ncclAllReduce of the gradients) as ONE graph
+  hipGraphExec_t g_dp; const bsig_comm* g_dp_comm;
+  int g_dp_state;              // 0: not tried, 1: captured, -1: capture failed (g_dp_error), -2: not applicable
+  char g_dp_error[200];
 };
 
 namespace bsig {
@@ -586,9 +591,10 @@ static int enqueue_hoisted_rff(bsig_fit_plan* p, hipStream_t st) {
 }
 
 static void drop_graphs(bsig_fit_plan* p) {
-  hipGraphExec_t* gs[4] = {&p->g_step, &p->g_grad, &p->g_apply, &p->g_eval};
+  hipGraphExec_t* gs[5] = {&p->g_step, &p->g_grad, &p->g_apply, &p->g_eval, &p->g_dp};
   for (auto g : gs)
     if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+  p->g_dp_state = 0; p->g_dp_comm = nullptr;
 }
 
 template <typename F>
@@ -1110,6 +1116,53 @@ __global__ void pack_dp_logs_kernel(const float* train_loss, const float* test_l
 }
 }  // namespace bsig
 
+// A steady-state update of a data-parallel rank whose updates run in the persistent kernel of the
+// linear heads -- the launch that takes the pending Adam step and writes this update's gradients,
+// then RCCL's all-reduce of the flat gradient buffer -- captured into ONE HIP graph (SURVEY.md
+// 8(e)).  Nothing in the launch's arguments changes from update to update (everything per-step is
+// resolved on the device).  BSIG_DP_GRAPH=0 keeps the direct calls; a failed capture is recorded
+// (bsig_fit_dp_graph_status) and the direct calls are used.
+static int ensure_dp_graph(bsig_fit_plan* p, bsig_comm* comm) {
+  if (p->g_dp_state == 1 && p->g_dp_comm == comm) return BSIG_OK;
+  if (p->g_dp_state < 0 && p->g_dp_comm == comm) return BSIG_OK;
+  if (p->g_dp) { (void)hipGraphExecDestroy(p->g_dp); p->g_dp = nullptr; }
+  p->g_dp_comm = comm; p->g_dp_error[0] = 0;
+  const char* env = getenv("BSIG_DP_GRAPH");
+  if (!p->use_graph || !p->persistent || bsig_comm_transport(comm) != 1 || !(env && env[0] == '1')) {
+    p->g_dp_state = -2;
+    snprintf(p->g_dp_error, sizeof(p->g_dp_error), "%s",
+             !(env && env[0] == '1') ? "not requested (BSIG_DP_GRAPH=1)" :
+             bsig_comm_transport(comm) != 1 ? "the exchange is not RCCL" : "the plan's updates are not one launch each");
+    return BSIG_OK;
+  }
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed);
+  int rc = BSIG_OK;
+  if (e == hipSuccess) {
+    p->adam_pending = true;
+    rc = enqueue_persistent(p, 1, p->cap_stream, dp_eval_total(p));
+    if (rc == BSIG_OK) rc = bsig_comm_allreduce(comm, p->buf.grads, p->L.total, reinterpret_cast<bsig_stream_t>(p->cap_stream));
+    e = hipStreamEndCapture(p->cap_stream, &graph);
+  }
+  if (e == hipSuccess && rc == BSIG_OK) e = hipGraphInstantiate(&p->g_dp, graph, nullptr, nullptr, 0);
+  if (graph) (void)hipGraphDestroy(graph);
+  if (e != hipSuccess || rc != BSIG_OK || !p->g_dp) {
+    snprintf(p->g_dp_error, sizeof(p->g_dp_error), "capture of launch + ncclAllReduce failed: %s",
+             rc != BSIG_OK ? bsig_last_error() : hipGetErrorString(e));
+    (void)hipGetLastError();
+    p->g_dp = nullptr; p->g_dp_state = -1;
+    return BSIG_OK;
+  }
+  p->g_dp_state = 1;
+  return BSIG_OK;
+}
+
+extern "C" int bsig_fit_dp_graph_status(const bsig_fit_plan* p, char* msg, size_t msg_bytes) {
+  if (!p) return 0;
+  if (msg && msg_bytes) snprintf(msg, msg_bytes, "%s", p->g_dp_error);
+  return p->g_dp_state;
+}
+
 extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates,
                                float* reduced_logs, bsig_stream_t stream) {
   bsig::Range roctx_range("bsig_fit_run_dp");
@@ -1124,10 +1177,19 @@ extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_upda
   if (p->use_graph) BSIG_TRY(ensure_graphs(p));
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
   int64_t n_evals = 0;
+  const bool was_pending = p->adam_pending;
+  BSIG_TRY(ensure_dp_graph(p, comm));
+  p->adam_pending = was_pending;
   for (int64_t it = 0; it < n_updates; ++it) {
-    BSIG_TRY(bsig_fit_grad(p, stream));
-    BSIG_TRY(bsig_comm_allreduce(comm, p->buf.grads, p->L.total, stream));
-    BSIG_TRY(bsig_fit_apply(p, stream));
+    if (p->g_dp_state == 1 && p->adam_pending) {
+      // steady state: the captured launch (pending Adam step in, gradients out) + all-reduce
+      BSIG_HIP(hipGraphLaunch(p->g_dp, as_stream(stream)));
+      p->adam_pending = true;
+    } else {
+      BSIG_TRY(bsig_fit_grad(p, stream));
+      BSIG_TRY(bsig_comm_allreduce(comm, p->buf.grads, p->L.total, stream));
+      BSIG_TRY(bsig_fit_apply(p, stream));
+    }
     if (it % every == 0 || it + 1 == n_updates) { BSIG_TRY(bsig_fit_eval(p, stream)); ++n_evals; }
   }
   BSIG_TRY(bsig_fit_flush(p, stream));

@@ -317,19 +317,40 @@ DP_LOOP_US = {}
 def time_dp_loop(pkg, bsim):
     """COLLECTIVE (every rank calls it): the data-parallel update loop as the fit runs it,
     bsig_fit_run_dp = per update one launch + the all-reduce of the flat gradient buffer
-    (+ the held-out evaluations), enqueued from C; HIP events on the fit's stream."""
+    (+ the held-out evaluations), enqueued from C; HIP events on the fit's stream.  Twice: as
+    direct calls, and with the steady-state update (launch + ncclAllReduce) captured into ONE HIP
+    graph (BSIG_DP_GRAPH=1; the capture's outcome is reported with the time)."""
     lib, L, m = pkg._lib.load(), pkg._lib, bsim.model
     plan, st, stream = m._plan, pkg._lib.stream(), torch.cuda.current_stream()
     n_updates, batch, reps = 100, 100, 3
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for rep in range(reps + 1):
-        if rep == 1:
-            e0.record(stream)
-        L.check(lib.bsig_fit_begin(plan, 99 + rep, batch * m._dp.world, st))
-        L.check(lib.bsig_fit_run_dp(plan, m._dp.comm, n_updates, None, st))
-    e1.record(stream)
+    old = os.environ.get('BSIG_DP_GRAPH')
+    for mode in ('0', '1'):
+        os.environ['BSIG_DP_GRAPH'] = mode
+        # (another norm_batch drops the plan's graphs: the capture decision is taken again)
+        L.check(lib.bsig_fit_begin(plan, 98, batch * m._dp.world + 1, st))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(reps + 1):
+            if rep == 1:
+                e0.record(stream)
+            L.check(lib.bsig_fit_begin(plan, 99 + rep, batch * m._dp.world, st))
+            L.check(lib.bsig_fit_run_dp(plan, m._dp.comm, n_updates, None, st))
+        e1.record(stream)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (reps * n_updates)
+        if mode == '0':
+            DP_LOOP_US['us'] = us
+        else:
+            msg = C.create_string_buffer(256)
+            state = int(lib.bsig_fit_dp_graph_status(plan, msg, 256))
+            DP_LOOP_US['graph'] = {'us_per_update_with_exchange': us,
+                                   'capture': {1: 'captured', 0: 'not tried', -1: 'failed', -2: 'not applicable'}[state],
+                                   'detail': msg.value.decode('utf-8', 'replace')}
+    if old is None:
+        os.environ.pop('BSIG_DP_GRAPH', None)
+    else:
+        os.environ['BSIG_DP_GRAPH'] = old
+    L.check(lib.bsig_fit_begin(plan, 98, batch * m._dp.world + 1, st))     # back to the direct calls
     torch.cuda.synchronize()
-    DP_LOOP_US['us'] = e0.elapsed_time(e1) * 1e3 / (reps * n_updates)
 
 
 def time_update_kernel(pkg, cfg, bsim, device):
@@ -405,6 +426,7 @@ def time_update_kernel(pkg, cfg, bsim, device):
             'traffic': traffic, 'traffic_source': tsrc, 'avg_us': us,
             'us_per_update': us * len(runs) / n_updates,
             'us_per_update_with_exchange': loop_us,
+            'exchange_in_hip_graph': DP_LOOP_US.get('graph'),
             'algorithmic': '2*2*F*Nh = %.3e flop per row visit x %d rows x %.1f updates%s = %.3e flop '
                            'per launch' % (per_visit, batch, float(n_updates) / len(runs),
                                            '' if dp else ' + 2*F*Nh x %d rows x %d evaluations'

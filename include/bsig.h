@@ -377,6 +377,8 @@ typedef int (*bsig_exchange_fn)(void* ctx, int op, float* buf, int64_t n, int ro
                                 bsig_stream_t stream);
 int bsig_comm_init_external(int world, int rank, bsig_exchange_fn exchange, void* ctx,
                             bsig_comm** comm);
+/* 1: RCCL (its collectives can be captured into a HIP graph), 2: a caller-supplied exchange, 0: null */
+int bsig_comm_transport(const bsig_comm* comm);
 int bsig_comm_world(const bsig_comm* comm);
 int bsig_comm_rank(const bsig_comm* comm);
 /* buf[n] (device, fp32) <- sum over ranks, in place, asynchronous on `stream`. */
@@ -396,6 +398,11 @@ void bsig_comm_destroy(bsig_comm* comm);
  * n_test | #ranks with the non-finite flag | #ranks with a poll time-out. */
 int bsig_fit_run_dp(bsig_fit_plan* plan, bsig_comm* comm, int64_t n_updates,
                     float* reduced_logs, bsig_stream_t stream);
+/* With BSIG_DP_GRAPH=1, bsig_fit_run_dp captures a steady-state update of a rank whose updates run
+ * in the persistent kernel of the linear heads (launch + ncclAllReduce of the gradients) into ONE
+ * HIP graph and replays it.  Returns 1: captured, 0: not tried yet, -1: the capture failed (the
+ * runtime's message in msg; the direct calls are used), -2: not applicable (msg says why). */
+int bsig_fit_dp_graph_status(const bsig_fit_plan* plan, char* msg, size_t msg_bytes);
 
 /* Diagnostics: device buffer of [256][8][16] int64 wall-clock stamps filled by the
  * persistent update kernel (first 8 updates of every later launch); NULL = off.
