@@ -446,9 +446,19 @@ def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp=False, n_eva
     if not dp:                                          # forward passes of the evaluations
         flops += (2.0 * i * h + 2.0 * h * h + 2.0 * h * nh) * n_test * n_evals
     ach = flops / (us * 1e-6) / 1e12
-    traffic, tsrc = pmc_traffic('mdnn_updates_kernel') if not dp else (None, None)
+    import bayes_sim_ig_amd as _pkg
+    _lib = _pkg._lib.load()
+    streamed = int(_lib.bsig_fit_is_persistent(m._plan)) == 2 and int(_lib.bsig_fit_accepts_factors(m._plan)) == 0
+    kname = 'mdnn_stream_updates_kernel' if streamed else 'mdnn_updates_kernel'
+    traffic, tsrc = pmc_traffic(kname) if not dp else (None, None)
+    if streamed and traffic is not None:
+        # a streamed plan splits a call into the runs between its held-out evaluations (6 launches of
+        # 1 + 20 + 20 + 20 + 20 + 19 updates): the counters are per launch, the figure per call
+        traffic *= 6.0
     return {'bound': 'mfma',
-            'kernel': 'mdnn_updates_kernel: persistent update kernel of the two-layer MDNN, '
+            'kernel': kname + (': persistent update kernel of the two-layer MDNN with a STREAMED first layer '
+                               '(W1 and its Adam moments cross HBM once per update), ' if streamed else
+                               ': persistent update kernel of the two-layer MDNN, ') +
                       'trunk %d-128-128, heads %d, minibatch %d, %s per launch: '
                       'forward, NLL fwd/bwd, backward, Adam%s'
                       % (i, nh, batch, ('%d updates + %d held-out evaluations of %d rows'
@@ -461,6 +471,8 @@ def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp=False, n_eva
             'algorithmic': '2*(2*I*128) + 3*(2*128*128) + 3*(2*128*Nh) = %.3e flop per row visit x %d '
                            'rows x %.1f updates = %.3e flop per launch'
                            % (per_visit, batch, float(n_updates) / len(runs), flops),
+            'hbm_algorithmic_bytes_per_update': 6.0 * 4.0 * i * h if streamed else None,
+            'hbm_achieved_gbs_streamed_w1': (6.0 * 4.0 * i * h) / (us * len(runs) / n_updates * 1e-6) / 1e9 if streamed else None,
             'note': 'latency-bound by design of the reference protocol (minibatch 100): each update '
                     'is a chain of cross-workgroup hand-offs (tiles -> row owners -> tiles) around '
                     '~8 us of fp32-MFMA work per CU; see DESIGN.md'}

@@ -31,13 +31,18 @@ run_pmc() {     # name, counter, program, args...
   python3 $R/tools/pmc_dump.py "$db" $OUT/${TAG}_${name}_pmc_$ctr.txt \
     "rocprofv3 --pmc $ctr --kernel-trace -- python $prog $*"
 }
-B5="--steps 1 --warmup 1 --no-cpu-baseline --no-scaled-batch --no-per-config"
+B5="--steps 1 --warmup 1 --no-cpu-baseline --no-scaled-batch --no-per-config --no-largest-size"
 run_stats cfg5 bench.py $B5
 run_stats cfg3 bench.py --config cfg3 --pairs 20000 $B5
 run_stats scaled bench.py --only-scaled-batch
 run_stats summarizers tools/summarizer_bench.py
+# first layers that do not fit the chip: the streamed kernel (cfg/anymal.yaml, cfg/shadow_hand_more.yaml)
+run_stats anymal bench.py --config anymal_yaml --pairs 5000 $B5
+run_stats shadow_more bench.py --config shadow_more --pairs 5000 $B5
 for c in FETCH_SIZE WRITE_SIZE; do
-  run_pmc cfg5 $c bench.py --pairs 5000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch --no-per-config
-  run_pmc cfg3 $c bench.py --config cfg3 --pairs 5000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch --no-per-config
+  run_pmc anymal $c bench.py --config anymal_yaml --pairs 2000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch --no-per-config --no-largest-size
+  run_pmc shadow_more $c bench.py --config shadow_more --pairs 2000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch --no-per-config --no-largest-size
+  run_pmc cfg5 $c bench.py --pairs 5000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch --no-per-config --no-largest-size
+  run_pmc cfg3 $c bench.py --config cfg3 --pairs 5000 --steps 1 --warmup 0 --no-cpu-baseline --no-scaled-batch --no-per-config --no-largest-size
   run_pmc summarizers $c tools/summarizer_bench.py
 done
