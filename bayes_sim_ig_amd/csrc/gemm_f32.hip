@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
 }
 
 enum { TILE_64 = 0, TILE_128 = 1, TILE_128x32 = 2, TILE_128x64 = 3, TILE_128x96 = 4,
-       TILE_96x128 = 5, N_TILES = 6 };
-static const int kTileM[N_TILES] = {64, 128, 128, 128, 128, 96};
-static const int kTileN[N_TILES] = {64, 128, 32, 64, 96, 128};
+       TILE_96x128 = 5, TILE_128x288 = 6, TILE_288x128 = 7, N_TILES = 8 };
+static const int kTileM[N_TILES] = {64, 128, 128, 128, 128, 96, 128, 288};
+static const int kTileN[N_TILES] = {64, 128, 32, 64, 96, 128, 288, 128};
 struct GemmPlan { int tile; int splits; int k_chunk; };
 
 static int env_int(const char* name, int dflt) {
@@ -80,19 +80,30 @@ static int env_int(const char* name, int dflt) {
 // 128 x 128 tiles).
 static bool plan_gemm_large(int64_t m, int64_t n, int64_t k, size_t ws_bytes, GemmPlan* pl) {
   if (!((m >= 4096 || k >= 4096) && m * n >= ((int64_t)1 << 20) && k >= 1024 && m > 128)) return false;
-  static const int cand[] = {TILE_128, TILE_128x96, TILE_96x128, TILE_128x64, TILE_64};
-  static const double cost[] = {1.00, 1.04, 1.04, 1.15, 1.40};   // per-flop cost of the tile shape
+  static const int cand[] = {TILE_128, TILE_128x96, TILE_96x128, TILE_128x64, TILE_64, TILE_128x288, TILE_288x128};
+  // per-flop cost of the tile shape (a whole-width tile streams the long operand once)
+  static const double cost[] = {1.00, 1.04, 1.04, 1.15, 1.40, 0.98, 0.98};
+  // (measured on the scaled-batch fit, tools/scaled_tile_ab.py / profiles/r03_scaled_tile_ab.txt: the
+  // whole-width tiles run the forward product at 0.52 and dW at 0.51-0.58 of the fp32 MFMA peak, no
+  // better than the 96-wide ones -- one wavefront per SIMD does not hide the operand latency -- so
+  // they stay opt-in: BSIG_GEMM_WIDE_TILE=1)
+  const bool wide_ok = env_int("BSIG_GEMM_WIDE_TILE", 0) != 0;
   double best = 0.0;
   int best_t = -1;
   int64_t best_tiles = 0;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 7; ++i) {
     const int t = cand[i];
+    if (!wide_ok && (t == TILE_128x288 || t == TILE_288x128)) continue;
     const int64_t tm = ceil_div<int64_t>(m, kTileM[t]), tn = ceil_div<int64_t>(n, kTileN[t]);
     const double padded = (double)(tm * kTileM[t]) * (double)(tn * kTileN[t]) * cost[i];
     if (best_t < 0 || padded < best) { best = padded; best_t = t; best_tiles = tm * tn; }
   }
   int64_t splits = 1;
-  if (best_tiles < 640) {
+  if (best_t == TILE_128x288 || best_t == TILE_288x128) {
+    // 60 KB of LDS and 9 accumulators per wave: at most two workgroups per CU -- one round of 256..512
+    splits = std::max<int64_t>(env_int("BSIG_GEMM_WIDE_WGS", 256) / best_tiles, 1);
+    splits = std::min<int64_t>(splits, std::max<int64_t>(k / (8 * BK), 1));
+  } else if (best_tiles < 640) {
     splits = ceil_div<int64_t>(768, best_tiles);
     splits = std::min<int64_t>(splits, std::max<int64_t>(k / (8 * BK), 1));
     splits = std::min<int64_t>(splits, 32);
@@ -190,6 +201,10 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     rc = launch_tile_128x96(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else if (pl.tile == TILE_96x128)
     rc = launch_tile_96x128(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
+  else if (pl.tile == TILE_128x288)
+    rc = launch_tile_128x288(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
+  else if (pl.tile == TILE_288x128)
+    rc = launch_tile_288x128(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else
     rc = launch_tile_64(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   if (rc != BSIG_OK) return rc;

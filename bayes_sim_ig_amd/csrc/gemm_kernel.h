@@ -652,8 +652,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   BSIG_TILE_EPILOGUE(2, 0)
   BSIG_TILE_EPILOGUE(2, 1)
   BSIG_TILE_EPILOGUE(2, 2)
+  // (one row or one column of up to nine tiles: the whole-width tiles 128 x 288 / 288 x 128)
+  BSIG_TILE_EPILOGUE(0, 3) BSIG_TILE_EPILOGUE(0, 4) BSIG_TILE_EPILOGUE(0, 5)
+  BSIG_TILE_EPILOGUE(0, 6) BSIG_TILE_EPILOGUE(0, 7) BSIG_TILE_EPILOGUE(0, 8)
+  BSIG_TILE_EPILOGUE(3, 0) BSIG_TILE_EPILOGUE(4, 0) BSIG_TILE_EPILOGUE(5, 0)
+  BSIG_TILE_EPILOGUE(6, 0) BSIG_TILE_EPILOGUE(7, 0) BSIG_TILE_EPILOGUE(8, 0)
 #undef BSIG_TILE_EPILOGUE
-  static_assert(TM <= 3 && TN <= 3, "extend the tile enumeration");
+  static_assert((TM <= 3 && TN <= 3) || (TM == 1 && TN <= 9) || (TN == 1 && TM <= 9), "extend the tile enumeration");
   if (p.expsum && p.splits == 1) {   // one partial per workgroup, fixed order
     const float s = block_sum(exp_acc, smem);
     if (tid == 0) p.expsum[blockIdx.y * gridDim.x + blockIdx.x] = s;
@@ -693,5 +698,7 @@ int launch_tile_128x32(const GemmParams& p, bool akm, bool bkm, int avec, int bv
 int launch_tile_128x64(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
 int launch_tile_128x96(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
 int launch_tile_96x128(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
+int launch_tile_128x288(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
+int launch_tile_288x128(const GemmParams& p, bool akm, bool bkm, int avec, int bvec, hipStream_t st);
 
 }  // namespace bsig

@@ -120,7 +120,26 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
     // streaming outer product
     const int64_t total = (int64_t)S * A;
     bool bad = in_bad;
-    if (vec4) {
+    if (vec4 && (A & 3) == 0 && A <= 4 * nt) {
+      // A thread keeps ONE quad of action features (columns 4 jq .. 4 jq + 3) in registers and walks
+      // down the state features: per 16-byte store one LDS broadcast read and four multiplies
+      // (the generic loop below spends ~30 instructions per store on index arithmetic and eight
+      // LDS reads).  Consecutive threads cover consecutive quads of a row, then the next row: the
+      // stores of a wavefront are one contiguous run.
+      const int qpr = A >> 2, rstep = nt / qpr;
+      const int jq = tid % qpr, r0 = tid / qpr;
+      if (r0 < rstep) {
+        const float4 a4 = *reinterpret_cast<const float4*>(af + 4 * jq);
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        f32x4_t* orow = reinterpret_cast<f32x4_t*>(o) + jq;
+        for (int i = r0; i < S; i += rstep) {
+          const float sv = sf[i];
+          const f32x4_t pk = {sv * a4.x, sv * a4.y, sv * a4.z, sv * a4.w};
+          if (check_each) bad |= !(isfinite(pk.x) && isfinite(pk.y) && isfinite(pk.z) && isfinite(pk.w));
+          __builtin_nontemporal_store(pk, orow + (int64_t)i * qpr);
+        }
+      }
+    } else if (vec4) {
       // rows are 16-B aligned (ld_out % 4 == 0): one float4 per lane
       const int64_t nvec = total >> 2;
       const int step_i = (4 * nt) / A, step_j = (4 * nt) % A;
@@ -265,7 +284,10 @@ __global__ void signature3_kernel(const float* __restrict__ states,
   const int dp = (d + 3) & ~3;                 // increment rows padded to float4
   float* path = smem;                          // [length * d]
   float* delta = smem + ((length * d + 3) & ~3);   // [(length-1) * dp], zero padded
-  float* stage = delta + (length - 1) * dp;    // [d*d*d]
+  // level-3 terms are staged at the same offset modulo 4 floats as they have in the output row
+  // (o + d + d*d): 16-byte chunks are then aligned on both sides
+  const int mis = (d + d * d) & 3;
+  float* stage = delta + (length - 1) * dp + mis;    // [d*d*d]
   const int tid = threadIdx.x, nt = blockDim.x;
   const int npairs = d * d;
   const int i = tid / d, j = tid % d;
@@ -330,7 +352,19 @@ __global__ void signature3_kernel(const float* __restrict__ states,
     __syncthreads();
     float* o3 = o + d + npairs;
     const int n3 = npairs * d;
-    for (int e = tid; e < n3; e += nt) __builtin_nontemporal_store(stage[e], o3 + e);
+    if ((ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+      // head up to the first 16-byte boundary, aligned quads, tail
+      const int head = min((4 - mis) & 3, n3);
+      const int nq = (n3 - head) >> 2;
+      if (tid < head) __builtin_nontemporal_store(stage[tid], o3 + tid);
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      const f32x4_t* sq = reinterpret_cast<const f32x4_t*>(stage + head);
+      f32x4_t* oq = reinterpret_cast<f32x4_t*>(o3 + head);
+      for (int q = tid; q < nq; q += nt) __builtin_nontemporal_store(sq[q], oq + q);
+      for (int e = head + 4 * nq + tid; e < n3; e += nt) __builtin_nontemporal_store(stage[e], o3 + e);
+    } else {
+      for (int e = tid; e < n3; e += nt) __builtin_nontemporal_store(stage[e], o3 + e);
+    }
   }
 }
 
@@ -566,7 +600,7 @@ extern "C" int bsig_signature(const float* states, const float* actions, float* 
       return BSIG_EUNSUPPORTED;
     }
     const size_t lds = ((size_t)((length * d + 3) & ~3) + (size_t)(length - 1) * ((d + 3) & ~3) +
-                        (size_t)d * d * d) * sizeof(float);
+                        (size_t)d * d * d + 4) * sizeof(float);
     if (lds > 150 * 1024) {
       set_error("signature: %zu B of LDS needed", lds);
       return BSIG_EUNSUPPORTED;
