@@ -1236,12 +1236,37 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       if (tid == 0) flag_raise(p.flag_h2, o, epoch);
       if (w == 0) flags_wait(p.flag_o, p.n_hb, epoch, lane, flagp);
       __syncthreads();
-      for (int idx = tid; idx < MR * Nh16; idx += kMT) {
-        const int r = idx / Nh16, j = idx - r * Nh16;
-        const bool ok = j < Nh && r0 + r < B;
-        const float v = ok ? xwg_load(p.o_wide + ((int64_t)(j >> 5) * B + r0 + r) * kMNB + (j & 31)) : 0.f;
-        Os[r * po + j] = v;
-        if (ok && j >= K + DK && j < K + 2 * DK) eacc += expf(v);
+      {
+        // the owner's MR rows of every head block [n_hb][B][32] as 16-byte quads, four per thread in
+        // flight (a conditional 4-byte load per element came back one round trip at a time: ten
+        // dependent ~0.8 us trips with 8 rows per owner)
+        const int per_row = p.n_hb * (kMNB / 4), n_items = MR * per_row;
+        const __amdgpu_buffer_rsrc_t orr = xwg_buffer(p.o_wide);
+        for (int base = 0; base < n_items; base += 4 * kMT) {
+          f32x4 q[4];
+          int rr[4], jj[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = min(base + u * kMT + tid, n_items - 1);
+            const int r = idx / per_row, rem = idx - r * per_row;
+            rr[u] = r; jj[u] = (rem >> 3) * kMNB + (rem & 7) * 4;
+            q[u] = xwg_load4(orr, ((rem >> 3) * B + min(r0 + r, B - 1)) * kMNB + (rem & 7) * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (base + u * kMT + tid < n_items) {
+              const bool rok = r0 + rr[u] < B;
+              const float v4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int j = jj[u] + e;
+                const float v = rok && j < Nh ? v4[e] : 0.f;
+                if (j < Nh16) Os[rr[u] * po + j] = v;
+                if (rok && j >= K + DK && j < K + 2 * DK) eacc += expf(v);
+              }
+            }
+          }
+        }
       }
     }
     // ---- head outputs = h2 Wh^T + bh: column blocks w, w+8, w+16 -----------------------

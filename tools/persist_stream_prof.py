@@ -82,10 +82,10 @@ for g in tiles[3::55]:
     print('   wg %3d: ' % g + ' '.join('%7.2f' % (st[g, u, k] - t0) for k in range(8, 14)))
 t0w = st[254, 0, 0]
 if t0w > 0:
-    print('tile workgroup 3, update 4, second chunk, per wavefront (us after wavefront 0 entered): dW || Adam done / behind '
-          'the barrier / forward 1st quarter / stores issued / 2nd quarter / loads issued / forward done / behind the barrier / gradient in LDS')
+    print('tile workgroup 3, update 4, second chunk, per wavefront (us after wavefront 0 entered): entered / dW || Adam done / '
+          'behind the barrier / forward done (stores, loads issued inside) / behind the barrier / gradient in LDS')
     for w in range(8):
-        print('   wave %d: %6.2f |' % (w, st[254, w, 0] - t0w) + ' '.join('%6.2f' % (st[254, w, k] - t0w) for k in range(1, 10)))
+        print('   wave %d: ' % w + ' '.join('%6.2f' % (st[254, w, k] - t0w) for k in (0, 1, 2, 7, 8, 9)))
 if os.environ.get('DETAIL') == '1':
     u = 4
     t0 = min(st[g, u, 0] for g in tiles)
