@@ -517,11 +517,16 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
 #pragma unroll
           for (int gq8 = 0; gq8 < 13; ++gq8) {
             dw_group(gq8);
-            if (gq8 % 3 == 1) { adam_quad(gq8 / 3); __builtin_amdgcn_sched_barrier(0); }   // after groups 1, 4, 7, 10
+            if (gq8 % 3 == 1) {                            // after groups 1, 4, 7, 10
+              adam_quad(gq8 / 3);
+              store_quad(c, gq8 / 3);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         } else {
 #pragma unroll
           for (int u = 0; u < 4; ++u) adam_quad(u);
+          if (!has_next) store_chunk(c);
         }
         if (c == c_lo + 1) { asm volatile("" :: "v"(acc[0])); BSIG_MSTAMP(9); }
         asm volatile("" :: "v"(acc[0])); BSIG_WSTAMP(1);
@@ -537,14 +542,13 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
           // the block's 12 stores and the next chunk's 12 loads go out between the quarters of the
           // forward product: their issue (1 KB per instruction through the CU's 64 B/clk path) runs
           // in the shadow of the MFMAs instead of in front of a barrier
-          forward_chunk(c, 0, 2 * kHalf, defer ? -1 : c, more ? c + 1 : -1, moments);
+          forward_chunk(c, 0, 2 * kHalf, -1, more ? c + 1 : -1, moments);
           asm volatile("" :: "v"(facc[0])); BSIG_WSTAMP(7);
           if (c == c_lo + 1) { asm volatile("" :: "v"(facc[0])); BSIG_MSTAMP(12); }
           lds_barrier();                                   // the chunk's weights are read: Wc is free
           BSIG_WSTAMP(8);
-        } else {
-          store_chunk(c);
-          if (more) load_chunk(c + 1, moments);
+        } else if (more) {
+          load_chunk(c + 1, moments);
         }
         if (more) {
           dw_to_lds();
