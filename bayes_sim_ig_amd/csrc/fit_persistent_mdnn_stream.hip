@@ -40,19 +40,6 @@ constexpr int kSBP = 36;              // LDS pitch of a [rows][32] block (dz1 st
 constexpr int kSRedGroups = 32;       // slab groups of the cross-workgroup sum
 typedef f32x4 __attribute__((aligned(4))) f32x4u;   // rows of W1 are only 8-byte aligned (I = S*A + 2)
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
-// load and store of the wavefront (s_waitcnt vmcnt(0)): inside the pass that would expose the full
-// memory latency of the next chunk's loads at every barrier instead of hiding it behind the MFMAs.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// LDS hand-over inside one wavefront (its own stores before its own loads of other lanes' data)
-__device__ __forceinline__ void lds_wave_sync() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // k / a for 0 <= k < 2^24 without an integer division
 __device__ __forceinline__ int div_small(int k, int a, float ra) {
   int i = (int)((float)k * ra);
@@ -69,6 +56,13 @@ __device__ __forceinline__ int div_small(int k, int a, float ra) {
       p.prof[((int64_t)254 * kMProfUpdates + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); \
   } while (0)
 
+// (diagnostics) the shader clock beside the 100 MHz wall clock: the engine frequency during the pass
+#define BSIG_WCLK(k)                                                                        \
+  do {                                                                                      \
+    if (p.prof && g == 3 && t == 4 && c == c_lo + 1 && (threadIdx.x & 63) == 0)             \
+      p.prof[((int64_t)254 * kMProfUpdates + (threadIdx.x >> 6)) * 16 + (k)] = (int64_t)__builtin_readcyclecounter(); \
+  } while (0)
+
 template <bool DP>
 __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, float* smem) {
   const int PF = p.s_pf, NIP = p.s_nip, FR = p.FR, B = p.B;
@@ -79,6 +73,7 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
                                              // the dz1 block [FR][kSBP], the k-half exchange, partial sums
   float* red = Wc + kMNB * kSPitch;          // [64]
   float* b1s = red + 64;                     // [32] b1 of this block as of the forward product being summed
+  int* Tb = reinterpret_cast<int*>(b1s + kMNB);   // [chunks of this workgroup][2 k-halves][2 lane halves][16 steps][2]
   // (lane-derived indices are laundered once per update -- below -- so that the address arithmetic
   // built on them is recomputed where it is used instead of being kept live, and spilled, across
   // the update loop: a spilled address comes back as scratch_load + s_waitcnt vmcnt(0) in front of
@@ -198,17 +193,41 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
       ld4(chunk_ptr(p.m2, c, u), moments ? nv : 0, V4[u]);
     }
   };
+  auto store_quad_full = [&](int c, int u) {
+    st4(chunk_ptr(p.params, c, u), 4, W4[u]);
+    st4(chunk_ptr(p.m1, c, u), 4, M4[u]);
+    st4(chunk_ptr(p.m2, c, u), 4, V4[u]);
+  };
+  auto load_quad_full = [&](int c, int u) {
+    ld4(chunk_ptr(p.params, c, u), 4, W4[u]);
+    ld4(chunk_ptr(p.m1, c, u), 4, M4[u]);
+    ld4(chunk_ptr(p.m2, c, u), 4, V4[u]);
+  };
+  // (every chunk but the matrix's last one is 256 whole columns: one uniform test instead of a
+  // per-lane width on each of the 24 memory instructions of a chunk)
   auto store_quad = [&](int c, int u) {
-    const int nv = quad_valid(c);
-    st4(chunk_ptr(p.params, c, u), nv, W4[u]);
-    st4(chunk_ptr(p.m1, c, u), nv, M4[u]);
-    st4(chunk_ptr(p.m2, c, u), nv, V4[u]);
+    if (__builtin_expect((c + 1) * kSC <= I, 1)) {
+      st4(chunk_ptr(p.params, c, u), 4, W4[u]);
+      st4(chunk_ptr(p.m1, c, u), 4, M4[u]);
+      st4(chunk_ptr(p.m2, c, u), 4, V4[u]);
+    } else {
+      const int nv = quad_valid(c);
+      st4(chunk_ptr(p.params, c, u), nv, W4[u]);
+      st4(chunk_ptr(p.m1, c, u), nv, M4[u]);
+      st4(chunk_ptr(p.m2, c, u), nv, V4[u]);
+    }
   };
   auto load_quad = [&](int c, int u, bool moments) {
-    const int nv = quad_valid(c);
-    ld4(chunk_ptr(p.params, c, u), nv, W4[u]);
-    ld4(chunk_ptr(p.m1, c, u), moments ? nv : 0, M4[u]);
-    ld4(chunk_ptr(p.m2, c, u), moments ? nv : 0, V4[u]);
+    if (__builtin_expect((c + 1) * kSC <= I && moments, 1)) {
+      ld4(chunk_ptr(p.params, c, u), 4, W4[u]);
+      ld4(chunk_ptr(p.m1, c, u), 4, M4[u]);
+      ld4(chunk_ptr(p.m2, c, u), 4, V4[u]);
+    } else {
+      const int nv = quad_valid(c);
+      ld4(chunk_ptr(p.params, c, u), nv, W4[u]);
+      ld4(chunk_ptr(p.m1, c, u), moments ? nv : 0, M4[u]);
+      ld4(chunk_ptr(p.m2, c, u), moments ? nv : 0, V4[u]);
+    }
   };
   auto store_chunk = [&](int c) {
     const int nv = quad_valid(c);
@@ -240,38 +259,50 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     else { q.i = div_small(k4, A, rA); q.ai = k4 - q.i * A; }
     return q;
   };
-  auto forward_fetch = [&](const FwdPos& q, int kc, FwdOps& o) {
-    const float* frow = Fr + min(mt * 32 + l31, FR - 1) * PF;
-    o.sfv = frow[q.i - i_lo];
-    o.af4 = *reinterpret_cast<const float4*>(frow + NIP + (q.i >= S ? A + min(q.ai, 4) : q.ai));
-    o.b4 = *reinterpret_cast<const float4*>(Wc + l31 * kSPitch + kc);
-  };
-  // c_st >= 0: that chunk's block (in W4 / M4 / V4) is stored quad by quad behind steps 1..4;
-  // c_ld >= 0: the next chunk's block is loaded quad by quad behind steps 6..9 -- the memory
-  // instructions of a chunk are spread over the forward product instead of going out in two bursts
-  // (every CU of the chip runs the same phase at the same time: bursts saturate the write path)
-  auto forward_chunk = [&](int c, int kk_lo, int kk_hi, int c_st, int c_ld, bool moments) {
-    int kc = kh * (kSC / 2) + kk_lo + 4 * h;
-    FwdPos pos = forward_pos(c * kSC + kc);
+  // c_st >= 0: quads q_from.. of that chunk's block (in W4 / M4 / V4) are stored behind steps 1..4;
+  // c_ld >= 0: quads q_from.. of the next chunk's block are loaded behind steps 6..9
+  //
+  // On a SIMD the VALU instructions of its two wavefronts do NOT hide behind their MFMAs here
+  // (measured: the phase costs MFMAs + VALU; 18 address instructions per step were 20 % of it), so a
+  // step is 4 products + 2 address additions: where the factors of a step's columns sit in a factor
+  // row (the (i, j) walk with its wrap at j = A and the mean / std tail) is the same in every update
+  // -- byte offsets per (chunk, k-half, lane half, step) are tabulated in LDS once per launch.
+  auto forward_chunk = [&](int c, int kk_lo, int kk_hi, int c_st, int q_from, int c_ld, bool moments) {
+    const char* frow = reinterpret_cast<const char*>(Fr + min(mt * 32 + l31, FR - 1) * PF);
+    const float* wrow = Wc + l31 * kSPitch + kh * (kSC / 2) + 4 * h;
+    const int2* tb = reinterpret_cast<const int2*>(Tb + (((c - c_lo) * 2 + kh) * 2 + h) * 32);
+    auto fetch = [&](int2 o, int kk, FwdOps& d) {
+      d.sfv = *reinterpret_cast<const float*>(frow + o.x);
+      d.af4 = *reinterpret_cast<const float4*>(frow + o.y);
+      d.b4 = *reinterpret_cast<const float4*>(wrow + kk);
+    };
     FwdOps cur;
-    forward_fetch(pos, kc, cur);
+    fetch(tb[kk_lo / 8], kk_lo, cur);
+    int2 o_nxt = tb[kk_lo / 8 + 1];
 #pragma unroll
     for (int kk = kk_lo; kk < kk_hi; kk += 8) {
-      FwdOps nxt = cur;
+      const float a0_ = cur.sfv * cur.af4.x, a1_ = cur.sfv * cur.af4.y;
+      const float a2_ = cur.sfv * cur.af4.z, a3_ = cur.sfv * cur.af4.w;
+      const float4 b = cur.b4;
       if (kk + 8 < kk_hi) {
-        kc += 8; pos.ai += 8;
-        if (pos.i < S && pos.ai >= A) { pos.ai -= A; ++pos.i; }     // (A >= 8)
-        forward_fetch(pos, kc, nxt);
+        fetch(o_nxt, kk + 8, cur);
+        if (kk + 16 < kk_hi) o_nxt = tb[kk / 8 + 2];
       }
-      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.sfv * cur.af4.x, cur.b4.x, facc, 0, 0, 0);
-      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.sfv * cur.af4.y, cur.b4.y, facc, 0, 0, 0);
-      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.sfv * cur.af4.z, cur.b4.z, facc, 0, 0, 0);
-      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.sfv * cur.af4.w, cur.b4.w, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b.x, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b.y, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2_, b.z, facc, 0, 0, 0);
+      facc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3_, b.w, facc, 0, 0, 0);
       const int step = kk / 8;
-      if (c_st >= 0 && step >= 1 && step <= 4) store_quad(c_st, step - 1);
-      if (c_ld >= 0 && step >= 6 && step <= 9) load_quad(c_ld, step - 6, moments);
+      if (c_st >= 0 && step >= 1 && step <= 4 && step - 1 >= q_from) store_quad(c_st, step - 1);
+      if (c_ld >= 0 && step >= 6 && step <= 9 && step - 6 >= q_from) load_quad(c_ld, step - 6, moments);
+      // issue order of the step: the first product, MFMA 1, then -- in the 64 cycles the dependent
+      // MFMA 2 waits anyway -- the other products, the next step's addresses and its LDS reads
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       __builtin_amdgcn_sched_barrier(0);
-      cur = nxt;
     }
   };
   constexpr int kHalf = kSC / 4;             // a wavefront's 128 columns in two halves of 64
@@ -348,6 +379,15 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     if (tid == 0) flag_raise(p.flag_red, g, epoch);
   };
 
+  // ---- where a forward step finds its factors (see forward_chunk) ---------------------------------
+  for (int idx = tid; idx < (c_hi - c_lo) * 64; idx += kMT) {
+    const int st = idx & 15, hh = (idx >> 4) & 1, khh = (idx >> 5) & 1, ci = idx >> 6;
+    const FwdPos q = forward_pos((c_lo + ci) * kSC + khh * (kSC / 2) + st * 8 + 4 * hh);
+    Tb[idx * 2 + 0] = (q.i - i_lo) * 4;
+    Tb[idx * 2 + 1] = (NIP + (q.i >= S ? A + min(q.ai, 4) : q.ai)) * 4;
+  }
+  __syncthreads();
+
   // ---- prologue: the forward product of the launch's first minibatch --------------------------
   if (p.n_updates > 0) {
     load_factor_rows((int64_t)step0 * B);
@@ -358,7 +398,7 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     for (int c = c_lo; c < c_hi; ++c) {
       weights_to_lds();
       lds_barrier();
-      forward_chunk(c, 0, 2 * kHalf, -1, c + 1 < c_hi ? c + 1 : -1, false);
+      forward_chunk(c, 0, 2 * kHalf, -1, 0, c + 1 < c_hi ? c + 1 : -1, false);
       lds_barrier();
     }
     publish_and_sum((unsigned)step0 + 1u);
@@ -449,16 +489,56 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
       dw_s = *reinterpret_cast<const float4*>(sfp + 8 * gq8);
       dw_f = *reinterpret_cast<const float4*>(afp + 8 * gq8);
     };
+    // (always the 13 groups of FR <= 104 rows: rows past the minibatch are zeros in za and in Ft; a
+    // branch per group on FR cost more -- its masks spilled out of the SGPRs -- than the MFMAs it saved)
+    // A dependent MFMA waits ~64 cycles at the issue port for its predecessor, and nothing else of
+    // the SIMD issues meanwhile -- except what sits between the two in the SAME instruction stream.
+    // So the group's issue order is: first product, MFMA 1, then (in the wait of MFMA 2) the other
+    // products and the next group's LDS reads.
     auto dw_group = [&](int gq8) {
-      if (8 * gq8 < FR) {
-        const float4 s4 = dw_s, f4 = dw_f;
-        if (gq8 + 1 < 13 && 8 * (gq8 + 1) < FR) dw_fetch(gq8 + 1);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 0], s4.x * f4.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 1], s4.y * f4.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 2], s4.z * f4.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 3], s4.w * f4.w, acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      const float x0 = dw_s.x * dw_f.x, x1 = dw_s.y * dw_f.y, x2 = dw_s.z * dw_f.z, x3 = dw_s.w * dw_f.w;
+      if (gq8 + 1 < 13) dw_fetch(gq8 + 1);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 0], x0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 1], x1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 2], x2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 3], x3, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // The same group carrying the Adam step of quad u of chunk c (whole chunks c, c + 1): one weight
+    // (10 VALU instructions, two of them quarter rate: ~64 cycles) in the wait of each MFMA, the quad's
+    // stores and the reloads behind the last one.  Pinned by scheduling barriers: left to the
+    // scheduler (sched_group_barrier) the spread order exceeds the register budget and is reverted.
+    auto dw_group_adam = [&](int gq8, int c, int u) {
+      const float x0 = dw_s.x * dw_f.x, x1 = dw_s.y * dw_f.y, x2 = dw_s.z * dw_f.z, x3 = dw_s.w * dw_f.w;
+      if (gq8 + 1 < 13) dw_fetch(gq8 + 1);
+      float* gp = Wc + (rl + 8 * u) * kSPitch + cl;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gp);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 0], x0, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      W4[u][0] = adam_weight(g4.x, M4[u][0], V4[u][0], W4[u][0], a0, a1, ak);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 1], x1, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      W4[u][1] = adam_weight(g4.y, M4[u][1], V4[u][1], W4[u][1], a0, a1, ak);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 2], x2, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      W4[u][2] = adam_weight(g4.z, M4[u][2], V4[u][2], W4[u][2], a0, a1, ak);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[4 * gq8 + 3], x3, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      W4[u][3] = adam_weight(g4.w, M4[u][3], V4[u][3], W4[u][3], a0, a1, ak);
+      const f32x4 t4 = {W4[u][0], W4[u][1], W4[u][2], W4[u][3]};
+      *reinterpret_cast<f32x4*>(gp) = t4;                  // (same thread, same spot)
+      store_quad_full(c, u);
+      load_quad_full(c + 1, u);
+      __builtin_amdgcn_sched_barrier(0);
     };
     auto dw_to_lds = [&]() {
 #pragma unroll
@@ -514,13 +594,23 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
           dw_fetch(0);
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+          // (chunks c and c + 1 whole, moments live: no branch inside a group -- one scheduling region)
+          if (__builtin_expect((c + 2) * kSC <= I && moments, 1)) {
 #pragma unroll
-          for (int gq8 = 0; gq8 < 13; ++gq8) {
-            dw_group(gq8);
-            if (gq8 % 3 == 1) {                            // after groups 1, 4, 7, 10
-              adam_quad(gq8 / 3);
-              store_quad(c, gq8 / 3);
-              __builtin_amdgcn_sched_barrier(0);
+            for (int gq8 = 0; gq8 < 13; ++gq8) {
+              if (gq8 % 3 == 1) dw_group_adam(gq8, c, gq8 / 3);   // groups 1, 4, 7, 10
+              else dw_group(gq8);
+            }
+          } else {
+#pragma unroll
+            for (int gq8 = 0; gq8 < 13; ++gq8) {
+              dw_group(gq8);
+              if (gq8 % 3 == 1) {
+                adam_quad(gq8 / 3);
+                store_quad(c, gq8 / 3);
+                load_quad(c + 1, gq8 / 3, moments);
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
           }
         } else {
@@ -538,12 +628,12 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
         if (has_next) {
           lds_barrier();                                   // every block of the chunk holds its new weights
           if (c == c_lo + 1) BSIG_MSTAMP(11);
-          BSIG_WSTAMP(2);
+          BSIG_WSTAMP(2); BSIG_WCLK(10);
           // the block's 12 stores and the next chunk's 12 loads go out between the quarters of the
           // forward product: their issue (1 KB per instruction through the CU's 64 B/clk path) runs
           // in the shadow of the MFMAs instead of in front of a barrier
-          forward_chunk(c, 0, 2 * kHalf, -1, more ? c + 1 : -1, moments);
-          asm volatile("" :: "v"(facc[0])); BSIG_WSTAMP(7);
+          forward_chunk(c, 0, 2 * kHalf, -1, 4, -1, moments);
+          asm volatile("" :: "v"(facc[0])); BSIG_WSTAMP(7); BSIG_WCLK(11);
           if (c == c_lo + 1) { asm volatile("" :: "v"(facc[0])); BSIG_MSTAMP(12); }
           lds_barrier();                                   // the chunk's weights are read: Wc is free
           BSIG_WSTAMP(8);
@@ -605,7 +695,8 @@ bool mdnn_stream_tile_geom(int FR, int chunks_per_wg, int S, int A, int* nip, in
   int pitch = *nip + A + 8;
   while (pitch % 8 != 4) pitch += 4;            // 16-byte reads down the rows: conflict-free
   *pf = pitch;
-  const size_t floats = (size_t)FR * pitch + (size_t)(*nip + A + 8) * kSTP + (size_t)kMNB * kSPitch + 64 + kMNB;
+  const size_t floats = (size_t)FR * pitch + (size_t)(*nip + A + 8) * kSTP + (size_t)kMNB * kSPitch + 64 + kMNB +
+                        (size_t)chunks_per_wg * 128;   // (+ the forward steps' offset table)
   *lds_bytes = floats * sizeof(float);
   // (the chunk region also stages dz1 [FR][36], the k-half exchange [128][33] and the partial
   // sums [32][16][4]; the factor columns the [B][36] block of partial products; a factor row is

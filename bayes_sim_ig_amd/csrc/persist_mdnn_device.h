@@ -107,6 +107,21 @@ constexpr int kMProfUpdates = 8;
       p.prof[((int64_t)blockIdx.x * kMProfUpdates + t) * 16 + (k)] = wall_clock64(); \
   } while (0)
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
+// load and store of the wavefront (s_waitcnt vmcnt(0)): in the streamed pass that
+// would expose the latency of the next chunk's loads at every barrier, and in the owners the round
+// trip of each write-through store (h1, h2, d_out, dz2 leave for memory while the next product runs;
+// the s_waitcnt(0) in front of the owners' flag is what publishes them).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// LDS hand-over inside one wavefront (its own stores before its own loads of other lanes' data)
+__device__ __forceinline__ void lds_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -1185,7 +1200,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     }
     // ---- h1 = tanh(sum of the k-slices) (b1 rides on slice 0) -----------------------
     BSIG_MSTAMP(5);
-    __syncthreads();
+    lds_barrier();                             // (the W2 operand registers stay in flight)
     BSIG_MSTAMP(6);
     {
       // (row, column pair) items; kSub threads share an item's k-slices, their partial
@@ -1201,7 +1216,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         if (ok) xwg_store4(xwg_buffer(p.h1), (r0 + r) * kMH + c4, h0, h1v, h2v, h3);
       }
     }
-    __syncthreads();
+    lds_barrier();                             // (h1 rows still on their way out)
     BSIG_MSTAMP(7);
     // ---- h2 = tanh(h1 W2^T + b2): wave w -> columns 16w .. 16w+15 -------------------
     {
@@ -1228,7 +1243,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       }
     }
     if constexpr (WIDE) __builtin_amdgcn_s_waitcnt(0);   // h2 rows are out before the flag
-    __syncthreads();
+    lds_barrier();
     BSIG_MSTAMP(8);
     float eacc = 0.f;
     if constexpr (WIDE) {
@@ -1298,7 +1313,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     }
     eacc = wave_sum_dpp(eacc);
     if (lane == 0) red[w] = eacc;
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
       float sx = 0.f;
       for (int q = 0; q < kMT / 64; ++q) sx += red[q];
@@ -1326,7 +1341,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       const float uds_w = wave_sum_dpp(ro.uds);
       if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
       float sl = 0.f, su = 0.f;
       for (int q = 0; q < MR; ++q) { sl += red[16 + q]; su += red[32 + q]; }
@@ -1373,7 +1388,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     }
     if (ro.bad) atomicOr(flagp, 1);
     if constexpr (WIDE) __builtin_amdgcn_s_waitcnt(0);   // d_out rows are out before the flag
-    __syncthreads();
+    lds_barrier();
     BSIG_MSTAMP(14);
     if constexpr (WIDE) {
       // ---- wide heads: dz2 = (sum of the head blocks' shares of d_out Wh) * (1 - h2^2) -------
@@ -1430,7 +1445,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- dz1 = (dz2 W2) * (1 - h1^2) -------------------------------------------------------
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};

@@ -14,7 +14,7 @@ for b in open('include/bsig.h', 'rb').read():
 print('0x%016xull' % h)
 PY
 )
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBSIG_HEADER_HASH=$HHASH"
+FLAGS="${BSIG_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBSIG_HEADER_HASH=$HHASH"
 COMMON=$(cat "$SRC"/*.h include/bsig.h | sha256sum | cut -d' ' -f1)
 pids=()
 build_one() {  # name, source, extra flags

@@ -85,7 +85,8 @@ if t0w > 0:
     print('tile workgroup 3, update 4, second chunk, per wavefront (us after wavefront 0 entered): entered / dW || Adam done / '
           'behind the barrier / forward done (stores, loads issued inside) / behind the barrier / gradient in LDS')
     for w in range(8):
-        print('   wave %d: ' % w + ' '.join('%6.2f' % (st[254, w, k] - t0w) for k in (0, 1, 2, 7, 8, 9)))
+        print('   wave %d: ' % w + ' '.join('%6.2f' % (st[254, w, k] - t0w) for k in (0, 1, 2, 7, 8, 9)) +
+              '   forward: %d shader clocks in %.2f us = %.2f GHz' % ((st[254, w, 11] - st[254, w, 10]) * 100, st[254, w, 7] - st[254, w, 2], (st[254, w, 11] - st[254, w, 10]) * 100 / max(st[254, w, 7] - st[254, w, 2], 1e-9) / 1e3))
 if os.environ.get('DETAIL') == '1':
     u = 4
     t0 = min(st[g, u, 0] for g in tiles)
