@@ -93,3 +93,14 @@ if os.environ.get('DETAIL') == '1':
     print('update %d, tile workgroups: start / prefetched / released / dz1 / pass done / summed' % u)
     for g in tiles[::8]:
         print('   wg %3d: ' % g + ' '.join('%7.2f' % (st[g, u, k] - t0) for k in range(6)))
+if os.environ.get('WIDE_DETAIL') == '1':
+    u = 4
+    t0 = min(st[g, u, 0] for g in tiles)
+    print('update %d, head-block workgroups (us after t0): h2 flags seen / h2 in LDS / head outputs flagged / d_out flags seen / '
+          'd_out block in LDS / dz2 share flagged / weights published' % u)
+    for g in small[4:]:
+        print('   wg %3d: %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f' % tuple([g] + [st[g, u, k] - t0 for k in (7, 8, 9, 4, 5, 10, 6)]) +
+              '   [mfma issued %.2f, exchanged %.2f, stores issued %.2f, acked %.2f]' % tuple(st[g, u, k] - t0 for k in (1, 2, 11, 3)))
+    print('owners: sum flags seen / h1 / h2 (flagged) / head outputs in LDS + exp sum published / rows finished / d_out published / flag_own')
+    for g in owners[:6]:
+        print('   wg %3d: %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f' % tuple([g] + [st[g, u, k] - t0 for k in (6, 7, 8, 9, 13, 14, 15)]))
