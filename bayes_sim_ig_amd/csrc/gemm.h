@@ -34,6 +34,11 @@ struct GemmParams {
   // bias_p[row] with gradient bias_g[row] (column sums computed earlier)
   float* bias_p = nullptr; float* bias_m = nullptr; float* bias_v = nullptr;
   const float* bias_g = nullptr;
+  // set by gemm_run: a k-contiguous operand whose rows are not 16-byte aligned is still fetched
+  // in 16-byte quads (TileLoader::fetch)
+  int a_unal = 0, b_unal = 0;
+  // set by gemm_run / the kernel: XCD-aware workgroup -> tile remap, the K split of this workgroup
+  int xcd_swz = 0, bid_z = 0;
 };
 
 // n_expsum (optional) receives the number of expsum partials written.

@@ -18,6 +18,7 @@
 // permutation of 0..7, identical for A and B.
 // Split-K (gridDim.z) writes fp32 partial slabs and a second kernel reduces
 // them in a fixed order and applies the epilogue: bitwise reproducible.
+#include <cstdlib>
 #include "gemm_kernel.h"
 
 namespace bsig {
@@ -167,6 +168,11 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
 static int pick_vec(const float* ptr, int64_t ld) {
   return (ld % 4 == 0 && aligned(ptr, 16)) ? 4 : 1;
 }
+// k-contiguous operand with unaligned rows (ld % 4 != 0: the cross-correlation widths S*A + 2):
+// quads at any 4-byte address, the row's last one shifted into place
+static bool unaligned_quads(const float* ptr, int64_t ld, int kmajor, int k) {
+  return !kmajor && pick_vec(ptr, ld) == 1 && ld >= 4 && k >= 4 && getenv("BSIG_GEMM_NO_UNALIGNED") == nullptr;
+}
 
 int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st,
              int* n_expsum) {
@@ -189,7 +195,13 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
   p.splits = pl.splits; p.k_chunk = pl.k_chunk;
   p.partial = reinterpret_cast<float*>(workspace);
   // a device-resolved row offset changes the alignment of nothing: offsets are whole rows
-  const int avec = pick_vec(p.a, p.lda), bvec = pick_vec(p.b, p.ldb);
+  {
+    static const int xcd = [] { const char* e = getenv("BSIG_GEMM_XCD"); return e ? atoi(e) : 1; }();
+    p.xcd_swz = xcd;
+  }
+  p.a_unal = unaligned_quads(p.a, p.lda, p.a_kmajor, p.k);
+  p.b_unal = unaligned_quads(p.b, p.ldb, p.b_kmajor, p.k);
+  const int avec = p.a_unal ? 4 : pick_vec(p.a, p.lda), bvec = p.b_unal ? 4 : pick_vec(p.b, p.ldb);
   int rc;
   if (pl.tile == TILE_128)
     rc = launch_tile_128(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);

@@ -188,7 +188,7 @@ __device__ inline void tile_epilogue_vec(const GemmParams& p, const float* __res
 #pragma unroll
     for (int it = 0; it < 4; ++it)
       if (ok[it])
-        st4(p.partial + ((int64_t)blockIdx.z * p.m + row0 + it * 8 + r8) * p.n + col, v[it]);
+        st4(p.partial + ((int64_t)p.bid_z * p.m + row0 + it * 8 + r8) * p.n + col, v[it]);
   } else {
     F4 bias{{0.f, 0.f, 0.f, 0.f}};
     if constexpr (EPI == BSIG_EPI_BIAS || EPI == BSIG_EPI_BIAS_ACT || EPI == BSIG_EPI_COS_OFF)
@@ -289,7 +289,7 @@ __device__ inline void tile_epilogue(const GemmParams& p, const float* __restric
     for (int it = 0; it < 16; ++it) {
       const int row = rbase + 2 * it;
       if (colok && row < p.m)
-        p.partial[((int64_t)blockIdx.z * p.m + row) * p.n + col] = v[it];
+        p.partial[((int64_t)p.bid_z * p.m + row) * p.n + col] = v[it];
     }
   } else {
     float bias = 0.f;
@@ -388,24 +388,43 @@ struct TileLoader {
     }
   }
 
+  // `unal`: rows of a k-contiguous operand are not 16-byte aligned (ld % 4 != 0, e.g. the
+  // cross-correlation widths S*A + 2): the quads are still fetched with one 16-byte load each
+  // (gfx950 takes dwordx4 at any 4-byte address at full rate, tools/micro/stream_pattern_bench.hip);
+  // only the last quad of a row, clamped back inside the row, has to be shifted into place.
   __device__ inline void fetch(Regs& t, const float* __restrict__ g, int64_t ld,
                                const int32_t* __restrict__ idx, int row0, int nrows,
-                               int k0, int kend, int ktot, int tid) const {
+                               int k0, int kend, int ktot, int tid, bool unal = false) const {
     auto& r = t.r;
     if constexpr (!KMAJOR) {
       constexpr int per_row = BK / VEC;
       const int cc = (tid % per_row) * VEC;   // NT % per_row == 0: same for every item
       const int gk = k0 + cc;
-      // stay inside the row pitch (ld % 4 == 0 when VEC == 4)
+      // stay inside the row pitch (ld % 4 == 0 when VEC == 4 unless `unal`)
       const int gkc = (VEC == 4) ? min(gk, (int)ld - 4) : min(gk, ktot - 1);
+      typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
       for (int it = 0; it < kItems; ++it) {
         const float* src = g + (int64_t)srow[it] * ld + gkc;
         if constexpr (VEC == 4) {
-          const float4 q = *reinterpret_cast<const float4*>(src);
+          const f32x4u_t q = *reinterpret_cast<const f32x4u_t*>(src);
           r[it][0] = q.x; r[it][1] = q.y; r[it][2] = q.z; r[it][3] = q.w;
         } else {
           r[it][0] = src[0];
+        }
+      }
+      if constexpr (VEC == 4) {
+        if (unal) {
+          // slot v holds column gkc + v and stands for column gk + v: move slot v + s to v
+          // (slots that run past the row stand for columns >= ld >= kend: zeroed below)
+          const int sft = gk - gkc;
+#pragma unroll
+          for (int it = 0; it < kItems; ++it) {
+            const float q0 = r[it][0], q1 = r[it][1], q2 = r[it][2], q3 = r[it][3];
+            r[it][0] = sft == 0 ? q0 : (sft == 1 ? q1 : (sft == 2 ? q2 : q3));
+            r[it][1] = sft == 0 ? q1 : (sft == 1 ? q2 : q3);
+            r[it][2] = sft == 0 ? q2 : q3;
+          }
         }
       }
 #pragma unroll
@@ -497,8 +516,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * p.k_chunk;
+  // Workgroup -> tile.  The dispatcher deals consecutive workgroups round the 8 XCDs (block b on
+  // XCD b % 8, each with a private L2), so consecutive tiles -- which share an operand panel -- would
+  // each fetch it from HBM: with the remap an XCD works on a contiguous run of tiles (all column tiles
+  // of a row panel, all tiles of a K split) and the panel is read once per XCD.  A speed choice only:
+  // every tile is still computed exactly once (the remap is a bijection on [0, nwg)).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_swz) {
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * (int)gridDim.z;
+    const int lin = bx + gx * (by + gy * bz);
+    const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    bx = wgid % gx; by = (wgid / gx) % gy; bz = wgid / (gx * gy);
+  }
+  p.bid_z = bz;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * p.k_chunk;
   const int kend = min(p.k, kbeg + p.k_chunk);
 
   floatx16 acc[TM][TN];
@@ -534,8 +567,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
 #pragma unroll
   for (int s = 0; s < PD; ++s)
     if (s < nkt) {
-      la.fetch(ra[s], p.a, p.lda, p.a_rows, m0, p.m, kbeg + s * BK, kend, p.k, tid);
-      lb.fetch(rb[s], p.b, p.ldb, p.b_rows, n0, p.n, kbeg + s * BK, kend, p.k, tid);
+      la.fetch(ra[s], p.a, p.lda, p.a_rows, m0, p.m, kbeg + s * BK, kend, p.k, tid, p.a_unal != 0);
+      lb.fetch(rb[s], p.b, p.ldb, p.b_rows, n0, p.n, kbeg + s * BK, kend, p.k, tid, p.b_unal != 0);
     }
   // MFMAs of one staged K tile (BK = 32 -> 4 groups of 8 k; TM*TN*4 MFMAs each)
   auto compute_tile = [&](const float* __restrict__ At, const float* __restrict__ Bt) {
@@ -594,8 +627,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
       float* nxt = smem + ((kt + 1) & 1) * (kAs + kBs);
       if (kt + 1 < nkt) {
         const int k0 = kbeg + (kt + 1) * BK;
-        la.fetch(ra[0], p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid);
-        lb.fetch(rb[0], p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid);
+        la.fetch(ra[0], p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid, p.a_unal != 0);
+        lb.fetch(rb[0], p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid, p.b_unal != 0);
       }
       compute_tile(cur, cur + kAs);
       if (kt + 1 < nkt) {
@@ -615,8 +648,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
           __syncthreads();
           if (kt + PD < nkt) {   // refill this register slot
             const int k0 = kbeg + (kt + PD) * BK;
-            la.fetch(ra[s], p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid);
-            lb.fetch(rb[s], p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid);
+            la.fetch(ra[s], p.a, p.lda, p.a_rows, m0, p.m, k0, kend, p.k, tid, p.a_unal != 0);
+            lb.fetch(rb[s], p.b, p.ldb, p.b_rows, n0, p.n, k0, kend, p.k, tid, p.b_unal != 0);
           }
           compute_tile(As, Bs);
           __syncthreads();
@@ -661,7 +694,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
   static_assert((TM <= 3 && TN <= 3) || (TM == 1 && TN <= 9) || (TN == 1 && TM <= 9), "extend the tile enumeration");
   if (p.expsum && p.splits == 1) {   // one partial per workgroup, fixed order
     const float s = block_sum(exp_acc, smem);
-    if (tid == 0) p.expsum[blockIdx.y * gridDim.x + blockIdx.x] = s;
+    if (tid == 0) p.expsum[by * gridDim.x + bx] = s;
   }
 }
 

@@ -56,7 +56,10 @@ shapes = [('fwd head 8192x260x4096 NT gathered A', 8192, 260, 4096, 0, 0, 'a'),
           # (cfg/shadow_hand_more.yaml, I = 105002; cfg/anymal.yaml, I = 56402)
           ('wide L1 fwd 100x128x105002 NT gathered A', 100, 128, 105002, 0, 0, 'a'),
           ('wide L1 dW 128x105002x100 TN gathered B', 128, 105002, 100, 1, 1, 'b'),
-          ('wide L1 fwd 100x128x56402 NT gathered A', 100, 128, 56402, 0, 0, 'a')]
+          ('wide L1 fwd 100x128x56402 NT gathered A', 100, 128, 56402, 0, 0, 'a'),
+          # held-out evaluation of a streamed plan: the held-out fifth of a 1000-pair chunk
+          ('heldout L1 200x128x56402 NT', 200, 128, 56402, 0, 0, None),
+          ('heldout L1 200x128x105002 NT', 200, 128, 105002, 0, 0, None)]
 only = sys.argv[1:]
 for name, m, n, k, akm, bkm, g in shapes:
     if only and not any(o in name for o in only):
