@@ -63,47 +63,77 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
   const int S = w * sfeat, A = w * ad;
   float* sf = smem;            // [S]
   float* af = smem + S;        // [A]
-  float* red = af + A;         // [8]
   const int tid = threadIdx.x, nt = blockDim.x;
+  // A workgroup that stops storing while it fetches and reduces its next trajectory leaves the
+  // chip's write path idle for that time: with the fetch -> LDS -> mean -> std -> max chain of six
+  // workgroup barriers per trajectory the kernel ran at 0.8 of what the same store loop does alone
+  // (tools/micro/fill_bench.hip).  So the NEXT trajectory's features are fetched into registers
+  // before this one's store loop (their latency hides behind it), and the statistics are taken by
+  // every wavefront for itself (same values, same order in each: no barrier) -- two barriers per
+  // trajectory.
+  constexpr int kPfW = 10;                 // window <= 10 (crosscorr_window)
+  const bool pf_ok = sfeat <= nt && ad <= nt && w <= kPfW;   // (else: fetched in place, below)
+  float pf_s0[kPfW], pf_s1[kPfW], pf_a[kPfW];
+  auto prefetch = [&](int64_t traj) {
+    const float* s = states + traj * (int64_t)ts * sd;
+    const float* a = actions + traj * (int64_t)ta * ad;
+#pragma unroll
+    for (int t = 0; t < kPfW; ++t) {
+      if (t < w) {
+        const float* srow = s + (int64_t)t * sd;
+        const float* arow = a + (int64_t)min(t, ta - 1) * ad;   // pad: repeat the last step (:52-58)
+        if (tid < sfeat) { pf_s0[t] = srow[tid]; pf_s1[t] = use_diff ? srow[tid + 1] : 0.f; }
+        if (tid < ad) pf_a[t] = arow[tid];
+      }
+    }
+  };
+  if (pf_ok && (int64_t)blockIdx.x < n) prefetch(blockIdx.x);
   for (int64_t traj = blockIdx.x; traj < n; traj += gridDim.x) {
     const float* s = states + traj * (int64_t)ts * sd;
     const float* a = actions + traj * (int64_t)ta * ad;
     float* o = out ? out + traj * ld_out : nullptr;
     __syncthreads();
-    // state features: iterate (t, c) without integer division
-    for (int t = 0; t < w; ++t) {
-      const float* srow = s + (int64_t)t * sd;
-      for (int c = tid; c < sfeat; c += nt)
-        sf[t * sfeat + c] = use_diff ? (srow[c + 1] - srow[c]) : srow[c];
-      // actions beyond their own length repeat the last step (pad, :52-58)
-      const float* arow = a + (int64_t)min(t, ta - 1) * ad;
-      for (int c = tid; c < ad; c += nt) af[t * ad + c] = arow[c];
+    if (pf_ok) {
+#pragma unroll
+      for (int t = 0; t < kPfW; ++t) {
+        if (t < w) {
+          if (tid < sfeat) sf[t * sfeat + tid] = use_diff ? pf_s1[t] - pf_s0[t] : pf_s0[t];
+          if (tid < ad) af[t * ad + tid] = pf_a[t];
+        }
+      }
+    } else {
+      // state features: iterate (t, c) without integer division
+      for (int t = 0; t < w; ++t) {
+        const float* srow = s + (int64_t)t * sd;
+        for (int c = tid; c < sfeat; c += nt)
+          sf[t * sfeat + c] = use_diff ? (srow[c + 1] - srow[c]) : srow[c];
+        // actions beyond their own length repeat the last step (pad, :52-58)
+        const float* arow = a + (int64_t)min(t, ta - 1) * ad;
+        for (int c = tid; c < ad; c += nt) af[t * ad + c] = arow[c];
+      }
     }
     __syncthreads();
-    // mean and unbiased std (two passes, like torch.std)
+    if (pf_ok && traj + gridDim.x < n) prefetch(traj + gridDim.x);
+    // mean and unbiased std (two passes, like torch.std), per wavefront
+    const int ln = tid & 63;
     float part = 0.f;
-    for (int i = tid; i < S; i += nt) part += sf[i];
-    const float mean = block_sum(part, red) / (float)S;
+    for (int i = ln; i < S; i += 64) part += sf[i];
+    const float mean = wave_sum(part) / (float)S;
     part = 0.f;
-    for (int i = tid; i < S; i += nt) {
+    for (int i = ln; i < S; i += 64) {
       const float d = sf[i] - mean;
       part += d * d;
     }
-    const float ss = block_sum(part, red);
+    const float ss = wave_sum(part);
     const float sdev = (S < 2) ? 0.f : sqrtf(ss / (float)(S - 1));
     // isfinite(feats) (summarizers.py:120) without touching every product: all
     // inputs finite and max|sf| * max|af| far from overflow => every product is
     // finite; otherwise fall back to checking each product.
     float ms = 0.f, ma = 0.f;
     bool in_bad = false;
-    for (int i = tid; i < S; i += nt) { ms = fmaxf(ms, fabsf(sf[i])); in_bad |= !isfinite(sf[i]); }
-    for (int i = tid; i < A; i += nt) { ma = fmaxf(ma, fabsf(af[i])); in_bad |= !isfinite(af[i]); }
+    for (int i = ln; i < S; i += 64) { ms = fmaxf(ms, fabsf(sf[i])); in_bad |= !isfinite(sf[i]); }
+    for (int i = ln; i < A; i += 64) { ma = fmaxf(ma, fabsf(af[i])); in_bad |= !isfinite(af[i]); }
     ms = wave_max(ms); ma = wave_max(ma);
-    __syncthreads();
-    if ((tid & 63) == 0) { red[tid >> 6] = ms; red[4 + (tid >> 6)] = ma; }
-    __syncthreads();
-    ms = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    ma = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
     const bool check_each = !(ms < 1e18f && ma < 1e18f);
     if (fac) {
       float* f = fac + traj * ld_fac;
@@ -179,6 +209,102 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
     if (tid == 0) {
       o[total] = mean;
       o[total + 1] = sdev;
+      bad |= !(isfinite(mean) && isfinite(sdev));
+    }
+    if (bad && nonfinite) atomicOr(nonfinite, 1);
+  }
+}
+
+// The materialised summary alone (bsig_crosscorr, vector-width rows, A % 4 == 0): the same
+// arithmetic as crosscorr_kernel's quad path in a kernel small enough for 8 workgroups per CU, with
+// every wavefront's 1 KB run of stores starting on a 128-byte line.  The kernel is write-bound and
+// its rows (4 (S A + 2) bytes, padded to 16) start at arbitrary 16-byte offsets: streaming stores
+// that straddle lines ran at 4.0-4.4 TB/s where the same bytes in line-aligned runs take 5.2
+// (tools/micro/fill_bench.hip, profiles/r03_fill_bench.txt).  So the thread <-> quad map is rotated
+// per trajectory by the row's offset within a line: thread t owns quads shift + t + k * act of the
+// row (act = rstep * A/4 threads store per sweep, a multiple of 8 quads = 128 bytes); the up to
+// seven quads in front of the first line boundary are stored by threads 0..shift-1 on the side.
+__global__ __launch_bounds__(256) void crosscorr_quads_kernel(
+    const float* __restrict__ states, const float* __restrict__ actions, float* __restrict__ out,
+    int64_t n, int ts, int ta, int sd, int ad, int w, int use_diff, int64_t ld_out, int rstep,
+    int32_t* __restrict__ nonfinite) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const int sfeat = sd - 1;
+  const int S = w * sfeat, A = w * ad;
+  float* sf = smem;            // [S]
+  float* af = smem + S;        // [A]
+  const int tid = threadIdx.x, ln = tid & 63;
+  const int qpr = A >> 2, act = rstep * qpr;
+  constexpr int kPfW = 10;
+  float pf_s0[kPfW], pf_s1[kPfW], pf_a[kPfW];
+  auto prefetch = [&](int64_t traj) {     // (see crosscorr_kernel)
+    const float* s = states + traj * (int64_t)ts * sd;
+    const float* a = actions + traj * (int64_t)ta * ad;
+#pragma unroll
+    for (int t = 0; t < kPfW; ++t) {
+      if (t < w) {
+        const float* srow = s + (int64_t)t * sd;
+        const float* arow = a + (int64_t)min(t, ta - 1) * ad;
+        if (tid < sfeat) { pf_s0[t] = srow[tid]; pf_s1[t] = use_diff ? srow[tid + 1] : 0.f; }
+        if (tid < ad) pf_a[t] = arow[tid];
+      }
+    }
+  };
+  if ((int64_t)blockIdx.x < n) prefetch(blockIdx.x);
+  for (int64_t traj = blockIdx.x; traj < n; traj += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kPfW; ++t) {
+      if (t < w) {
+        if (tid < sfeat) sf[t * sfeat + tid] = use_diff ? pf_s1[t] - pf_s0[t] : pf_s0[t];
+        if (tid < ad) af[t * ad + tid] = pf_a[t];
+      }
+    }
+    __syncthreads();
+    if (traj + gridDim.x < n) prefetch(traj + gridDim.x);
+    float part = 0.f;
+    for (int i = ln; i < S; i += 64) part += sf[i];
+    const float mean = wave_sum(part) / (float)S;
+    part = 0.f;
+    for (int i = ln; i < S; i += 64) {
+      const float d = sf[i] - mean;
+      part += d * d;
+    }
+    const float sdev = (S < 2) ? 0.f : sqrtf(wave_sum(part) / (float)(S - 1));
+    float ms = 0.f, ma = 0.f;
+    bool bad = false;
+    for (int i = ln; i < S; i += 64) { ms = fmaxf(ms, fabsf(sf[i])); bad |= !isfinite(sf[i]); }
+    for (int i = ln; i < A; i += 64) { ma = fmaxf(ma, fabsf(af[i])); bad |= !isfinite(af[i]); }
+    ms = wave_max(ms); ma = wave_max(ma);
+    const bool check_each = !(ms < 1e18f && ma < 1e18f);   // (see crosscorr_kernel)
+    const int64_t base_q = (traj * ld_out) >> 2;
+    f32x4_t* o4 = reinterpret_cast<f32x4_t*>(out) + base_q;
+    const int shift = (int)((8 - (base_q & 7)) & 7);
+    if (tid < shift) {                       // quads in front of the first line boundary
+      const int i = tid / qpr, jq = tid - i * qpr;
+      const float sv = sf[i];
+      const float4 a4 = *reinterpret_cast<const float4*>(af + 4 * jq);
+      const f32x4_t pk = {sv * a4.x, sv * a4.y, sv * a4.z, sv * a4.w};
+      if (check_each) bad |= !(isfinite(pk.x) && isfinite(pk.y) && isfinite(pk.z) && isfinite(pk.w));
+      o4[tid] = pk;
+    }
+    if (tid < act) {
+      const int q0 = shift + tid;
+      const int i0 = q0 / qpr, jq = q0 - i0 * qpr;
+      const float4 a4 = *reinterpret_cast<const float4*>(af + 4 * jq);
+      f32x4_t* orow = o4 + jq;
+      for (int i = i0; i < S; i += rstep) {
+        const float sv = sf[i];
+        const f32x4_t pk = {sv * a4.x, sv * a4.y, sv * a4.z, sv * a4.w};
+        if (check_each) bad |= !(isfinite(pk.x) && isfinite(pk.y) && isfinite(pk.z) && isfinite(pk.w));
+        __builtin_nontemporal_store(pk, orow + (int64_t)i * qpr);
+      }
+    }
+    if (tid == 0) {
+      float* o = out + traj * ld_out;
+      o[(int64_t)S * A] = mean;
+      o[(int64_t)S * A + 1] = sdev;
       bad |= !(isfinite(mean) && isfinite(sdev));
     }
     if (bad && nonfinite) atomicOr(nonfinite, 1);
@@ -272,7 +398,9 @@ __global__ __launch_bounds__(256) void crosscorr_wave_kernel(
 //   S2[i,j]   += (S1[i] + D[i]/2) * D[j]
 //   S1[i]      = X_l[i] - X_0[i]
 // One thread per (i,j) pair keeps S2[i,j] and the S3[i,j,:] row in registers
-// for the whole path; the result is staged in LDS and stored lane-contiguous.
+// for the whole path; the result is staged in LDS and stored lane-contiguous (straight from the
+// registers -- 16 bytes per lane at a stride of 4 d bytes -- the same stores ran at 2.4 instead of
+// 4.0 TB/s: a wavefront's store instruction wants one contiguous run).
 // Algorithmic bytes / trajectory: 4*(L*d + d + d^2 + d^3).
 template <int DMAX>
 __global__ void signature3_kernel(const float* __restrict__ states,
@@ -292,21 +420,36 @@ __global__ void signature3_kernel(const float* __restrict__ states,
   const int npairs = d * d;
   const int i = tid / d, j = tid % d;
   const bool active = tid < npairs;
+  // the next trajectory's samples are fetched into registers before this one's store phase
+  // (one element per thread: their latency hides behind it instead of opening every trajectory)
+  const bool pf_ok = length * sd <= nt && length * ad <= nt;
+  float pf_s = 0.f, pf_a = 0.f;
+  auto prefetch = [&](int64_t traj) {
+    if (tid < length * sd) pf_s = states[traj * (int64_t)length * sd + tid];
+    if (tid < length * ad) pf_a = actions[traj * (int64_t)length * ad + tid];
+  };
+  if (pf_ok && (int64_t)blockIdx.x < n) prefetch(blockIdx.x);
   for (int64_t traj = blockIdx.x; traj < n; traj += gridDim.x) {
     const float* s = states + traj * (int64_t)length * sd;
     const float* a = actions + traj * (int64_t)length * ad;
     float* o = out + traj * ld_out;
     __syncthreads();
-    for (int e = tid; e < length * sd; e += nt) {
-      const int l = e / sd, c = e - l * sd;
-      path[l * d + 1 + c] = s[e];
-    }
-    for (int e = tid; e < length * ad; e += nt) {
-      const int l = e / ad, c = e - l * ad;
-      path[l * d + 1 + sd + c] = a[e];
+    if (pf_ok) {
+      if (tid < length * sd) { const int l = tid / sd, c = tid - l * sd; path[l * d + 1 + c] = pf_s; }
+      if (tid < length * ad) { const int l = tid / ad, c = tid - l * ad; path[l * d + 1 + sd + c] = pf_a; }
+    } else {
+      for (int e = tid; e < length * sd; e += nt) {
+        const int l = e / sd, c = e - l * sd;
+        path[l * d + 1 + c] = s[e];
+      }
+      for (int e = tid; e < length * ad; e += nt) {
+        const int l = e / ad, c = e - l * ad;
+        path[l * d + 1 + sd + c] = a[e];
+      }
     }
     for (int l = tid; l < length; l += nt) path[l * d] = (float)(l + 1);
     __syncthreads();
+    if (pf_ok && traj + gridDim.x < n) prefetch(traj + gridDim.x);
     for (int e = tid; e < (length - 1) * dp; e += nt) {
       const int l = e / dp, c = e - l * dp;
       delta[e] = c < d ? path[(l + 1) * d + c] - path[l * d + c] : 0.f;
@@ -353,8 +496,11 @@ __global__ void signature3_kernel(const float* __restrict__ states,
     float* o3 = o + d + npairs;
     const int n3 = npairs * d;
     if ((ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-      // head up to the first 16-byte boundary, aligned quads, tail
-      const int head = min((4 - mis) & 3, n3);
+      // head up to the first 128-byte LINE of the output row (a wavefront's 64 quads are then whole
+      // lines: streaming stores that straddle lines run at 4.0-4.4 TB/s, line-aligned runs at 5.2,
+      // tools/micro/fill_bench.hip), aligned quads, tail.  (head = (4 - mis) mod 4: the stage has
+      // the row's 16-byte phase)
+      const int head = min((int)((32 - ((reinterpret_cast<uintptr_t>(o3) >> 2) & 31)) & 31), n3);
       const int nq = (n3 - head) >> 2;
       if (tid < head) __builtin_nontemporal_store(stage[tid], o3 + tid);
       typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -511,6 +657,19 @@ static int crosscorr_launch(const float* states, const float* actions, float* ou
     return BSIG_OK;
   }
   const int vec4 = out && (ld_out % 4 == 0) && aligned(out, 16);
+  // the materialised summary alone, quads of action features: the lean streaming kernel
+  if (out && !fac && vec4 && (A & 3) == 0 && sd - 1 <= 256 && ad <= 256 && w <= 10 &&
+      getenv("BSIG_CC_GENERAL") == nullptr) {
+    const int qpr = (int)(A >> 2);
+    int m8 = 8; for (int g = qpr; (g & 1) == 0 && m8 > 1; g >>= 1) m8 >>= 1;   // 8 / gcd(qpr, 8)
+    const int rstep = (256 / qpr) / m8 * m8;
+    if (rstep >= 1 && S * qpr >= 512) {
+      hipLaunchKernelGGL(crosscorr_quads_kernel, dim3(grid_for(n)), dim3(256), lds, st, states, actions,
+                         out, n, t_states, t_actions, sd, ad, w, use_state_diff, ld_out, rstep, nonfinite);
+      BSIG_CHECK_LAUNCH("crosscorr_quads");
+      return BSIG_OK;
+    }
+  }
   hipLaunchKernelGGL(crosscorr_kernel, dim3(grid_for(n)), dim3(256), lds, st,
                      states, actions, out, n, t_states, t_actions, sd, ad, w,
                      use_state_diff, ld_out, vec4, nonfinite, fac, ld_fac);
