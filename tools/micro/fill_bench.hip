@@ -58,7 +58,7 @@ template <typename F> static double time_us(F&& f, int reps) {
 }
 
 int main() {
-  for (double gb : {0.5, 2.36}) {
+  for (double gb : {0.1, 0.5, 2.36, 9.44}) {
     const size_t bytes = (size_t)(gb * 1e9) / 65536 * 65536;
     f4* buf; CK(hipMalloc(&buf, bytes));
     const size_t nq = bytes / 16;
