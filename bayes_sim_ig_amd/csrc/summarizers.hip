@@ -43,6 +43,28 @@ __global__ __launch_bounds__(256) void summary_start_kernel(
   }
 }
 
+// mean and unbiased std of a feature row (summarizers.py:114-119: torch.mean / torch.std, two
+// passes), taken by one wavefront from LDS.  Accumulated in fp64 and rounded once: the value every
+// fp32 summation order approximates (the reference's own order is a property of the torch build),
+// at 5 elements per lane.  Every lane returns the same value.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ void row_mean_std(const float* sf, int S, int ln, float& mean, float& sdev) {
+  double part = 0.0;
+  for (int i = ln; i < S; i += 64) part += (double)sf[i];
+  const double m = wave_sum_f64(part) / (double)S;
+  part = 0.0;
+  for (int i = ln; i < S; i += 64) {
+    const double d = (double)sf[i] - m;
+    part += d * d;
+  }
+  mean = (float)m;
+  sdev = (S < 2) ? 0.f : (float)sqrt(wave_sum_f64(part) / (double)(S - 1));
+}
+
 // ------------------------------------------------------------------ K2
 // cross_correlation: summarizers.py:90-122.
 //   sf[t*(sd-1)+c] = s[t,c+1]-s[t,c]  (corrdiff, :105-106)  or  s[t,c] (:108)
@@ -116,16 +138,8 @@ __global__ __launch_bounds__(256) void crosscorr_kernel(
     if (pf_ok && traj + gridDim.x < n) prefetch(traj + gridDim.x);
     // mean and unbiased std (two passes, like torch.std), per wavefront
     const int ln = tid & 63;
-    float part = 0.f;
-    for (int i = ln; i < S; i += 64) part += sf[i];
-    const float mean = wave_sum(part) / (float)S;
-    part = 0.f;
-    for (int i = ln; i < S; i += 64) {
-      const float d = sf[i] - mean;
-      part += d * d;
-    }
-    const float ss = wave_sum(part);
-    const float sdev = (S < 2) ? 0.f : sqrtf(ss / (float)(S - 1));
+    float mean, sdev;
+    row_mean_std(sf, S, ln, mean, sdev);
     // isfinite(feats) (summarizers.py:120) without touching every product: all
     // inputs finite and max|sf| * max|af| far from overflow => every product is
     // finite; otherwise fall back to checking each product.
@@ -263,15 +277,8 @@ __global__ __launch_bounds__(256) void crosscorr_quads_kernel(
     }
     __syncthreads();
     if (traj + gridDim.x < n) prefetch(traj + gridDim.x);
-    float part = 0.f;
-    for (int i = ln; i < S; i += 64) part += sf[i];
-    const float mean = wave_sum(part) / (float)S;
-    part = 0.f;
-    for (int i = ln; i < S; i += 64) {
-      const float d = sf[i] - mean;
-      part += d * d;
-    }
-    const float sdev = (S < 2) ? 0.f : sqrtf(wave_sum(part) / (float)(S - 1));
+    float mean, sdev;
+    row_mean_std(sf, S, ln, mean, sdev);
     float ms = 0.f, ma = 0.f;
     bool bad = false;
     for (int i = ln; i < S; i += 64) { ms = fmaxf(ms, fabsf(sf[i])); bad |= !isfinite(sf[i]); }
