@@ -480,6 +480,7 @@ static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, int 
     pb.n_test = (int)b.n_test;
     pb.x_test = b.x_test; pb.ldx_test = b.ldx_test; pb.y_test = b.y_test; pb.ldy_test = b.ldy_test;
     pb.test_loss = b.test_loss;
+    pb.n_train = b.n_train;
   }
   PersistHyper hy;
   hy.lr = p->cfg.lr; hy.beta1 = p->cfg.beta1; hy.beta2 = p->cfg.beta2;
@@ -929,7 +930,9 @@ static int dp_eval_total(const bsig_fit_plan* p) {
   const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
   if (!p->split_adam || p->buf.n_test < 1 || p->n_updates < 1 || (no_ike && no_ike[0] == '1')) return 0;
   if (p->persistent && persist_eval_supported(persist_shape(p))) return (int)p->n_updates;
-  if (p->persistent_mdnn && persist_mdnn_eval_supported(persist_mdnn_shape(p))) return (int)p->n_updates;
+  // (a data-parallel rank of a streamed first layer evaluates between its launches)
+  if (p->persistent_mdnn && !p->mdnn_streams && persist_mdnn_eval_supported(persist_mdnn_shape(p)))
+    return (int)p->n_updates;
   return 0;
 }
 

@@ -55,7 +55,7 @@ struct MdnnGeom {
   int mr;                       // minibatch rows per owner workgroup
   int eval_passes;              // 0: evaluations stay outside the launches
   size_t lds;
-  size_t slab_floats, act_floats, dout_floats, eval_floats;
+  size_t slab_floats, act_floats, dout_floats, eval_floats, eval_slab_floats;
 };
 
 static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
@@ -117,8 +117,14 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   g->dout_floats = (size_t)s.batch * g->NhP;
   // in-launch evaluations: slabs of both parities and the parked head outputs
   g->eval_passes = s.max_test > 0 ? ceil_div(s.max_test, s.batch) : 0;
-  if (g->eval_passes > 8 || g->wide || g->stream) g->eval_passes = 0;   // wide heads, streamed W1: evaluation graphs between launches
-  g->eval_floats = (size_t)2 * g->eval_passes * g->slab_floats +
+  if (g->eval_passes > 8 || g->wide) g->eval_passes = 0;   // wide heads: evaluation graphs between launches
+  if (g->stream) {   // (A/B switch: a streamed plan's evaluations as graphs between its launches)
+    const char* e = getenv("BSIG_NO_STREAM_EVAL");
+    if (e && e[0] == '1') g->eval_passes = 0;
+  }
+  // (streamed W1: an evaluation pass leaves ONE summed slab [B][128], like an update)
+  g->eval_slab_floats = g->stream ? g->act_floats : g->slab_floats;
+  g->eval_floats = (size_t)2 * g->eval_passes * g->eval_slab_floats +
                    (size_t)g->eval_passes * s.batch * g->NhP;
   return true;
 }
@@ -172,7 +178,7 @@ static size_t mdnn_data_bytes(const MdnnGeom& g) {
   return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats + 2 * kPackFloats +
                            g.eval_floats + mdnn_wide_floats(g) + (g.stream ? g.act_floats : 0)) * sizeof(float), 256);
 }
-static size_t mdnn_sync_bytes() { return 10 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
+static size_t mdnn_sync_bytes() { return 12 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
 
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
   MdnnGeom g;
@@ -222,8 +228,8 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
     BSIG_REQUIRE(mdnn_stream_fits(g, b.x_s, b.x_a, &s_nip, &s_pf, &s_lds),
                  "persistent MDNN updates: factor rows S=%d A=%d not covered by the streamed first layer",
                  b.x_s, b.x_a);
-    BSIG_REQUIRE(!b.adam_pending && !b.do_eval && n >= 1,
-                 "persistent MDNN updates: a streamed first layer takes its Adam step / evaluations outside");
+    BSIG_REQUIRE(!b.adam_pending && n >= 1 && !(b.do_eval && b.grads),
+                 "persistent MDNN updates: a streamed first layer takes its Adam step outside");
   }
   // the > 64 KB dynamic-LDS attribute is per device (the plan's device is the current one:
   // the Python mirror enters the model's device around every call)
@@ -273,7 +279,7 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.w2f_pack = p.d_out + g.dout_floats;
   p.w2b_pack = p.w2f_pack + kPackFloats;
   p.eval_slabs = p.w2b_pack + kPackFloats;
-  p.eval_out = p.eval_slabs + (size_t)2 * g.eval_passes * g.slab_floats;
+  p.eval_out = p.eval_slabs + (size_t)2 * g.eval_passes * g.eval_slab_floats;
   p.wide = g.wide; p.n_hb = g.NhP / kMNB;
   p.o_wide = p.eval_out + (size_t)g.eval_passes * s.batch * g.NhP;
   p.dz2_part = p.o_wide + g.dout_floats;
@@ -294,13 +300,20 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.flag_red = p.flag_dz2 + kFlagArr;
   p.o_slabs = g.stream ? p.hpre : p.slabs; p.o_k_slices = g.stream ? 1 : g.k_slices;
   p.o_flags = g.stream ? p.flag_red : p.flag_fwd;
-  p.gran = reinterpret_cast<unsigned long long*>(sync + 10 * kFlagArr * sizeof(unsigned));
+  p.flag_evp = p.flag_red + kFlagArr;     // streamed W1, evaluation passes: slab out / quads summed
+  p.flag_evr = p.flag_evp + kFlagArr;
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 12 * kFlagArr * sizeof(unsigned));
   p.gran_eval = p.gran + 3 * kGranArr;
   if (b.do_eval) {
     BSIG_REQUIRE(g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
-                     b.x_test && b.y_test && b.test_loss && b.eval_every >= 1 && b.n_total >= 1 &&
-                     b.ldx_test % 4 == 0 && b.ldx_test >= s.input_dim && aligned(b.x_test, 16),
+                     b.y_test && b.test_loss && b.eval_every >= 1 && b.n_total >= 1 &&
+                     (g.stream || (b.x_test && b.ldx_test % 4 == 0 && b.ldx_test >= s.input_dim &&
+                                   aligned(b.x_test, 16))),
                  "persistent MDNN updates: in-launch evaluation not covered");
+    // (streamed W1: the held-out pairs' FACTOR rows, which lie behind the training rows in the
+    // bound block -- bsig_fit_buffers.x_kind)
+    BSIG_REQUIRE(!g.stream || b.n_train >= 1, "persistent MDNN updates: held-out factor rows need n_train");
+    p.eval_row0 = b.n_train;
     p.do_eval = 1; p.eval_every = b.eval_every; p.n_total = b.n_total; p.n_test = b.n_test;
     p.eval_passes = ceil_div(b.n_test, s.batch);
     p.x_test = b.x_test; p.ldx_test = b.ldx_test; p.y_test = b.y_test; p.ldy_test = b.ldy_test;

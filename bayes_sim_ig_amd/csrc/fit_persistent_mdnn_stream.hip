@@ -122,13 +122,17 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
   // ---- factor rows of the minibatch starting at id-table row `row0` -> Fr (row-major): slots
   //      [0, NIP) hold sf[i_lo ..] (i == S: the "1" beside mean / std), then af | mean | std | zeros.
   //      All loads of a wavefront's 13 rows are in flight together.
-  auto load_factor_rows = [&](int64_t row0) {
+  // (direct: rows row0 .. row0 + rows - 1 of x themselves -- the held-out pairs of an evaluation pass --
+  // instead of the rows the id table names)
+  auto load_factor_rows = [&](int64_t row0, bool direct = false, int rows = 0) {
+    const int nrow = direct ? rows : B;
     const int per_row = NIP + A + 8;
     constexpr int kRows = 13, kCols = 3;                    // rows per wavefront, 64-column groups
     float v[kRows][kCols];
     int fr[kRows];
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) fr[r] = p.ids[row0 + min(w + 8 * r, B - 1)];
+    for (int r = 0; r < kRows; ++r)
+      fr[r] = direct ? (int)(row0 + min(w + 8 * r, nrow - 1)) : p.ids[row0 + min(w + 8 * r, B - 1)];
 #pragma unroll
     for (int r = 0; r < kRows; ++r) asm volatile("" : "+v"(fr[r]));
     // (unconditional loads from clamped addresses, the selects afterwards: a load under a branch
@@ -155,7 +159,7 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
 #pragma unroll
       for (int u = 0; u < kCols; ++u) {
         const int c = lane + 64 * u;
-        if (b < FR && c < per_row) Fr[b * PF + c] = (b < B && live[u]) ? v[r][u] : 0.f;
+        if (b < FR && c < per_row) Fr[b * PF + c] = (b < nrow && live[u]) ? v[r][u] : 0.f;
       }
     }
   };
@@ -312,7 +316,9 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     if (p.prof && tid == 0 && epoch >= (unsigned)step0 + 2u && epoch - (unsigned)step0 - 2u < kMProfUpdates)
       p.prof[((int64_t)blockIdx.x * kMProfUpdates + (epoch - step0 - 2u)) * 16 + slot] = wall_clock64();
   };
-  auto publish_and_sum = [&](unsigned epoch) {
+  // (pub / done: the flag arrays of the hand-off -- the update's or an evaluation pass's --, dst: where
+  // the summed [B][128] slab goes)
+  auto publish_and_sum = [&](unsigned epoch, unsigned* pub, unsigned* done, float* dst, bool stamps) {
     {
       // the two k-halves meet in LDS; the [B][32] block goes out as 16-byte write-through stores
       float* X = Wc;                                       // [4][32][33]
@@ -338,11 +344,11 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (tid == 0) flag_raise(p.flag_fwd, g, epoch);
-    stamp_sum(epoch, 14);
-    if (w == 0) flags_wait(p.flag_fwd, T, epoch, lane, flagp);
+    if (tid == 0) flag_raise(pub, g, epoch);
+    if (stamps) stamp_sum(epoch, 14);
+    if (w == 0) flags_wait(pub, T, epoch, lane, flagp);
     __syncthreads();
-    stamp_sum(epoch, 15);
+    if (stamps) stamp_sum(epoch, 15);
     // my share of the B*8 quads of the block's [B, 32] columns; 32 groups of slabs per quad, partial
     // sums combined in group order
     const int nq = B * (kMNB / 4);
@@ -369,14 +375,14 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
         f32x4 s = *reinterpret_cast<const f32x4*>(part + tid * 4);
         for (int u = 1; u < kSRedGroups; ++u) s += *reinterpret_cast<const f32x4*>(part + (u * 16 + tid) * 4);
         const int qd = qb + tid, b = qd >> 3, n = (qd & 7) * 4;
-        xwg_store4(xwg_buffer(p.hpre), b * kMH + nb * kMNB + n, s.x + b1s[n], s.y + b1s[n + 1],
+        xwg_store4(xwg_buffer(dst), b * kMH + nb * kMNB + n, s.x + b1s[n], s.y + b1s[n + 1],
                    s.z + b1s[n + 2], s.w + b1s[n + 3]);
       }
       __syncthreads();
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (tid == 0) flag_raise(p.flag_red, g, epoch);
+    if (tid == 0) flag_raise(done, g, epoch);
   };
 
   // ---- where a forward step finds its factors (see forward_chunk) ---------------------------------
@@ -387,6 +393,44 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     Tb[idx * 2 + 1] = (NIP + (q.i >= S ? A + min(q.ai, 4) : q.ai)) * 4;
   }
   __syncthreads();
+
+  // ---- held-out evaluation number eidx (mdnn.py:235-242), the tile workgroups' part: a forward-only
+  //      pass per 100 held-out pairs over the weights in memory (those of the update just taken: the
+  //      pass runs while the row owners work on the next update's rows, the window in which the tile
+  //      workgroups otherwise wait), from the held-out pairs' factor rows; the summed slabs go to
+  //      eval_slabs[eidx & 1][pass], the owners evaluate from there (owner_eval).  The update's slabs
+  //      are reused: `slabs_free_at` is the flag_red tag of their last readers (0: none left).
+  //      Clobbers Fr, Ft, Wc, the chunk registers and the forward accumulators.
+  auto eval_all = [&](int eidx, unsigned slabs_free_at) {
+    for (int pass = 0; pass < p.eval_passes; ++pass) {
+      const int rows = min(B, p.n_test - pass * B);
+      if (rows <= 0) break;
+      const unsigned tag = (unsigned)eidx * 16u + (unsigned)pass + 1u;
+      if (w == 0) {
+        if (pass == 0) flags_wait(p.flag_red, T, slabs_free_at, lane, flagp);
+        else flags_wait(p.flag_evr, T, tag - 1u, lane, flagp);
+      }
+      __syncthreads();
+      load_factor_rows(p.eval_row0 + (int64_t)pass * B, true, rows);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) facc[i] = 0.f;
+      if (c_lo < c_hi) load_chunk(c_lo, false);
+      __syncthreads();
+      for (int c = c_lo; c < c_hi; ++c) {
+        weights_to_lds();
+        lds_barrier();
+        forward_chunk(c, 0, 2 * kHalf, -1, 0, c + 1 < c_hi ? c + 1 : -1, false);
+        lds_barrier();
+      }
+      publish_and_sum(tag, p.flag_evp, p.flag_evr,
+                      p.eval_slabs + ((int64_t)(eidx & 1) * p.eval_passes + pass) * B * kMH, false);
+    }
+    if (tid == 0) flag_raise(p.flag_eval, g, (unsigned)eidx + 1u);
+    // (nobody overwrites its slab -- the next update's product -- before every workgroup has read it)
+    const int last = min(p.eval_passes, (p.n_test + B - 1) / B) - 1;
+    if (w == 0 && last >= 0) flags_wait(p.flag_evr, T, (unsigned)eidx * 16u + (unsigned)last + 1u, lane, flagp);
+    __syncthreads();
+  };
 
   // ---- prologue: the forward product of the launch's first minibatch --------------------------
   if (p.n_updates > 0) {
@@ -401,7 +445,7 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
       forward_chunk(c, 0, 2 * kHalf, -1, 0, c + 1 < c_hi ? c + 1 : -1, false);
       lds_barrier();
     }
-    publish_and_sum((unsigned)step0 + 1u);
+    publish_and_sum((unsigned)step0 + 1u, p.flag_fwd, p.flag_red, p.hpre, true);
   }
 
   for (int t = 0; t < p.n_updates; ++t) {
@@ -411,6 +455,13 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     const bool moments = !(fresh && t == 0);
     relaunder();
     if (run_aborted(flagp, red, tid)) break;
+    // the evaluation due after the previous update, then this minibatch's factor rows again
+    if (!DP && __builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
+      eval_all(mdnn_evals_before(step, p.eval_every) - 1, epoch);
+      relaunder();
+      load_factor_rows((int64_t)step * B);
+      __syncthreads();
+    }
     BSIG_MSTAMP(0);
     // ---- while the owners work: the first chunk (the long fetch first), this minibatch's factor
     //      columns (dW), the next minibatch's factor rows (forward), Adam scalars
@@ -651,10 +702,16 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     }
     BSIG_MSTAMP(4);
     if (has_next) {
-      publish_and_sum(epoch + 1u);
+      publish_and_sum(epoch + 1u, p.flag_fwd, p.flag_red, p.hpre, true);
       if (c_lo < c_hi) store_chunk(c_hi - 1);              // the deferred block of the last chunk
     }
     BSIG_MSTAMP(5);
+  }
+
+  // ---- the evaluation after the last update of the call -------------------------------------------
+  if (!DP && p.do_eval && step0 + p.n_updates == p.n_total && !run_aborted(flagp, red, tid)) {
+    relaunder();
+    eval_all(mdnn_evals_before(p.n_total - 1, p.eval_every), 0u);
   }
 
   // ---- write b1 back, advance the engine state -------------------------------------------------
@@ -668,7 +725,13 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     reinterpret_cast<double*>(st + 12)[1] = b2t;
     reinterpret_cast<float*>(st)[4] = a0;
     reinterpret_cast<float*>(st)[5] = a1;
-    reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)p.n_updates;   // one jitter stream per update
+    // (one jitter stream per update and per evaluation, in program order)
+    int n_ev = 0;
+    if (!DP && p.do_eval) {
+      n_ev = mdnn_evals_before(step0 + p.n_updates, p.eval_every) - mdnn_evals_before(step0, p.eval_every);
+      if (step0 + p.n_updates == p.n_total && (p.n_total - 1) % p.eval_every != 0) ++n_ev;
+    }
+    reinterpret_cast<uint64_t*>(st + 8)[1] += (uint64_t)(p.n_updates + n_ev);
     st[0] = step0 + p.n_updates;
   }
 }

@@ -32,6 +32,7 @@ struct PersistMdnnBuffers {
   // of the call with it % eval_every == 0 and after the last of its n_total updates
   // (mdnn.py:235-242); evaluation k writes test_loss[state[1]] and advances state[1]
   int do_eval = 0; int eval_every = 1; int n_total = 0; int n_test = 0;
+  int64_t n_train = 0;   // factor rows bound as x: rows n_train .. n_train + n_test - 1 are the held-out pairs'
   const float* x_test = nullptr; int64_t ldx_test = 0;
   const float* y_test = nullptr; int64_t ldy_test = 0;
   float* test_loss = nullptr;

@@ -98,6 +98,8 @@ struct MdnnArgs {
   int s_nip, s_pf;     // factor rows in LDS: sf slots [0, s_nip), af | mean std 0.. at s_nip, pitch s_pf
   float* hpre;         // [B][128] layer-1 pre-activations summed over the tile workgroups (+ b1)
   unsigned* flag_red;  // [G1] the quads of hpre this workgroup sums are out
+  unsigned* flag_evp; unsigned* flag_evr;   // [G1] evaluation passes of a streamed plan: slab out / summed
+  int64_t eval_row0;   // first held-out factor row in x
 };
 
 constexpr int kMProfUpdates = 8;
@@ -997,9 +999,11 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     }
     float eacc = 0.f;
     for (int gp = 0; gp < p.eval_passes; ++gp) {
-      const float* slabs = p.eval_slabs + (((int64_t)(eidx & 1) * p.eval_passes + gp) * p.k_slices) * zs;
+      // (streamed W1: the tile workgroups have summed the pass already -- one slab)
+      const int ek = p.stream ? 1 : p.k_slices;
+      const float* slabs = p.eval_slabs + (((int64_t)(eidx & 1) * p.eval_passes + gp) * ek) * zs;
       {
-        const f32x4 v = slab_quads_sum<MR>(slabs, p.k_slices, (int)zs, min(r0 + (tid >> 5 & (MR - 1)), B - 1), tid, part4);
+        const f32x4 v = slab_quads_sum<MR>(slabs, ek, (int)zs, min(r0 + (tid >> 5 & (MR - 1)), B - 1), tid, part4);
         if (tid < (MR * (kMH / 4))) {
           const int r = tid >> 5, c4 = (tid & 31) * 4;
           const bool ok = r0 + r < B && gp * B + r0 + r < p.n_test;

@@ -29,7 +29,7 @@ def _guards():
     yield
     pkg.MDNN.EPS_NOISE = old
     pkg.MDNN.USE_GRAPH = True
-    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_STREAMED_W1'):
+    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_STREAMED_W1', 'BSIG_NO_STREAM_EVAL'):
         os.environ.pop(k, None)
 
 
@@ -45,7 +45,7 @@ SMALL = dict(d=3, k=5, t=8, sd=21, ad=12)
 
 def _chunk(B, cfg, n=1000, batch=100, n_updates=100, seed=3, eps=0.0, env=None, lazy=True):
     import bench
-    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_STREAMED_W1'):
+    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_STREAMED_W1', 'BSIG_NO_STREAM_EVAL'):
         os.environ.pop(k, None)
     os.environ.update(env or {})
     B.MDNN.EPS_NOISE = eps
@@ -215,3 +215,22 @@ def test_streamed_data_parallel_rank_matches_resident(B):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n', [1000, 650])
+def test_streamed_evaluations_inside_the_launch_match_the_evaluation_graphs(B, n):
+    """mdnn.py:235-242: the six held-out evaluations of a chunk.  A streamed plan (narrow heads) takes
+    them inside its ONE launch -- the tile workgroups form the held-out pairs' first-layer products from
+    their factor rows in the window in which they wait for the row owners, the owners finish them -- ;
+    BSIG_NO_STREAM_EVAL=1 runs them as graphs on materialised held-out rows between six launches.  Same
+    weights at every evaluation point (the updates are bitwise the same), the evaluation arithmetic
+    differs (summation order of the first layer).  n = 650: a ragged second evaluation pass (130
+    held-out pairs)."""
+    cfg = _cfg(**SMALL)
+    logs_i, flat_i, bs_i, _ = _chunk(B, cfg, n=n, eps=1e-5, n_updates=40)
+    logs_g, flat_g, bs_g, _ = _chunk(B, cfg, n=n, eps=1e-5, n_updates=40, env={'BSIG_NO_STREAM_EVAL': '1'})
+    assert _streams(B, bs_i) and _streams(B, bs_g)
+    assert logs_i['train_loss'] == logs_g['train_loss']
+    assert torch.equal(flat_i, flat_g)
+    assert len(logs_i['test_loss']) == 6
+    assert np.allclose(logs_i['test_loss'], logs_g['test_loss'], rtol=2e-5, atol=2e-5), (logs_i, logs_g)
