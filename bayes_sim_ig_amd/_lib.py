@@ -47,7 +47,8 @@ class FitBuffers(C.Structure):
                 ('y_test', vp), ('ldy_test', i64),
                 ('ids_table', vp), ('train_loss', vp), ('test_loss', vp),
                 ('state', vp), ('workspace', vp), ('workspace_bytes', sz),
-                ('x_kind', i32), ('x_s', i32), ('x_a', i32)]
+                ('x_kind', i32), ('x_s', i32), ('x_a', i32),
+                ('x_test_factors', vp), ('ldx_test_factors', i64)]
 
 
 _PROTOS = {

@@ -480,7 +480,7 @@ static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, int 
     pb.n_test = (int)b.n_test;
     pb.x_test = b.x_test; pb.ldx_test = b.ldx_test; pb.y_test = b.y_test; pb.ldy_test = b.ldy_test;
     pb.test_loss = b.test_loss;
-    pb.n_train = b.n_train;
+    pb.x_test_fac = b.x_test_factors; pb.ldx_test_fac = b.ldx_test_factors;
   }
   PersistHyper hy;
   hy.lr = p->cfg.lr; hy.beta1 = p->cfg.beta1; hy.beta2 = p->cfg.beta2;
@@ -1062,8 +1062,10 @@ extern "C" int bsig_fit_run(bsig_fit_plan* p, int64_t n_updates, bsig_stream_t s
   if (p->persistent && !p->split_adam && n_updates >= 1 && p->buf.n_test >= 1 &&
       !(no_ike && no_ike[0] == '1') && persist_eval_supported(persist_shape(p)))
     return enqueue_persistent(p, (int)n_updates, st, (int)n_updates);
+  // (a streamed first layer evaluates in the launch only from the held-out pairs' factor rows)
   if (p->persistent_mdnn && !p->split_adam && n_updates >= 1 && p->buf.n_test >= 1 &&
-      !(no_ike && no_ike[0] == '1') && persist_mdnn_eval_supported(persist_mdnn_shape(p)))
+      !(no_ike && no_ike[0] == '1') && persist_mdnn_eval_supported(persist_mdnn_shape(p)) &&
+      (!p->mdnn_streams || p->buf.x_test_factors))
     return enqueue_persistent_mdnn(p, (int)n_updates, st, (int)n_updates);
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
   int64_t done = 0;

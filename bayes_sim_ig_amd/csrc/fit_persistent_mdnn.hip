@@ -312,8 +312,9 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
                  "persistent MDNN updates: in-launch evaluation not covered");
     // (streamed W1: the held-out pairs' FACTOR rows, which lie behind the training rows in the
     // bound block -- bsig_fit_buffers.x_kind)
-    BSIG_REQUIRE(!g.stream || b.n_train >= 1, "persistent MDNN updates: held-out factor rows need n_train");
-    p.eval_row0 = b.n_train;
+    BSIG_REQUIRE(!g.stream || (b.x_test_fac && b.ldx_test_fac >= b.x_s + b.x_a + 3),
+                 "persistent MDNN updates: a streamed first layer evaluates from the held-out pairs' factor rows");
+    p.xe = b.x_test_fac; p.ldxe = b.ldx_test_fac;
     p.do_eval = 1; p.eval_every = b.eval_every; p.n_total = b.n_total; p.n_test = b.n_test;
     p.eval_passes = ceil_div(b.n_test, s.batch);
     p.x_test = b.x_test; p.ldx_test = b.ldx_test; p.y_test = b.y_test; p.ldy_test = b.ldy_test;

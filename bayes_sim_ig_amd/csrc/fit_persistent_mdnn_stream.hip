@@ -149,7 +149,7 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     }
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
-      const float* src = p.x + (int64_t)fr[r] * p.ldx;
+      const float* src = direct ? p.xe + (int64_t)fr[r] * p.ldxe : p.x + (int64_t)fr[r] * p.ldx;
 #pragma unroll
       for (int u = 0; u < kCols; ++u) v[r][u] = src[ofs[u]];
     }
@@ -411,7 +411,7 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
         else flags_wait(p.flag_evr, T, tag - 1u, lane, flagp);
       }
       __syncthreads();
-      load_factor_rows(p.eval_row0 + (int64_t)pass * B, true, rows);
+      load_factor_rows((int64_t)pass * B, true, rows);
 #pragma unroll
       for (int i = 0; i < 16; ++i) facc[i] = 0.f;
       if (c_lo < c_hi) load_chunk(c_lo, false);

@@ -32,7 +32,8 @@ struct PersistMdnnBuffers {
   // of the call with it % eval_every == 0 and after the last of its n_total updates
   // (mdnn.py:235-242); evaluation k writes test_loss[state[1]] and advances state[1]
   int do_eval = 0; int eval_every = 1; int n_total = 0; int n_test = 0;
-  int64_t n_train = 0;   // factor rows bound as x: rows n_train .. n_train + n_test - 1 are the held-out pairs'
+  // streamed first layer: the held-out pairs' factor rows (in-launch evaluation)
+  const float* x_test_fac = nullptr; int64_t ldx_test_fac = 0;
   const float* x_test = nullptr; int64_t ldx_test = 0;
   const float* y_test = nullptr; int64_t ldy_test = 0;
   float* test_loss = nullptr;

@@ -99,7 +99,7 @@ struct MdnnArgs {
   float* hpre;         // [B][128] layer-1 pre-activations summed over the tile workgroups (+ b1)
   unsigned* flag_red;  // [G1] the quads of hpre this workgroup sums are out
   unsigned* flag_evp; unsigned* flag_evr;   // [G1] evaluation passes of a streamed plan: slab out / summed
-  int64_t eval_row0;   // first held-out factor row in x
+  const float* xe; int64_t ldxe;   // streamed plan: the held-out pairs' factor rows
 };
 
 constexpr int kMProfUpdates = 8;

@@ -594,6 +594,8 @@ class MDNN(nn.Module):
         fb.workspace, fb.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         if factored:
             fb.x_kind, fb.x_s, fb.x_a = _lib.X_CROSSCORR_FACTORS, x_data.s_dim, x_data.a_dim
+            if n_test > 0:      # the held-out pairs' factor rows lie behind the training rows
+                fb.x_test_factors, fb.ldx_test_factors = x_stage.data_ptr() + 4 * n_train * ldx, ldx
         flags = (_lib.FIT_GRAPH if type(self).USE_GRAPH else 0) | \
             (_lib.FIT_SPLIT_ADAM if self._dp is not None else 0)
         _lib.check(lib.bsig_fit_bind(self._plan, C.byref(fb), flags))

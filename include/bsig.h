@@ -265,6 +265,11 @@ typedef struct bsig_fit_buffers {
    * row and call); the held-out x_test rows, read once per evaluation, are always summary
    * rows (bsig_crosscorr_expand of their factor rows). */
   int32_t x_kind; int32_t x_s; int32_t x_a;
+  /* optional, with x_kind == BSIG_X_CROSSCORR_FACTORS: the factor rows of the n_test held-out
+   * pairs (same layout as the x_train rows).  A plan whose first layer is streamed
+   * (bsig_fit_accepts_factor_rows) then takes its evaluations inside the launch of the run,
+   * from these rows; without them (NULL) it runs them between its launches on x_test. */
+  const float* x_test_factors; int64_t ldx_test_factors;
 } bsig_fit_buffers;
 #define BSIG_X_ROWS 0
 #define BSIG_X_CROSSCORR_FACTORS 1
