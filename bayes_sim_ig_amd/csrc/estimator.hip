@@ -930,8 +930,8 @@ static int dp_eval_total(const bsig_fit_plan* p) {
   const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
   if (!p->split_adam || p->buf.n_test < 1 || p->n_updates < 1 || (no_ike && no_ike[0] == '1')) return 0;
   if (p->persistent && persist_eval_supported(persist_shape(p))) return (int)p->n_updates;
-  // (a data-parallel rank of a streamed first layer evaluates between its launches)
-  if (p->persistent_mdnn && !p->mdnn_streams && persist_mdnn_eval_supported(persist_mdnn_shape(p)))
+  // (a data-parallel rank of a streamed first layer or of wide heads evaluates between its launches)
+  if (p->persistent_mdnn && persist_mdnn_dp_eval_supported(persist_mdnn_shape(p)))
     return (int)p->n_updates;
   return 0;
 }

@@ -117,7 +117,11 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   g->dout_floats = (size_t)s.batch * g->NhP;
   // in-launch evaluations: slabs of both parities and the parked head outputs
   g->eval_passes = s.max_test > 0 ? ceil_div(s.max_test, s.batch) : 0;
-  if (g->eval_passes > 8 || g->wide) g->eval_passes = 0;   // wide heads: evaluation graphs between launches
+  if (g->eval_passes > 8) g->eval_passes = 0;
+  if (g->wide) {   // (A/B switch: a wide-head plan's evaluations as graphs between its launches)
+    const char* e = getenv("BSIG_NO_WIDE_EVAL");
+    if (e && e[0] == '1') g->eval_passes = 0;
+  }
   if (g->stream) {   // (A/B switch: a streamed plan's evaluations as graphs between its launches)
     const char* e = getenv("BSIG_NO_STREAM_EVAL");
     if (e && e[0] == '1') g->eval_passes = 0;
@@ -125,7 +129,8 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   // (streamed W1: an evaluation pass leaves ONE summed slab [B][128], like an update)
   g->eval_slab_floats = g->stream ? g->act_floats : g->slab_floats;
   g->eval_floats = (size_t)2 * g->eval_passes * g->eval_slab_floats +
-                   (size_t)g->eval_passes * s.batch * g->NhP;
+                   (size_t)g->eval_passes * s.batch * g->NhP +
+                   (g->wide && g->eval_passes > 0 ? g->act_floats + g->dout_floats : 0);   // h2e, oe
   return true;
 }
 
@@ -169,6 +174,11 @@ bool persist_mdnn_eval_supported(const PersistMdnnShape& s) {
   MdnnGeom g;
   return mdnn_geom(s, &g) && mdnn_device_can_host(g) && g.eval_passes > 0;
 }
+// ... by a data-parallel rank (one launch per update): narrow heads on a resident first layer only
+bool persist_mdnn_dp_eval_supported(const PersistMdnnShape& s) {
+  MdnnGeom g;
+  return mdnn_geom(s, &g) && mdnn_device_can_host(g) && g.eval_passes > 0 && !g.wide && !g.stream;
+}
 
 constexpr size_t kPackFloats = (size_t)2 * kMH * kMH;   // both parities
 static size_t mdnn_wide_floats(const MdnnGeom& g) {
@@ -178,7 +188,7 @@ static size_t mdnn_data_bytes(const MdnnGeom& g) {
   return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats + 2 * kPackFloats +
                            g.eval_floats + mdnn_wide_floats(g) + (g.stream ? g.act_floats : 0)) * sizeof(float), 256);
 }
-static size_t mdnn_sync_bytes() { return 12 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
+static size_t mdnn_sync_bytes() { return 14 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
 
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
   MdnnGeom g;
@@ -281,7 +291,9 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.eval_slabs = p.w2b_pack + kPackFloats;
   p.eval_out = p.eval_slabs + (size_t)2 * g.eval_passes * g.eval_slab_floats;
   p.wide = g.wide; p.n_hb = g.NhP / kMNB;
-  p.o_wide = p.eval_out + (size_t)g.eval_passes * s.batch * g.NhP;
+  p.h2e = p.eval_out + (size_t)g.eval_passes * s.batch * g.NhP;     // (wide heads with evaluations only)
+  p.oe = p.h2e + (g.wide && g.eval_passes > 0 ? g.act_floats : 0);
+  p.o_wide = p.oe + (g.wide && g.eval_passes > 0 ? g.dout_floats : 0);
   p.dz2_part = p.o_wide + g.dout_floats;
   p.hpre = g.wide ? p.dz2_part + (size_t)(g.NhP / kMNB) * g.act_floats : p.o_wide;   // (o_wide / dz2_part: wide plans only)
   p.stream = g.stream; p.s_chunks = g.s_chunks; p.s_nip = s_nip; p.s_pf = s_pf;
@@ -302,7 +314,9 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.o_flags = g.stream ? p.flag_red : p.flag_fwd;
   p.flag_evp = p.flag_red + kFlagArr;     // streamed W1, evaluation passes: slab out / quads summed
   p.flag_evr = p.flag_evp + kFlagArr;
-  p.gran = reinterpret_cast<unsigned long long*>(sync + 12 * kFlagArr * sizeof(unsigned));
+  p.flag_h2e = p.flag_evr + kFlagArr;
+  p.flag_oe = p.flag_h2e + kFlagArr;
+  p.gran = reinterpret_cast<unsigned long long*>(sync + 14 * kFlagArr * sizeof(unsigned));
   p.gran_eval = p.gran + 3 * kGranArr;
   if (b.do_eval) {
     BSIG_REQUIRE(g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&

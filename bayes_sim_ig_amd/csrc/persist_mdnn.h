@@ -50,6 +50,7 @@ int persist_mdnn_streams(const PersistMdnnShape& s);
 bool persist_mdnn_accepts_factors(const PersistMdnnShape& s, int S, int A);
 // ... and the held-out evaluations of up to s.max_test rows can run inside the launches
 bool persist_mdnn_eval_supported(const PersistMdnnShape& s);
+bool persist_mdnn_dp_eval_supported(const PersistMdnnShape& s);
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s);
 struct ZeroRegion;   // persist.h
 int persist_mdnn_reset_regions(const PersistMdnnShape& s, void* workspace, size_t workspace_bytes,

@@ -100,6 +100,10 @@ struct MdnnArgs {
   unsigned* flag_red;  // [G1] the quads of hpre this workgroup sums are out
   unsigned* flag_evp; unsigned* flag_evr;   // [G1] evaluation passes of a streamed plan: slab out / summed
   const float* xe; int64_t ldxe;   // streamed plan: the held-out pairs' factor rows
+  // wide heads, evaluation passes: h2 rows of the held-out pairs [B][128] out (owners), their head
+  // outputs [n_hb][B][32] out (head blocks)  (last: the offsets of the fields above are the ones the
+  // update loop's register allocation was tuned with)
+  float* h2e; float* oe; unsigned* flag_h2e; unsigned* flag_oe;
 };
 
 constexpr int kMProfUpdates = 8;
@@ -579,6 +583,75 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   }
 }
 
+// ---- wide heads, held-out evaluation number eidx, a head-block workgroup's part: head outputs of
+//      the pass's rows for its 32 columns, from the h2 rows the owners publish (h2e) to
+//      oe [n_hb][B][32]; the weights are those of the operand copy Wb / bsh.  Deliberately NOT
+//      inlined: it runs six times per call, and its registers (and the scalar arguments it keeps)
+//      must not weigh on the update loops of the kernel -- inlined, the tile workgroups' loop spilled.
+__device__ __attribute__((noinline)) void mdnn_serve_eval(float* Hs, const float* Wb, float* Xo, const float* bsh,
+                                                          const float* h2e, float* oe, unsigned* flag_h2e,
+                                                          unsigned* flag_oe, int32_t* flagp, int eval_passes,
+                                                          int n_test, int B, int n_owner, int hb, int eidx) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  for (int gp = 0; gp < eval_passes; ++gp) {
+    if (n_test - gp * B <= 0) break;
+    const unsigned wtag = (unsigned)eidx * 16u + (unsigned)gp + 1u;
+    if (w == 0) flags_wait(flag_h2e, n_owner, wtag, lane, flagp);
+    __syncthreads();
+    {
+      const __amdgpu_buffer_rsrc_t hr = xwg_buffer(h2e);
+      for (int base = 0; base < B * (kMH / 4); base += kMT * 4) {
+        f32x4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = min(base + u * kMT + tid, B * (kMH / 4) - 1);
+          q[u] = xwg_load4(hr, (idx >> 5) * kMH + (idx & 31) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * kMT + tid;
+          if (idx < B * (kMH / 4))
+            *reinterpret_cast<f32x4*>(Hs + (idx >> 5) * kMHP + (idx & 31) * 4) = q[u];
+        }
+      }
+    }
+    __syncthreads();
+    const int mt = w & 3, kh = w >> 2;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* ap = Hs + (mt * 32 + l31) * kMHP + kh * 64 + 4 * h;
+    const float* bp = Wb + l31 * kMHP + kh * 64 + 4 * h;
+#pragma unroll 4
+    for (int kk = 0; kk < 64; kk += 8) {
+      const float4 a4 = *reinterpret_cast<const float4*>(ap + kk);
+      const float4 b4 = *reinterpret_cast<const float4*>(bp + kk);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Xo[(mt * 32 + acc_row(i, h)) * kMPbuf + l31] = acc[i];
+    }
+    __syncthreads();
+    if (kh == 0) {
+      const float bias = bsh[l31];
+      float* dst = fresh_ptr(oe + ((int64_t)hb * B + mt * 32 + 4 * h) * kMNB + l31);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = mt * 32 + acc_row(i, h);
+        if (row < B) xwg_store(dst + acc_row0(i) * kMNB, acc[i] + Xo[row * kMPbuf + l31] + bias);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) flag_raise(flag_oe, hb, wtag);
+  }
+}
+
 // ---- small-weight workgroups: 32 rows of W2 or of the head matrix ----------------
 template <bool DP, bool WIDE>
 __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* smem) {
@@ -679,6 +752,15 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
     flag_raise(p.flag_pack, sb, p.launch_tag);
   for (int idx = tid; idx < (p.FR - B) * kMHP; idx += kMT) Hs[B * kMHP + idx] = 0.f;
   __syncthreads();
+
+  // (wide heads: the head outputs of an evaluation pass -- mdnn_serve_eval, out of line)
+  auto serve_eval = [&](int eidx) {
+    if constexpr (WIDE) {
+      if (whead)
+        mdnn_serve_eval(Hs, Wb, Xo, bsh, p.h2e, p.oe, p.flag_h2e, p.flag_oe, flagp, p.eval_passes, p.n_test,
+                        B, p.n_owner, hb, eidx);
+    }
+  };
 
   for (int t = 0; t < p.n_updates; ++t) {
     const int step = step0 + t;
@@ -857,6 +939,15 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
         xwg_store(p.params + b_off + n0 + lane, bw);
       }
     }
+    // wide heads: the evaluation due after the PREVIOUS update asks for head outputs now -- the owners
+    // run it behind this update's rows -- and wants that update's weights: the operand copy, before
+    // it is refreshed with this update's step
+    if constexpr (WIDE && !DP) {
+      if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
+        __syncthreads();
+        serve_eval(mdnn_evals_before(step, p.eval_every) - 1);
+      }
+    }
     if (!DP) {
       BSIG_REFRESH_OPERAND_COPY()   // (all reads of the old copy are behind the barrier above)
       __builtin_amdgcn_s_waitcnt(0);
@@ -865,6 +956,11 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
         flag_raise(p.flag_small, sb, epoch);
     }
     BSIG_MSTAMP(6);
+  }
+  // the evaluation after the last update of the call (the operand copy holds that update's weights)
+  if constexpr (WIDE && !DP) {
+    if (p.do_eval && step0 + p.n_updates == p.n_total && !run_aborted(flagp, red, tid))
+      serve_eval(mdnn_evals_before(p.n_total - 1, p.eval_every));
   }
   if (!DP) {
 #pragma unroll
@@ -979,14 +1075,18 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       // (a data-parallel rank has them behind flag_pack, waited for at the top)
       if (!DP && w == 0) flags_wait(p.flag_small, p.n_small, (unsigned)step, lane, flagp);
       __syncthreads();
-      const __amdgpu_buffer_rsrc_t whr = xwg_buffer(Wh);
-      for (int idx = tid; idx < Nh16 * (kMH / 4); idx += kMT) {
-        const int n = idx >> 5, c4 = (idx & 31) * 4;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(Whs + n * kMH + (c4 ^ (4 * (n & 15)))) = n < Nh ? xwg_load4(whr, n * kMH + c4) : zero;
+      if constexpr (!WIDE) {
+        const __amdgpu_buffer_rsrc_t whr = xwg_buffer(Wh);
+        for (int idx = tid; idx < Nh16 * (kMH / 4); idx += kMT) {
+          const int n = idx >> 5, c4 = (idx & 31) * 4;
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(Whs + n * kMH + (c4 ^ (4 * (n & 15)))) = n < Nh ? xwg_load4(whr, n * kMH + c4) : zero;
+        }
       }
       if (tid < kMH) b2s[tid] = xwg_load(p.params + p.b2_off + tid);
-      for (int j = tid; j < Nh16; j += kMT) bhs[j] = j < Nh ? xwg_load(p.params + p.bh_off + j) : 0.f;
+      if constexpr (!WIDE) {
+        for (int j = tid; j < Nh16; j += kMT) bhs[j] = j < Nh ? xwg_load(p.params + p.bh_off + j) : 0.f;
+      }
     }
     if (w == 0) flags_wait(p.flag_eval, p.G1, etag, lane, flagp);
     __syncthreads();
@@ -1027,12 +1127,57 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         if (4 * g < MR) {
           const int n = 16 * w + c16;
           const float bias = b2s[n];
+          if constexpr (WIDE) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * kMHP + n] = tanhf(acc[r] + bias);
+            for (int r = 0; r < 4; ++r) {
+              const float v = tanhf(acc[r] + bias);
+              H2s[(4 * g + r) * kMHP + n] = v;
+              if (r0 + 4 * g + r < B) xwg_store(p.h2e + (int64_t)(r0 + 4 * g + r) * kMH + n, v);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * kMHP + n] = tanhf(acc[r] + bias);
+          }
         }
       }
+      if constexpr (WIDE) __builtin_amdgcn_s_waitcnt(0);   // h2 rows are out before the flag
       __syncthreads();
-      for (int cb = w; cb * 16 < Nh16; cb += 8) {
+      if constexpr (WIDE) {
+        // wide heads: the head-block workgroups form the pass's head outputs (with the weights of the
+        // evaluated update: they serve this before they refresh their operand copies)
+        const unsigned wtag = (unsigned)eidx * 16u + (unsigned)gp + 1u;
+        if (tid == 0) flag_raise(p.flag_h2e, o, wtag);
+        if (w == 0) flags_wait(p.flag_oe, p.n_hb, wtag, lane, flagp);
+        __syncthreads();
+        const int per_row = p.n_hb * (kMNB / 4), n_items = MR * per_row;
+        const __amdgpu_buffer_rsrc_t orr = xwg_buffer(p.oe);
+        for (int base = 0; base < n_items; base += 4 * kMT) {
+          f32x4 q[4];
+          int rr[4], jj[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = min(base + u * kMT + tid, n_items - 1);
+            const int r = idx / per_row, rem = idx - r * per_row;
+            rr[u] = r; jj[u] = (rem >> 3) * kMNB + (rem & 7) * 4;
+            q[u] = xwg_load4(orr, ((rem >> 3) * B + min(r0 + r, B - 1)) * kMNB + (rem & 7) * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (base + u * kMT + tid < n_items) {
+              const bool rok = r0 + rr[u] < B && gp * B + r0 + rr[u] < p.n_test;
+              const float v4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int j = jj[u] + e;
+                const float v = rok && j < Nh ? v4[e] : 0.f;
+                if (j < Nh16) Os[rr[u] * po + j] = v;
+                if (rok && j >= K + DK && j < K + 2 * DK) eacc += expf(v);
+              }
+            }
+          }
+        }
+      }
+      for (int cb = w; !WIDE && cb * 16 < Nh16; cb += 8) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int n = 16 * cb + c16;
         const float* ap = H2s + rowA * kMHP + 4 * g;
@@ -1487,13 +1632,13 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     }
     // the evaluation due after the previous update: the tile workgroups formed its
     // first-layer products while this update's rows were being finished
-    if (!WIDE && __builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
+    if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
       __syncthreads();
       owner_eval(mdnn_evals_before(step, p.eval_every) - 1,
                  rng_ctr0 + (uint64_t)t + (uint64_t)(mdnn_evals_before(step, p.eval_every) - ev0) - 1u, step, false);
     }
   }
-  if (!WIDE && p.do_eval && step0 + p.n_updates == p.n_total && (!DP || p.n_updates == 0) &&
+  if (p.do_eval && step0 + p.n_updates == p.n_total && (!DP || p.n_updates == 0) &&
       !run_aborted(flagp, red, tid_0))
     owner_eval(mdnn_evals_before(p.n_total - 1, p.eval_every),
                rng_ctr0 + (uint64_t)p.n_updates +
