@@ -29,7 +29,7 @@ def _guards():
     yield
     pkg.MDNN.EPS_NOISE = old
     pkg.MDNN.USE_GRAPH = True
-    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_STREAMED_W1', 'BSIG_NO_STREAM_EVAL'):
+    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_STREAMED_W1', 'BSIG_NO_STREAM_EVAL', 'BSIG_NO_WIDE_EVAL'):
         os.environ.pop(k, None)
 
 
@@ -45,7 +45,7 @@ SMALL = dict(d=3, k=5, t=8, sd=21, ad=12)
 
 def _chunk(B, cfg, n=1000, batch=100, n_updates=100, seed=3, eps=0.0, env=None, lazy=True):
     import bench
-    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_STREAMED_W1', 'BSIG_NO_STREAM_EVAL'):
+    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_STREAMED_W1', 'BSIG_NO_STREAM_EVAL', 'BSIG_NO_WIDE_EVAL'):
         os.environ.pop(k, None)
     os.environ.update(env or {})
     B.MDNN.EPS_NOISE = eps
@@ -230,6 +230,26 @@ def test_streamed_evaluations_inside_the_launch_match_the_evaluation_graphs(B, n
     logs_i, flat_i, bs_i, _ = _chunk(B, cfg, n=n, eps=1e-5, n_updates=40)
     logs_g, flat_g, bs_g, _ = _chunk(B, cfg, n=n, eps=1e-5, n_updates=40, env={'BSIG_NO_STREAM_EVAL': '1'})
     assert _streams(B, bs_i) and _streams(B, bs_g)
+    assert logs_i['train_loss'] == logs_g['train_loss']
+    assert torch.equal(flat_i, flat_g)
+    assert len(logs_i['test_loss']) == 6
+    assert np.allclose(logs_i['test_loss'], logs_g['test_loss'], rtol=2e-5, atol=2e-5), (logs_i, logs_g)
+
+
+@pytest.mark.parametrize('streamed', [True, False])
+def test_wide_heads_evaluate_inside_the_launch(B, streamed):
+    """Wide heads (10 components x D = 17: the head-block workgroups form the head outputs): the
+    evaluations inside the launch -- owners publish the pass's h2 rows, the head blocks return the head
+    outputs with the evaluated update's weights (their operand copies, before the refresh) -- against
+    BSIG_NO_WIDE_EVAL=1 (evaluation graphs between the launches).  streamed: first layer streamed
+    (I = 15362); else resident (I = 1026)."""
+    cfg = _cfg(d=17, k=10, t=8, sd=21, ad=12) if streamed else _cfg(d=17, k=10, t=8, sd=5, ad=4)
+    logs_i, flat_i, bs_i, _ = _chunk(B, cfg, eps=1e-5, n_updates=40)
+    logs_g, flat_g, bs_g, _ = _chunk(B, cfg, eps=1e-5, n_updates=40, env={'BSIG_NO_WIDE_EVAL': '1'})
+    lib = B._lib.load()
+    assert lib.bsig_fit_is_persistent(bs_i.model._plan) == 2 and lib.bsig_fit_is_persistent(bs_g.model._plan) == 2
+    if streamed:
+        assert _streams(B, bs_i)
     assert logs_i['train_loss'] == logs_g['train_loss']
     assert torch.equal(flat_i, flat_g)
     assert len(logs_i['test_loss']) == 6
