@@ -1017,6 +1017,50 @@ __device__ __forceinline__ f32x4 slab_quads_sum(const float* slabs, int k_slices
   return v;
 }
 
+// ---- wide heads, an owner's part of an evaluation pass: flag its h2 rows (stored, acknowledged),
+//      wait for the head blocks' outputs, fetch its MR rows of them into Os; returns this thread's
+//      share of sum(exp(pre)).  Out of line for the same reason as mdnn_serve_eval.
+template <int MR>
+__device__ __attribute__((noinline)) float mdnn_owner_eval_heads(unsigned* flag_h2e, unsigned* flag_oe, const float* oe,
+                                                                 int32_t* flagp, float* Os, int po, int o, int n_hb,
+                                                                 int B, int r0, int Nh, int Nh16, int K, int DK,
+                                                                 int n_test, int gp, int eidx) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const unsigned wtag = (unsigned)eidx * 16u + (unsigned)gp + 1u;
+  float eacc = 0.f;
+  if (tid == 0) flag_raise(flag_h2e, o, wtag);
+  if (w == 0) flags_wait(flag_oe, n_hb, wtag, lane, flagp);
+  __syncthreads();
+  const int per_row = n_hb * (kMNB / 4), n_items = MR * per_row;
+  const __amdgpu_buffer_rsrc_t orr = xwg_buffer(oe);
+  for (int base = 0; base < n_items; base += 4 * kMT) {
+    f32x4 q[4];
+    int rr[4], jj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(base + u * kMT + tid, n_items - 1);
+      const int r = idx / per_row, rem = idx - r * per_row;
+      rr[u] = r; jj[u] = (rem >> 3) * kMNB + (rem & 7) * 4;
+      q[u] = xwg_load4(orr, ((rem >> 3) * B + min(r0 + r, B - 1)) * kMNB + (rem & 7) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (base + u * kMT + tid < n_items) {
+        const bool rok = r0 + rr[u] < B && gp * B + r0 + rr[u] < n_test;
+        const float v4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = jj[u] + e;
+          const float v = rok && j < Nh ? v4[e] : 0.f;
+          if (j < Nh16) Os[rr[u] * po + j] = v;
+          if (rok && j >= K + DK && j < K + 2 * DK) eacc += expf(v);
+        }
+      }
+    }
+  }
+  return eacc;
+}
+
 template <bool DP, bool WIDE, bool FULL, int MR = kMR>
 __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
   const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
@@ -1145,37 +1189,8 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       if constexpr (WIDE) {
         // wide heads: the head-block workgroups form the pass's head outputs (with the weights of the
         // evaluated update: they serve this before they refresh their operand copies)
-        const unsigned wtag = (unsigned)eidx * 16u + (unsigned)gp + 1u;
-        if (tid == 0) flag_raise(p.flag_h2e, o, wtag);
-        if (w == 0) flags_wait(p.flag_oe, p.n_hb, wtag, lane, flagp);
-        __syncthreads();
-        const int per_row = p.n_hb * (kMNB / 4), n_items = MR * per_row;
-        const __amdgpu_buffer_rsrc_t orr = xwg_buffer(p.oe);
-        for (int base = 0; base < n_items; base += 4 * kMT) {
-          f32x4 q[4];
-          int rr[4], jj[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int idx = min(base + u * kMT + tid, n_items - 1);
-            const int r = idx / per_row, rem = idx - r * per_row;
-            rr[u] = r; jj[u] = (rem >> 3) * kMNB + (rem & 7) * 4;
-            q[u] = xwg_load4(orr, ((rem >> 3) * B + min(r0 + r, B - 1)) * kMNB + (rem & 7) * 4);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (base + u * kMT + tid < n_items) {
-              const bool rok = r0 + rr[u] < B && gp * B + r0 + rr[u] < p.n_test;
-              const float v4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int j = jj[u] + e;
-                const float v = rok && j < Nh ? v4[e] : 0.f;
-                if (j < Nh16) Os[rr[u] * po + j] = v;
-                if (rok && j >= K + DK && j < K + 2 * DK) eacc += expf(v);
-              }
-            }
-          }
-        }
+        eacc += mdnn_owner_eval_heads<MR>(p.flag_h2e, p.flag_oe, p.oe, flagp, Os, po, o, p.n_hb, B, r0, Nh, Nh16,
+                                          K, DK, p.n_test, gp, eidx);
       }
       for (int cb = w; !WIDE && cb * 16 < Nh16; cb += 8) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
