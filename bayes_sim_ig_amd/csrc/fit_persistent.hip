@@ -782,8 +782,10 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
 template <bool DP>
 __global__ __launch_bounds__(kPT) void linear_head_updates_kernel(PersistArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifndef BSIG_HOST_SAN_BUILD   // (see fit_persistent_mdnn.hip)
   if ((int)blockIdx.x < p.G) tile_workgroup<DP>(p, smem);
   else owner_workgroup(p, smem);
+#endif
 }
 
 // ---------------------------------------------------------------- host side

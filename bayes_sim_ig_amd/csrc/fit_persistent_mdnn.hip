@@ -41,10 +41,14 @@ namespace bsig {
 template <bool DP, bool FAC, bool WIDE, bool FULL>
 __global__ __launch_bounds__(kMT) void mdnn_updates_kernel(MdnnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // (BSIG_HOST_SAN_BUILD: tools/build_host_san.sh checks the HOST side under the sanitizers and
+  // launches nothing -- the device bodies, minutes of compile time, are left out of that build)
+#ifndef BSIG_HOST_SAN_BUILD
   const int wg = blockIdx.x;
   if (wg < p.G1) mdnn_tile_workgroup<DP, FAC>(p, smem);
   else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP, WIDE, FULL>(p, smem);
   else mdnn_small_workgroup<DP, WIDE>(p, smem);
+#endif
 }
 
 // ---------------------------------------------------------------- host side

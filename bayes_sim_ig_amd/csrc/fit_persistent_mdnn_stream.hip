@@ -740,11 +740,13 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
 template <bool DP, bool WIDE, bool FULL>
 __global__ __launch_bounds__(kMT) void mdnn_stream_updates_kernel(MdnnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifndef BSIG_HOST_SAN_BUILD
   const int wg = blockIdx.x;
   if (wg < p.G1) mdnn_stream_tile_workgroup<DP>(p, smem);
 #ifndef BSIG_STREAM_TILE_ONLY   // (resource usage of the tile body alone)
   else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP, WIDE, FULL, kStreamMR>(p, smem);
   else mdnn_small_workgroup<DP, WIDE>(p, smem);
+#endif
 #endif
 }
 

@@ -496,6 +496,7 @@ constexpr int lds_floats() { return KMAJOR ? BK * ROWS : ROWS * BKP; }
 
 template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int AVEC, int BVEC>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
+#ifndef BSIG_HOST_SAN_BUILD   // (the host-sanitizer build launches nothing: fit_persistent_mdnn.hip)
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int kAs = lds_floats<BM, AKM>(), kBs = lds_floats<BN, BKM>();
@@ -696,6 +697,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmParams p) {
     const float s = block_sum(exp_acc, smem);
     if (tid == 0) p.expsum[by * gridDim.x + bx] = s;
   }
+#endif
 }
 
 template <int WM, int WN, int TM, int TN>

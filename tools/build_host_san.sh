@@ -10,7 +10,7 @@ cd "$(dirname "$0")/.."
 SRC=bayes_sim_ig_amd/csrc
 OUT=build/host_san
 mkdir -p "$OUT"
-FLAGS="--offload-arch=gfx950 -O1 -std=c++17 -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-gpu-sanitize -fno-omit-frame-pointer -w"
+FLAGS="--offload-arch=gfx950 -O1 -std=c++17 -fPIC -DBSIG_HOST_SAN_BUILD -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-gpu-sanitize -fno-omit-frame-pointer -w"
 COMMON=$(cat "$SRC"/*.h include/bsig.h | sha256sum | cut -d' ' -f1)
 pids=()
 build_one() {  # name, source
