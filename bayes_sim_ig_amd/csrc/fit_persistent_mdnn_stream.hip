@@ -448,16 +448,22 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
     publish_and_sum((unsigned)step0 + 1u, p.flag_fwd, p.flag_red, p.hpre, true);
   }
 
-  for (int t = 0; t < p.n_updates; ++t) {
+  // (one more trip than updates when the call's last evaluation is due: the evaluation passes have
+  // ONE call site -- inlined twice they cost the chunk loop registers: spills inside the pass)
+  const bool eval_last = !DP && p.do_eval && step0 + p.n_updates == p.n_total;
+  for (int t = 0; t < p.n_updates + (eval_last ? 1 : 0); ++t) {
     const int step = step0 + t;
     const unsigned epoch = (unsigned)step + 1u;
+    const bool tail = t == p.n_updates;                    // only the evaluation after the last update
     const bool has_next = !DP && t + 1 < p.n_updates;
     const bool moments = !(fresh && t == 0);
     relaunder();
     if (run_aborted(flagp, red, tid)) break;
     // the evaluation due after the previous update, then this minibatch's factor rows again
-    if (!DP && __builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
-      eval_all(mdnn_evals_before(step, p.eval_every) - 1, epoch);
+    if (!DP && __builtin_expect(p.do_eval && step > 0 && ((step - 1) % p.eval_every == 0 || tail), 0)) {
+      eval_all(tail ? mdnn_evals_before(p.n_total - 1, p.eval_every) : mdnn_evals_before(step, p.eval_every) - 1,
+               tail ? 0u : epoch);
+      if (tail) break;
       relaunder();
       load_factor_rows((int64_t)step * B);
       __syncthreads();
@@ -706,12 +712,6 @@ __device__ __forceinline__ void mdnn_stream_tile_workgroup(const MdnnArgs& p, fl
       if (c_lo < c_hi) store_chunk(c_hi - 1);              // the deferred block of the last chunk
     }
     BSIG_MSTAMP(5);
-  }
-
-  // ---- the evaluation after the last update of the call -------------------------------------------
-  if (!DP && p.do_eval && step0 + p.n_updates == p.n_total && !run_aborted(flagp, red, tid)) {
-    relaunder();
-    eval_all(mdnn_evals_before(p.n_total - 1, p.eval_every), 0u);
   }
 
   // ---- write b1 back, advance the engine state -------------------------------------------------
