@@ -88,7 +88,13 @@ static bool plan_gemm_large(int64_t m, int64_t n, int64_t k, size_t ws_bytes, Ge
   // whole-width tiles run the forward product at 0.52 and dW at 0.51-0.58 of the fp32 MFMA peak, no
   // better than the 96-wide ones -- one wavefront per SIMD does not hide the operand latency -- so
   // they stay opt-in: BSIG_GEMM_WIDE_TILE=1)
+  // (and they are only in a library built with BSIG_BUILD_WIDE_TILES=1 ./build.sh: each of the two
+  // takes 3.5 minutes to compile, longer than the rest of the library together)
+#ifdef BSIG_WITH_WIDE_TILES
   const bool wide_ok = env_int("BSIG_GEMM_WIDE_TILE", 0) != 0;
+#else
+  const bool wide_ok = false;
+#endif
   double best = 0.0;
   int best_t = -1;
   int64_t best_tiles = 0;
@@ -213,10 +219,12 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     rc = launch_tile_128x96(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else if (pl.tile == TILE_96x128)
     rc = launch_tile_96x128(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
+#ifdef BSIG_WITH_WIDE_TILES
   else if (pl.tile == TILE_128x288)
     rc = launch_tile_128x288(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else if (pl.tile == TILE_288x128)
     rc = launch_tile_288x128(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
+#endif
   else
     rc = launch_tile_64(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   if (rc != BSIG_OK) return rc;

@@ -15,6 +15,10 @@ print('0x%016xull' % h)
 PY
 )
 FLAGS="${BSIG_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBSIG_HEADER_HASH=$HHASH"
+# the whole-width GEMM tiles (measured slower than the planner's picks; 3.5 minutes of
+# compile time each) are built on request only: BSIG_BUILD_WIDE_TILES=1 ./build.sh, then BSIG_GEMM_WIDE_TILE=1
+WIDE_TILES=""
+if [ "${BSIG_BUILD_WIDE_TILES:-0}" = "1" ]; then FLAGS="$FLAGS -DBSIG_WITH_WIDE_TILES"; WIDE_TILES="gemm_tile_128x288 gemm_tile_288x128"; fi
 COMMON=$(cat "$SRC"/*.h include/bsig.h | sha256sum | cut -d' ' -f1)
 pids=()
 build_one() {  # name, source, extra flags
@@ -25,7 +29,8 @@ build_one() {  # name, source, extra flags
     pids+=($!)
   fi
 }
-for f in summarizers gemm_f32 gemm_tile_64 gemm_tile_128 gemm_tile_128x32 gemm_tile_128x64 gemm_tile_128x96 gemm_tile_96x128 gemm_tile_128x288 gemm_tile_288x128 mdn_head flat_ops estimator fit_persistent fit_persistent_mdnn fit_persistent_mdnn_stream; do
+[ -n "$WIDE_TILES" ] || rm -f "$OUT"/obj/gemm_tile_128x288.* "$OUT"/obj/gemm_tile_288x128.*
+for f in summarizers gemm_f32 gemm_tile_64 gemm_tile_128 gemm_tile_128x32 gemm_tile_128x64 gemm_tile_128x96 gemm_tile_96x128 $WIDE_TILES mdn_head flat_ops estimator fit_persistent fit_persistent_mdnn fit_persistent_mdnn_stream; do
   build_one "$f" "$SRC/$f.hip" ""
 done
 for f in api comm; do

@@ -1,5 +1,6 @@
 """Scaled-batch fit with the 96-wide GEMM tiles (default) and with the whole-width 128 x 288 / 288 x 128
-tiles (BSIG_GEMM_WIDE_TILE=1) at one and two workgroups per CU."""
+tiles (BSIG_GEMM_WIDE_TILE=1, library built with BSIG_BUILD_WIDE_TILES=1 ./build.sh) at one and two
+workgroups per CU."""
 import os, sys, subprocess, json
 sys.path.insert(0, '.')
 for env in ({}, {'BSIG_GEMM_WIDE_TILE': '1', 'BSIG_GEMM_WIDE_WGS': '256'}, {'BSIG_GEMM_WIDE_TILE': '1', 'BSIG_GEMM_WIDE_WGS': '512'}):
