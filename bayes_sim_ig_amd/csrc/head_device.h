@@ -14,8 +14,11 @@ constexpr int kXwgMax = 256;        // persistent kernel: at most this many work
 // 100 workgroups costs 2.75 us when the flags are consecutive dwords (every poller hammers the
 // same few lines of one memory channel) and 1.4 us at this spacing
 // (tools/micro/fanin_bench.hip, profiles/r02_fanin_bench.txt).
-constexpr int kFlagStride = 16;                       // dwords between two flags
-constexpr int kGranStride = 8;                        // 8-byte granules between two granules
+#ifndef BSIG_XWG_STRIDE_BYTES
+#define BSIG_XWG_STRIDE_BYTES 64
+#endif
+constexpr int kFlagStride = BSIG_XWG_STRIDE_BYTES / 4;   // dwords between two flags
+constexpr int kGranStride = BSIG_XWG_STRIDE_BYTES / 8;   // 8-byte granules between two granules
 constexpr int kFlagArr = kXwgMax * kFlagStride;       // dwords of one flag array
 constexpr int kGranArr = kXwgMax * kGranStride;       // granule slots of one granule array
 
@@ -54,10 +57,35 @@ struct RowOut { float lse, uds; bool bad; float esg0[kElemsPerLane]; };
 // `eps_fn()` delivers the jitter scale; it is called (by the whole wave) after
 // everything that does not depend on it -- the Philox draws, exp(pre), the
 // mixture weights -- so that a caller can hide a cross-workgroup wait there.
+// The row's jitter draws u ~ U[0, 1) (mdnn.py:116), element q of the lane as in diag_row: they
+// depend on (seed, stream, row) only, so a caller that waits for the row's head outputs anyway can
+// draw them during the wait and hand them to diag_row (`eu_pre`).
+__device__ __forceinline__ void diag_row_noise(const HeadArgs& a, int row, bool active, int lane,
+                                               float (&eu)[kElemsPerLane]) {
+  const int D = a.D, K = a.K;
+  const int groups = 64 / K, TPR = groups * K;
+  const int k = lane % K, d0 = lane / K;
+  const bool elem = active && lane < TPR;
+  const bool jitter = !a.from_tuple && a.eps_noise != 0.f;
+  const bool draw = jitter && a.noise == nullptr;
+  const uint64_t rng_seed = a.dyn_rng ? a.dyn_rng[0] : a.seed;
+  const uint64_t rng_sid = a.dyn_rng ? a.dyn_rng[1] : a.stream_id;
+  Philox4 ph{{0u, 0u, 0u, 0u}};
+#pragma unroll
+  for (int q = 0; q < kElemsPerLane; ++q) {
+    const int d = d0 + q * groups;
+    eu[q] = 0.f;
+    if ((q & 3) == 0 && draw && elem && d < D)
+      ph = philox4x32_10(rng_seed, rng_sid, ((uint64_t)row * 64 + lane) * 2 + (q >> 2));
+    if (elem && d < D && jitter) eu[q] = a.noise ? a.noise[((int64_t)row * D + d) * K + k] : u01(ph.v[q & 3]);
+  }
+}
+
 template <typename EpsFn>
 __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active, int lane,
                                          float* tile, const float* yv, float* rk, float* lpk,
-                                         float* dlg, EpsFn&& eps_fn, RowOut& out) {
+                                         float* dlg, EpsFn&& eps_fn, RowOut& out,
+                                         const float* eu_pre = nullptr) {
   const int D = a.D, K = a.K;
   const int DK = D * K;
   const int groups = 64 / K;               // d-slots per sweep
@@ -78,11 +106,11 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
   for (int q = 0; q < kElemsPerLane; ++q) {
     const int d = d0 + q * groups;
     ez[q] = 0.f; esg[q] = 1.f; esg0[q] = 1.f; eu[q] = 0.f;
-    if ((q & 3) == 0 && draw && elem && d < D)
+    if (eu_pre == nullptr && (q & 3) == 0 && draw && elem && d < D)
       ph = philox4x32_10(rng_seed, rng_sid, ((uint64_t)row * 64 + lane) * 2 + (q >> 2));
     if (elem && d < D && !a.from_tuple) {
       esg0[q] = expf(tile[K + DK + d * K + k]);
-      if (jitter) eu[q] = a.noise ? a.noise[((int64_t)row * D + d) * K + k] : u01(ph.v[q & 3]);
+      if (jitter) eu[q] = eu_pre ? eu_pre[q] : (a.noise ? a.noise[((int64_t)row * D + d) * K + k] : u01(ph.v[q & 3]));
     }
   }
   // mixture weights (mdnn.py:109-111): lane j < K owns component j, the sums over
@@ -388,6 +416,35 @@ __device__ inline void flags_wait(unsigned* flags, int G, unsigned epoch, int la
       break;
     }
     __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// Quiet waiting.  A workgroup that reaches a fan-in long before its producers (a tile workgroup
+// waiting ~10 us for the row owners, a row owner waiting for the next forward product) would poll all
+// G flags every ~0.1 us for that long -- 255 workgroups x 100 lines of cache-bypassing reads per round,
+// on the memory channels the producers' own latency-critical exchanges go through.  It first waits
+// for ONE of the words (every lane reads the same address: one request per round), sleeping in
+// between, and only then gathers the rest, which are up or nearly up by then.  Bounded like the others.
+__device__ inline void flag_wait_one(const unsigned* flags, int slot, unsigned epoch, int32_t* flag) {
+  for (unsigned spin = 0;; ++spin) {
+    const unsigned x = __hip_atomic_load(flags + slot * kFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (x >= epoch) break;
+    if (spin > (1u << 17)) {
+      if (flag) atomicOr(flag, 2);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(3);
+  }
+}
+__device__ inline void granule_wait_one(const unsigned long long* g, int slot, uint32_t tag, int32_t* flag) {
+  for (unsigned spin = 0;; ++spin) {
+    const unsigned long long x = __hip_atomic_load(g + slot * kGranStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(x >> 32) == tag) break;
+    if (spin > (1u << 17)) {
+      if (flag) atomicOr(flag, 2);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(3);
   }
 }
 

@@ -46,6 +46,13 @@ __device__ __forceinline__ bool run_aborted(int32_t* flagp, float* red, int tid)
 }
 
 
+// Workgroup barrier that waits for this wavefront's LDS traffic only.  __syncthreads() lowers to
+// s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: with global loads (a prefetched tile) or write-through
+// stores in flight every wavefront would first wait for their round trip.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // 8-byte cache-bypassing load (two adjacent floats) for data that crosses workgroups
 __device__ inline float2 xwg_load2(const float* p) {
   const unsigned long long x = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),

@@ -118,9 +118,7 @@ constexpr int kMProfUpdates = 8;
 // would expose the latency of the next chunk's loads at every barrier, and in the owners the round
 // trip of each write-through store (h1, h2, d_out, dz2 leave for memory while the next product runs;
 // the s_waitcnt(0) in front of the owners' flag is what publishes them).
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
+// (lds_barrier: persist_device.h)
 
 // LDS hand-over inside one wavefront (its own stores before its own loads of other lanes' data)
 __device__ __forceinline__ void lds_wave_sync() {

@@ -418,6 +418,15 @@ void bsig_debug_persist_profile(void* device_buffer);
  * (its bounded polls then time out: bit 1 of the state block's flag word; the Python mirror
  * restores the call's start state and repeats it on the per-phase kernels). */
 int bsig_debug_spin(int blocks, size_t lds_bytes, int ms, bsig_stream_t stream);
+/* Diagnostics / tests: how the persistent update kernel of the linear heads (MDRFF) would tile a
+ * head of n_comp components over out_dim parameters on feat_dim features at this minibatch size --
+ * host arithmetic only, no device is asked.  out[16] = { NT (16-row blocks per tile), k-slice
+ * width, head blocks, k-slices, tile workgroups G, workgroups of the launch T, row owners, rows per
+ * owner, evaluation owners, rows per evaluation owner, evaluation passes (0: evaluations outside
+ * the launches), LDS bytes per workgroup, owners that also hold a tile, 0, 0, 0 }.
+ * Returns 1 if the shape is covered, 0 if not. */
+int bsig_debug_persist_geometry(int batch, int feat_dim, int out_dim, int n_comp, int max_test,
+                                int32_t* out);
 
 #ifdef __cplusplus
 }

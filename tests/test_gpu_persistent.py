@@ -239,7 +239,8 @@ def test_in_launch_evaluations_equal_the_evaluation_graphs(B, eps, n, batch, n_u
 
 def test_time_out_is_recovered_on_the_phase_kernels(B):
     """A persistent launch needs every workgroup resident at once.  With 200 of the 256 CUs held by another
-    kernel (bsig_debug_spin on a side stream, 1.5 s) its bounded polls give up and raise bit 1 of
+    kernel (bsig_debug_spin on a side stream, 1.5 s; workgroups that take a CU's whole LDS, so that the small
+    tiles of this head cannot move in beside them) its bounded polls give up and raise bit 1 of
     the flag word; BayesSim.fit then restores the parameters / Adam moments / RNG states it saved
     at its start and repeats the loop on the per-phase kernels: the result is bit for bit the
     per-phase fit (BSIG_NO_PERSISTENT=1), not a partially updated model."""
@@ -262,7 +263,7 @@ def test_time_out_is_recovered_on_the_phase_kernels(B):
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     import ctypes as C
-    B._lib.check(lib.bsig_debug_spin(200, 120 * 1024, 1500, C.c_void_p(side.cuda_stream)))
+    B._lib.check(lib.bsig_debug_spin(200, 160 * 1024, 1500, C.c_void_p(side.cuda_stream)))
     logs = bs.fit(theta, states, actions)
     torch.cuda.synchronize()
     assert getattr(bs.model, '_no_persistent', False), 'the launch was expected to time out'

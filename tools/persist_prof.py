@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Phase breakdown of the persistent update kernel (fit_persistent.hip) from its
-wall-clock stamps (bsig_debug_persist_profile): one cfg5-shaped chunk."""
+"""Phase breakdown of the persistent update kernel of the linear heads from its wall-clock
+stamps (bsig_debug_persist_profile): one cfg5-shaped chunk.  fit_persistent.hip (unified
+workgroups: every workgroup holds a weight tile, the first B also own a minibatch row), or
+fit_persistent_v1.hip with BSIG_PERSIST_V1=1 (tile workgroups + row-owner workgroups)."""
 import ctypes as C
 import os
 import sys
@@ -30,37 +32,70 @@ torch.cuda.synchronize()
 lib.bsig_debug_persist_profile(None)
 st = buf.cpu().numpy().reshape(256, 8, 16).astype(np.float64) / 100.0   # 100 MHz -> us
 live = [g for g in range(256) if st[g, 1, 0] > 0]
-owners = [g for g in live if st[g, 1, 4] > 0]
-tiles = [g for g in live if st[g, 1, 4] == 0]
-print('%s: %d tile workgroups + %d row owners; updates 1..7 of the last launch' % (name, len(tiles), len(owners)))
-for g in (tiles[0], tiles[-1]):
-    print('tile wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
-    for n, a, b in (('feat tile -> LDS', 0, 1), ('fwd mfma', 1, 2), ('slab store+flag', 2, 3),
-                    ('wait for owners', 3, 10), ('dO^T load', 10, 11), ('dW mfma+adam', 11, 12)):
-        print('    %-18s %6.2f us' % (n, (st[g, 1:8, b] - st[g, 1:8, a]).mean()))
-for g in (owners[0], owners[-1]):
-    print('owner wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
-    for n, a, b in (('y + wait fwd flags', 0, 4), ('slab sum', 4, 5), ('row: pre-eps part', 5, 6),
-                    ('eps gather + row', 6, 7), ('dO/E store+publish', 7, 9)):
-        print('    %-18s %6.2f us' % (n, (st[g, 1:8, b] - st[g, 1:8, a]).mean()))
-    print('    %-18s %6.2f us' % ('idle until next', (st[g, 2:8, 0] - st[g, 1:7, 9]).mean()))
+v1 = os.environ.get('BSIG_PERSIST_V1') == '1'
+
+
+def phases(g, table):
+    for n, a, b in table:
+        print('    %-22s %6.2f us' % (n, (st[g, 1:8, b] - st[g, 1:8, a]).mean()))
+
+
+if v1:
+    owners = [g for g in live if st[g, 1, 4] > 0]
+    tiles = [g for g in live if st[g, 1, 4] == 0]
+    print('%s (v1): %d tile workgroups + %d row owners; updates 1..7 of the last launch' % (name, len(tiles), len(owners)))
+    for g in (tiles[0], tiles[-1]):
+        print('tile wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
+        phases(g, (('feat tile -> LDS', 0, 1), ('fwd mfma', 1, 2), ('slab store+flag', 2, 3),
+                   ('wait for owners', 3, 10), ('dO^T load', 10, 11), ('dW mfma+adam', 11, 12)))
+    for g in (owners[0], owners[-1]):
+        print('owner wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
+        phases(g, (('y + wait fwd flags', 0, 4), ('slab sum', 4, 5), ('row: pre-eps part', 5, 6),
+                   ('eps gather + row', 6, 7), ('dO/E store+publish', 7, 9)))
+        print('    %-22s %6.2f us' % ('idle until next', (st[g, 2:8, 0] - st[g, 1:7, 9]).mean()))
+    rows = [('last tile wg has its feature tile in LDS', tiles, 1, np.max),
+            ('last tile wg done with the forward MFMAs', tiles, 2, np.max),
+            ('last forward flag raised', tiles, 3, np.max)]
+else:
+    owners = [g for g in live if st[g, 1, 4] > 0]
+    tiles = [g for g in live if st[g, 1, 3] > 0]
+    print('%s: %d workgroups with a weight tile, %d of the launch own a minibatch row; updates 1..7 of the last launch'
+          % (name, len(tiles), len(owners)))
+    both = [g for g in owners if g in tiles]
+    only_t = [g for g in tiles if g not in owners]
+    for g in both[:1] + both[-1:]:
+        print('tile + row wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
+        phases(g, (('fwd mfma (wave 0)', 0, 1), ('slab store+flag', 1, 3), ('wait fwd flags', 3, 4),
+                   ('slab sum', 4, 5), ('row: pre-eps part', 5, 6), ('eps gather + row', 6, 7),
+                   ('dO/E store+publish', 7, 9), ('next tile requested', 9, 2), ('wait for owners', 2, 10), ('dO^T load', 10, 11),
+                   ('dW mfma+adam (wave 0)', 11, 8), ('end barrier', 8, 12)))
+    only_o = [g for g in owners if g not in tiles]
+    for g in only_o[:1] + only_o[-1:]:
+        print('row wg %3d (no tile): update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
+        phases(g, (('wait fwd flags', 0, 4), ('slab sum', 4, 5), ('row: pre-eps part', 5, 6),
+                   ('eps gather + row', 6, 7), ('dO/E store+publish', 7, 9)))
+        print('    %-22s %6.2f us' % ('idle until next', (st[g, 2:8, 0] - st[g, 1:7, 9]).mean()))
+    for g in only_t[:1] + only_t[-1:]:
+        print('tile wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
+        phases(g, (('fwd mfma (wave 0)', 0, 1), ('slab store+flag', 1, 3), ('next tile requested', 3, 2), ('wait for owners', 2, 10),
+                   ('dO^T load', 10, 11), ('dW mfma+adam (wave 0)', 11, 8),
+                   ('end barrier', 8, 12)))
+    rows = [('last wg done with the forward MFMAs (wave 0)', tiles, 1, np.max),
+            ('last forward flag raised', tiles, 3, np.max)]
 
 # chip-level critical path of one update (wall_clock64 is one 100 MHz counter for the chip)
 print('chip-level timeline, mean over updates 2..6 of the launch (us after the first tile workgroup starts the update):')
-rows = [('last tile wg has its feature tile in LDS', tiles, 1, np.max),
-        ('last tile wg done with the forward MFMAs', tiles, 2, np.max),
-        ('last forward flag raised', tiles, 3, np.max),
-        ('first owner released', owners, 4, np.min),
-        ('last owner released', owners, 4, np.max),
-        ('last owner has its row (slab sum, exp published)', owners, 5, np.max),
-        ('last owner waits for eps', owners, 6, np.max),
-        ('last row finished', owners, 7, np.max),
-        ('last owner published d_out', owners, 9, np.max),
-        ('first tile wg released', tiles, 10, np.min),
-        ('last tile wg released', tiles, 10, np.max),
-        ('last d_out^T tile in LDS', tiles, 11, np.max),
-        ('first tile wg finished the update', tiles, 12, np.min),
-        ('last tile wg finished the update', tiles, 12, np.max)]
+rows += [('first owner released', owners, 4, np.min),
+         ('last owner released', owners, 4, np.max),
+         ('last owner has its row (slab sum, exp published)', owners, 5, np.max),
+         ('last owner waits for eps', owners, 6, np.max),
+         ('last row finished', owners, 7, np.max),
+         ('last owner published d_out', owners, 9, np.max),
+         ('first tile wg released', tiles, 10, np.min),
+         ('last tile wg released', tiles, 10, np.max),
+         ('last d_out^T tile in LDS', tiles, 11, np.max),
+         ('first tile wg finished the update', tiles, 12, np.min),
+         ('last tile wg finished the update', tiles, 12, np.max)]
 acc = {r[0]: [] for r in rows}
 for u in range(2, 7):
     t0 = min(st[g, u, 0] for g in tiles)
