@@ -80,6 +80,7 @@ struct UArgs {
   unsigned* flag_eval;               // [G]   evaluation number + 1
   unsigned long long* gran_eval;     // [2][kGranArr]
   long long* prof;                   // diagnostics: [T][kUProf][16] wall-clock stamps, or null
+  int prof_t0;                       // ... of updates prof_t0 .. prof_t0 + kUProf of the launch (BSIG_PROF_T0)
 };
 
 __device__ __forceinline__ f32x4 umfma(float a, float b, f32x4 c) {
@@ -114,17 +115,23 @@ __device__ __forceinline__ URole wg_role(int wg, int T, int G) {
   return r;
 }
 
+// Position of minibatch row b along the rows of F^T / d_out^T in LDS: inside its block of 16, row
+// 4c + g sits at 4g + c.  The dW product reads 16 bytes at 16S + 4g of both operands, and MFMA c of
+// step S then contracts the four ADJACENT rows 16S + 4c .. + 3: the padding behind the last
+// minibatch row (100 rows: 12 of the last 16) costs no MFMAs.
+__device__ __forceinline__ int u_rowpos(int b) { return (b & ~15) + ((b & 3) << 2) + ((b >> 2) & 3); }
+
 __device__ __forceinline__ int u_evals_before(int s, int every) { return s == 0 ? 0 : (s - 1) / every + 1; }
 
 #define BSIG_USTAMP(k)                                                           \
   do {                                                                           \
-    if (p.prof && threadIdx.x == 0 && t < kUProf)                                \
-      p.prof[((int64_t)wg * kUProf + t) * 16 + (k)] = wall_clock64();            \
+    if (p.prof && threadIdx.x == 0 && t >= p.prof_t0 && t < p.prof_t0 + kUProf)  \
+      p.prof[((int64_t)wg * kUProf + t - p.prof_t0) * 16 + (k)] = wall_clock64(); \
   } while (0)
 
 // A row owner's sum over the k-slices: out[r * out_pitch + col] = sum_z slabs[z * zs + rowoff(r) + col]
 // for r < nrows, col < n_cols (float offsets; `slabs` workgroup-uniform), slices added in order, up
-// to 32 loads in flight per lane (one round trip for up to 32 k-slices) -- buffer loads: one address register per lane, the slice offset
+// to 16 loads in flight per lane -- buffer loads: one address register per lane, the slice offset
 // is scalar.  `fn(col, v)` sees every sum.
 template <typename RowOff, typename F>
 __device__ __forceinline__ void u_rows_sum(const float* slabs, RowOff&& rowoff, int k_slices, int zs, int nrows,
@@ -134,19 +141,91 @@ __device__ __forceinline__ void u_rows_sum(const float* slabs, RowOff&& rowoff, 
     const int r = idx / n_cols, col = idx - r * n_cols;
     const int voff = (rowoff(r) + col) * 4;
     float v = 0.f;
-    for (int z = 0; z < k_slices; z += 32) {
-      float q[32];
+    for (int z = 0; z < k_slices; z += 16) {
+      float q[16];
 #pragma unroll
-      for (int u = 0; u < 32; ++u)
+      for (int u = 0; u < 16; ++u)
         q[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, voff, min(z + u, k_slices - 1) * zs * 4, kXwgPolicy));
 #pragma unroll
-      for (int u = 0; u < 32; ++u)
+      for (int u = 0; u < 16; ++u)
         if (z + u < k_slices) v += q[u];
     }
     out[r * out_pitch + col] = v;
     fn(col, v);
   }
 }
+
+// The same sum in ONE round trip for an owner without a tile (its LDS is free): thread (quad column,
+// slice group sg) adds the slices sg, sg + SG, ... of 4 adjacent columns (16-byte loads, <= 8 in
+// flight), the SG partial sums meet in LDS (`part`, 4 * kUT floats) and are added in group order.
+// A fixed partition: bitwise reproducible.  nrows * ld / 4 <= kUT quads (else: u_rows_sum).
+template <typename RowOff, typename F>
+__device__ __forceinline__ void u_rows_sum4(const float* slabs, RowOff&& rowoff, int k_slices, int zs, int nrows,
+                                            int n_cols, int ld, float* out, int out_pitch, float* part, int tid,
+                                            F&& fn) {
+  const __amdgpu_buffer_rsrc_t sr = xwg_buffer(slabs);
+  const int ncq = ld >> 2, Q = nrows * ncq;
+  const int SG = max(1, min(min(k_slices, kUT / Q), 8));
+  const int qc = tid % Q, sg = tid / Q;
+  if (sg < SG) {
+    const int r = qc / ncq, c4 = (qc - r * ncq) * 4;
+    const int voff = rowoff(r) + c4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z0 = sg; z0 < k_slices; z0 += 8 * SG) {
+      f32x4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = xwg_load4(sr, voff + min(z0 + u * SG, k_slices - 1) * zs);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (z0 + u * SG < k_slices) v += q[u];
+    }
+    *reinterpret_cast<f32x4*>(part + 4 * (sg * Q + qc)) = v;
+  }
+  __syncthreads();
+  if (tid < Q) {
+    const int r = tid / ncq, c4 = (tid - r * ncq) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + 4 * tid);
+    for (int g = 1; g < SG; ++g) v += *reinterpret_cast<const f32x4*>(part + 4 * (g * Q + tid));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c4 + j < n_cols) {
+        out[r * out_pitch + c4 + j] = v[j];
+        fn(c4 + j, v[j]);
+      }
+  }
+}
+
+// The jitter scale EPS_NOISE * mean(exp(pre)) of an update from the owners' sum(exp(pre)) granules,
+// for diag_row_impl: the granule loads are issued before the row arithmetic that does not need the
+// scale and looked at after it -- by then the other owners' granules (published about when this
+// owner published its own) have arrived, and the gather costs no round trip of its own.  A granule
+// that was not up yet sends get() through the bounded polling loop.
+struct GranuleEps {
+  const unsigned long long* g; int G; uint32_t tag; int lane; int32_t* flag; float scale; bool on;
+  unsigned long long x[4];
+  __device__ __forceinline__ void issue() {
+    if (on) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        x[u] = __hip_atomic_load(g + min(lane + 64 * u, G - 1) * kGranStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __device__ __forceinline__ float get() {
+    if (!on) return 0.f;
+    float v[4];
+    bool all = true;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool mine = lane + 64 * u < G, up = (uint32_t)(x[u] >> 32) == tag;
+      v[u] = mine && up ? __uint_as_float((uint32_t)x[u]) : 0.f;
+      all = all && (!mine || up);
+    }
+    float sum;
+    if (__all(all)) sum = (wave_sum_dpp(v[0]) + wave_sum_dpp(v[1])) + (wave_sum_dpp(v[2]) + wave_sum_dpp(v[3]));
+    else sum = granule_gather(const_cast<unsigned long long*>(g), G, tag, lane, flag);
+    return scale * sum;
+  }
+};
 
 // ---- tile part of held-out evaluation eidx: held-out rows x this tile's weights (the B operand
 //      straight from memory, six 16-column steps at a time) -> evaluation slab buffer eidx % 3, flag
@@ -284,6 +363,151 @@ __device__ __forceinline__ void u_owner_eval(const UArgs& p, float* XS, float* r
   __syncthreads();
 }
 
+// ---- the row-owner role ---------------------------------------------------------------------
+// (functions of their own with a context struct, not code inside the tile workgroups' loop: a
+// workgroup WITHOUT a tile runs owner_only_workgroup, where none of the tile registers -- 72 of the
+// next minibatch tile, the Adam moments -- exist, and the row arithmetic has the register file to
+// itself; inside the common function it spilled)
+struct UOwn {
+  int own, r0, per_wave;          // owner rank, first row, floats of a row's block in LDS
+  bool has_tile;                  // (a workgroup without a tile sums the k-slices through its free F^T region)
+  float *XS, *red, *part;         // LDS: row blocks, [64] scratch, partial k-slice sums
+  HeadArgs a; RowGeom rg;
+  uint64_t rng_ctr0; int step0, ev0; float norm; int32_t* flagp;
+};
+__device__ __forceinline__ void u_own_init(const UArgs& p, UOwn& o, int own, bool has_tile, float* XS,
+                                           float* red, float* part, int lane0) {
+  o.own = own; o.r0 = own * p.R; o.per_wave = p.Nh + p.D + 3 * p.K; o.has_tile = has_tile;
+  o.XS = XS; o.red = red; o.part = part;
+  o.a = HeadArgs{};
+  o.a.D = p.D; o.a.K = p.K; o.a.Nh = p.Nh; o.a.batch = p.B; o.a.from_tuple = 0;
+  o.a.min_w = p.min_w; o.a.ll_limit = p.ll_limit; o.a.inv_norm = p.inv_norm;
+  o.a.eps_noise = p.eps_noise; o.a.seed = reinterpret_cast<const uint64_t*>(p.state + 8)[0]; o.a.d_out = p.d_out;
+  o.rg = row_geom(p.D, p.K, lane0);       // (integer divisions by run-time values: once per launch)
+  o.rng_ctr0 = reinterpret_cast<const uint64_t*>(p.state + 8)[1];
+  o.step0 = p.state[0];
+  o.ev0 = p.do_eval ? u_evals_before(o.step0, p.eval_every) : 0;
+  o.norm = (float)p.B * (float)(p.D * p.K);
+  o.flagp = p.state + 2;
+}
+// jitter stream of evaluation e (one stream per update and per evaluation, in program order: the
+// per-phase path's numbering); `last`: the evaluation after the call's last update
+__device__ __forceinline__ uint64_t u_eval_stream(const UArgs& p, const UOwn& o, int e, bool last) {
+  const int at = last ? p.n_total : e * p.eval_every + 1;     // the update it precedes
+  return o.rng_ctr0 + (uint64_t)(at - o.step0) + (uint64_t)(e - o.ev0);
+}
+
+// Update t of the launch for the rows r0 .. r0 + R of this owner (every wavefront of the workgroup
+// comes through here; wavefront w < R runs row r0 + w): k-slice sum, NLL forward / backward.
+__device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int w, int lane0, int wg) {
+  const int B = p.B, Nh = p.Nh, NhP = p.NhP, D = p.D, K = p.K, DK = D * K;
+  const int step = o.step0 + t;
+  const unsigned epoch = (unsigned)step + 1u;
+  const uint32_t tag = epoch * 4u;
+  const int own = o.own, r0 = o.r0, per_wave = o.per_wave;
+  const bool has_tile = o.has_tile;
+  float* XS = o.XS; float* red = o.red; float* Ft = o.part;
+  int32_t* flagp = o.flagp;
+  HeadArgs& a = o.a;
+  const RowGeom& rg = o.rg;
+  const uint64_t rng_ctr0 = o.rng_ctr0;
+  const int ev0 = o.ev0;
+  const float norm = o.norm;
+  const int tid = threadIdx.x;
+  float* tile = XS + w * per_wave;             // (only waves < R touch theirs)
+  float* yv = tile + Nh;
+  float* rk = yv + D;
+  float* lpk = rk + K;
+  float* dlg = lpk + K;
+  const int row = r0 + w;
+  const bool owner_wave = w < p.R;
+  const bool active = owner_wave && row < B;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tid_l = 64 * w + lane;
+    if (active) {      // target row (independent of the forward product)
+      const int64_t yrow = p.ids[(int64_t)step * B + row];
+      for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
+    }
+    // the row's jitter draws do not depend on the forward product: drawn in the wait
+    float eu_pre[kElemsPerLane];
+    a.stream_id = rng_ctr0 + (uint64_t)t + (uint64_t)(p.do_eval ? u_evals_before(step, p.eval_every) - ev0 : 0);
+    if (owner_wave) diag_row_noise(a, rg.groups, rg.k, rg.d0, row, active, lane, eu_pre);
+    if (w == 0) {
+      flag_wait_one(p.flag_fwd, p.G - 1, epoch, flagp);
+      flags_wait(p.flag_fwd, p.G, epoch, lane, flagp);
+    }
+    __syncthreads();
+    BSIG_USTAMP(4);
+    float eacc = 0.f;
+    if (!has_tile && p.R * NhP <= 4 * kUT)      // (the F^T region of a workgroup without a tile is free)
+      u_rows_sum4(p.slabs, [&](int r) { return (r0 + r) * NhP; }, p.k_slices, B * NhP, min(p.R, B - r0), Nh,
+                  NhP, XS, per_wave, Ft, tid_l,
+                  [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
+    else
+      u_rows_sum(p.slabs, [&](int r) { return (r0 + r) * NhP; }, p.k_slices, B * NhP,
+                 min(p.R, B - r0), Nh, XS, per_wave, tid_l,
+                 [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
+    eacc = wave_sum_dpp(eacc);
+    if (lane == 0) red[w] = eacc;
+    __syncthreads();
+    if (tid_l == 0) {
+      float sx = 0.f;
+      for (int q = 0; q < kUT / 64; ++q) sx += red[q];
+      granule_publish(p.gran, own, tag + 1, sx);
+    }
+    BSIG_USTAMP(5);
+    RowOut ro;
+    ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
+#pragma unroll
+    for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
+    if (owner_wave) {
+      GranuleEps ge{p.gran, p.n_owner, tag + 1, lane, flagp, p.eps_noise / norm, p.eps_noise != 0.f, {0ull, 0ull, 0ull, 0ull}};
+      diag_row_impl(a, rg, row, active, lane, tile, yv, rk, lpk, dlg, ge, ro, eu_pre);
+#ifdef BSIG_ROW_PROF
+      if (p.prof && tid == 0 && t >= p.prof_t0 && t < p.prof_t0 + kUProf)
+        for (int i = 0; i < 9; ++i)
+          p.prof[(int64_t)256 * kUProf * 16 + ((int64_t)wg * kUProf + t - p.prof_t0) * 16 + i] = ro.ts[i];
+#endif
+      const float uds_w = wave_sum_dpp(ro.uds);
+      if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
+      BSIG_USTAMP(7);
+      if (active) {
+        // d_out row without the jitter-scale term, and exp(pre) of the row for the tile
+        // workgroups to add it (lane's elements are columns lane + q*TPR)
+        for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
+        __builtin_amdgcn_wave_barrier();
+        float* dst = p.d_out + (int64_t)row * NhP;
+        for (int j = lane; j < Nh; j += 64) xwg_store(dst + j, tile[j]);
+        if (p.eps_noise != 0.f) {
+          const int TPR = (64 / K) * K;
+          float* est = p.e_out + (int64_t)row * NhP + K + DK;
+#pragma unroll
+          for (int q = 0; q < kElemsPerLane; ++q)
+            if (lane < TPR && lane + q * TPR < DK) xwg_store(est + lane + q * TPR, ro.esg0[q]);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid_l == 0) {
+      float sl = 0.f, su = 0.f;
+      for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
+      granule_publish(p.gran + kGranArr, own, tag + 2, su);
+      granule_publish(p.gran + 2 * kGranArr, own, tag + 3, sl);
+    }
+    BSIG_USTAMP(9);
+    if (own == 0 && w == 0) {
+      const float s = granule_gather(p.gran + 2 * kGranArr, p.n_owner, tag + 3, lane, flagp);
+      if (lane == 0) {
+        const float l = -s / (float)B;
+        p.train_loss[step] = l;
+        if (!isfinite(l)) atomicOr(flagp, 1);
+      }
+    }
+    if (ro.bad) atomicOr(flagp, 1);
+}
+
 // The minibatch tile of update `step`, straight into the forward product's B-operand registers:
 // wavefront w < MT holds rows 16w .. 16w+15, lane (c16, g4) the four columns 16S + 4 g4 .. +3 of
 // step S (64 contiguous bytes per row and instruction).
@@ -313,7 +537,7 @@ __device__ __forceinline__ void u_owner_eval(const UArgs& p, float* XS, float* r
 
 // DP: data-parallel rank (gradients out, pending Adam step in).  NT: 16-row blocks per tile.
 template <bool DP, int NT>
-__device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
+__device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, const URole& role) {
   constexpr int NBW = 16 * NT;                 // head rows of the tile
   constexpr int MAXBLK = NT == 1 ? 3 : 2;      // 16-column blocks per wavefront in the dW / Adam phase
   float* Ft = smem;                            // [KS][FP]   minibatch features of this k-slice, transposed
@@ -325,10 +549,10 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wavefront-uniform: scalar tests)
   const int c16 = lane0 & 15, g4 = lane0 >> 4;
   const int wg = blockIdx.x;
-  const URole role = wg_role(wg, p.T, p.G);
-  const int slot = max(role.tile, 0), own = role.owner;
-  const bool has_tile = role.tile >= 0, has_row = own < p.n_owner;
-  const int ks = has_tile ? slot / p.n_blocks : 0, nb = has_tile ? slot - ks * p.n_blocks : 0;
+  const int slot = role.tile, own = role.owner;
+  constexpr bool has_tile = true;           // (workgroups without a tile: owner_only_workgroup)
+  const bool has_row = own < p.n_owner;
+  const int ks = slot / p.n_blocks, nb = slot - ks * p.n_blocks;
   const int n0 = nb * NBW, k0 = ks * p.KS;
   const int B = p.B, Nh = p.Nh, NhP = p.NhP, D = p.D, K = p.K, DK = D * K;
   constexpr int FP = kUFP;
@@ -478,35 +702,13 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
       *reinterpret_cast<f32x4*>(Ft + 4 * idx) = zero;
     }
 
-  // ---- row-owner state -------------------------------------------------------------------
-  const uint64_t rng_seed = reinterpret_cast<const uint64_t*>(p.state + 8)[0];
-  const uint64_t rng_ctr0 = reinterpret_cast<const uint64_t*>(p.state + 8)[1];
-  HeadArgs a{};
-  a.D = D; a.K = K; a.Nh = Nh; a.batch = B; a.from_tuple = 0;
-  a.min_w = p.min_w; a.ll_limit = p.ll_limit; a.inv_norm = p.inv_norm;
-  a.eps_noise = p.eps_noise; a.seed = rng_seed; a.d_out = p.d_out;
-  const float norm = (float)B * (float)DK;
-  const int per_wave = Nh + D + 3 * K;
-  const int r0 = own * p.R;
-  float* tile = XS + w * per_wave;             // (only waves < R touch theirs)
-  float* yv = tile + Nh;
-  float* rk = yv + D;
-  float* lpk = rk + K;
-  float* dlg = lpk + K;
-  const int row = r0 + w;
-  const bool owner_wave = has_row && w < p.R;
-  const bool active = owner_wave && row < B;
-  const int ev0 = p.do_eval ? u_evals_before(step0, p.eval_every) : 0;
+  // ---- row-owner state (a tile workgroup that also owns minibatch rows: heads with no CUs to spare)
+  UOwn o;
+  u_own_init(p, o, own, true, XS, red, Ft, lane0);
   // evaluation owner: the workgroups without a minibatch row come first
   const int eo = (own - p.n_owner + p.T) % p.T;
   const bool has_erow = p.do_eval && eo < p.NE;
   int pending_eval = -1;                       // evaluation whose tile part is out and whose row part is due
-  // jitter stream of evaluation e (one stream per update and per evaluation, in program order:
-  // the per-phase path's numbering); `last`: the evaluation after the call's last update
-  auto eval_stream = [&](int e, bool last) {
-    const int at = last ? p.n_total : e * p.eval_every + 1;     // the update it precedes
-    return rng_ctr0 + (uint64_t)(at - step0) + (uint64_t)(e - ev0);
-  };
 
   // feature tile of the first update (later ones are fetched during the waits)
   f32x4 Freg[kUSteps];
@@ -533,7 +735,7 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
     const uint32_t tag = epoch * 4u;
     if (red[63] != 0.f) break;     // time-out bit as sampled during the previous update's wait
     BSIG_USTAMP(0);
-    if (has_tile) {
+    {
       // ---- 1. forward: P^T[n, b] = sum_k W[n, k] F[b, k] on this k-slice ------------------
       if (w < p.MT) {
         const bool rok = 16 * w + c16_l < B;
@@ -550,7 +752,7 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
           acc[nt] = ks == 0 ? *reinterpret_cast<const f32x4*>(biasl + 16 * nt + 4 * g4_l) : zero;
         }
         const float* ap = Wl + c16_l * WP + 4 * g4_l;
-        float* ftp = Ft + (4 * g4_l) * FP + 16 * w + c16_l;
+        float* ftp = Ft + (4 * g4_l) * FP + 16 * w + u_rowpos(c16_l);
 #pragma unroll
         for (int G6 = 0; G6 < kUSteps / kUGroup; ++G6) {
           if (kUGroup * G6 < p.ksteps) {
@@ -595,105 +797,23 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
     a0 = (float)(p.lr / (1.0 - b1t));
     a1 = (float)(1.0 / sqrt(1.0 - b2t));
 
-    // ---- 2. row owners: k-slice sum, NLL forward / backward of the row -----------------------
-    if (has_row) {
-      int lane = lane0;
-      asm volatile("" : "+v"(lane));
-      const int tid_l = 64 * w + lane;
-      if (active) {      // target row (independent of the forward product)
-        const int64_t yrow = p.ids[(int64_t)step * B + row];
-        for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
-      }
-      // the row's jitter draws do not depend on the forward product: drawn in the wait
-      float eu_pre[kElemsPerLane];
-      a.stream_id = rng_ctr0 + (uint64_t)t + (uint64_t)(p.do_eval ? u_evals_before(step, p.eval_every) - ev0 : 0);
-      if (owner_wave) diag_row_noise(a, row, active, lane, eu_pre);
-      if (w == 0) {
-        flag_wait_one(p.flag_fwd, p.G - 1, epoch, flagp);
-        flags_wait(p.flag_fwd, p.G, epoch, lane, flagp);
-      }
-      __syncthreads();
-      BSIG_USTAMP(4);
-      float eacc = 0.f;
-      u_rows_sum(p.slabs, [&](int r) { return (r0 + r) * NhP; }, p.k_slices, B * NhP,
-                 min(p.R, B - r0), Nh, XS, per_wave, tid_l,
-                 [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
-      eacc = wave_sum_dpp(eacc);
-      if (lane == 0) red[w] = eacc;
-      __syncthreads();
-      if (tid_l == 0) {
-        float sx = 0.f;
-        for (int q = 0; q < kUT / 64; ++q) sx += red[q];
-        granule_publish(p.gran, own, tag + 1, sx);
-      }
-      BSIG_USTAMP(5);
-      RowOut ro;
-      ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
-#pragma unroll
-      for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
-      if (owner_wave) {
-        diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg,
-                 [&] {
-                   BSIG_USTAMP(6);
-                   return p.eps_noise != 0.f
-                              ? p.eps_noise * (granule_gather(p.gran, p.n_owner, tag + 1, lane, flagp) / norm)
-                              : 0.f;
-                 },
-                 ro, eu_pre);
-        const float uds_w = wave_sum_dpp(ro.uds);
-        if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
-        BSIG_USTAMP(7);
-        if (active) {
-          // d_out row without the jitter-scale term, and exp(pre) of the row for the tile
-          // workgroups to add it (lane's elements are columns lane + q*TPR)
-          for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
-          __builtin_amdgcn_wave_barrier();
-          float* dst = p.d_out + (int64_t)row * NhP;
-          for (int j = lane; j < Nh; j += 64) xwg_store(dst + j, tile[j]);
-          if (p.eps_noise != 0.f) {
-            const int TPR = (64 / K) * K;
-            float* est = p.e_out + (int64_t)row * NhP + K + DK;
-#pragma unroll
-            for (int q = 0; q < kElemsPerLane; ++q)
-              if (lane < TPR && lane + q * TPR < DK) xwg_store(est + lane + q * TPR, ro.esg0[q]);
-          }
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
-      if (tid_l == 0) {
-        float sl = 0.f, su = 0.f;
-        for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
-        granule_publish(p.gran + kGranArr, own, tag + 2, su);
-        granule_publish(p.gran + 2 * kGranArr, own, tag + 3, sl);
-      }
-      BSIG_USTAMP(9);
-      if (own == 0 && w == 0) {
-        const float s = granule_gather(p.gran + 2 * kGranArr, p.n_owner, tag + 3, lane, flagp);
-        if (lane == 0) {
-          const float l = -s / (float)B;
-          p.train_loss[step] = l;
-          if (!isfinite(l)) atomicOr(flagp, 1);
-        }
-      }
-      if (ro.bad) atomicOr(flagp, 1);
-    }
-
-    // ---- held-out evaluations in the wait: the row part of the evaluation whose products went
-    //      out during the previous update, the tile part of the one due after the previous update
+    // ---- 2. rows of this workgroup, if it owns any ------------------------------------------------
+    if (has_row) u_own_update(p, o, t, w, lane0, wg);
+    // ---- held-out evaluations in the wait: the row part of the evaluation whose products went out
+    //      during the previous update, the tile part of the one due after the previous update
     if (__builtin_expect(pending_eval >= 0, 0)) {
       __syncthreads();
-      if (has_erow) u_owner_eval(p, XS, red, eo, pending_eval, eval_stream(pending_eval, false), a);
+      if (has_erow) u_owner_eval(p, XS, red, eo, pending_eval, u_eval_stream(p, o, pending_eval, false), o.a);
       pending_eval = -1;
     }
     if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0)) {
       const int e = u_evals_before(step, p.eval_every) - 1;
-      if (has_tile) u_tile_eval<NT>(p, Wl, biasl, slot, ks, n0, k0, e);
+      u_tile_eval<NT>(p, Wl, biasl, slot, ks, n0, k0, e);
       pending_eval = e;
     }
 
     // ---- 3. dW = d_out^T F on this tile, Adam --------------------------------------------------
-    if (has_tile) {
+    {
       int tid_l = tid, c16_l = c16, g4_l = g4;
       asm volatile("" : "+v"(tid_l), "+v"(c16_l), "+v"(g4_l));
       const int lane = tid_l & 63;
@@ -741,7 +861,7 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
               for (int j = 0; j < 4; ++j) {
                 const int n = n0 + c4 + j;
                 const float ev = (n >= sg_lo && n < sg_hi) ? e[u][j] : 0.f;   // (other columns of e_out hold no data)
-                XS[(c4 + j) * FP + b] = q[u][j] + c * ev;
+                XS[(c4 + j) * FP + u_rowpos(b)] = q[u][j] + c * ev;
               }
             }
           }
@@ -774,15 +894,8 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
           }
         }
       }
-      // the d_out^T operand is the same for every block of the wavefront: read once
-      f32x4 a4[NT][kUMT];
-      {
-        const float* ap = XS + c16_l * FP + 4 * g4_l;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int S = 0; S < kUMT; ++S) a4[nt][S] = *reinterpret_cast<const f32x4*>(ap + nt * 16 * FP + 16 * S);
-      }
+      const int n4 = (B + 3) >> 2;
+      const float* ap = XS + c16_l * FP + 4 * g4_l;
 #pragma unroll
       for (int jj = 0; jj < MAXBLK; ++jj) {
         const int j = w + 8 * jj;
@@ -791,19 +904,29 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
           const float* bp = Ft + (16 * j + c16_l) * FP + 4 * g4_l;
 #pragma unroll
           for (int S = 0; S < kUMT; ++S) b4[S] = *reinterpret_cast<const f32x4*>(bp + 16 * S);
+          // Groups of 4 minibatch rows: n4 = ceil(B / 4) MFMAs per accumulator would do; the reference's
+          // minibatch of 100 rows (n4 = 25: 6 steps and one MFMA) has its own straight-line variant, any
+          // other size runs all 7 steps (the padding rows are zeros) -- a test per step costs more than
+          // the three MFMAs it saves (every step its own basic block: 4.0 -> 4.6 us for the phase).
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
+            f32x4 a4[kUMT];
+#pragma unroll
+            for (int S = 0; S < kUMT; ++S) a4[S] = *reinterpret_cast<const f32x4*>(ap + nt * 16 * FP + 16 * S);
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             acc[nt] = zero;
-          }
 #pragma unroll
-          for (int S = 0; S < kUMT; ++S) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              acc[nt] = umfma(a4[nt][S][0], b4[S][0], acc[nt]);
-              acc[nt] = umfma(a4[nt][S][1], b4[S][1], acc[nt]);
-              acc[nt] = umfma(a4[nt][S][2], b4[S][2], acc[nt]);
-              acc[nt] = umfma(a4[nt][S][3], b4[S][3], acc[nt]);
+            for (int S = 0; S < kUMT - 1; ++S) {
+              acc[nt] = umfma(a4[S][0], b4[S][0], acc[nt]);
+              acc[nt] = umfma(a4[S][1], b4[S][1], acc[nt]);
+              acc[nt] = umfma(a4[S][2], b4[S][2], acc[nt]);
+              acc[nt] = umfma(a4[S][3], b4[S][3], acc[nt]);
+            }
+            acc[nt] = umfma(a4[kUMT - 1][0], b4[kUMT - 1][0], acc[nt]);
+            if (n4 != 4 * (kUMT - 1) + 1) {
+              acc[nt] = umfma(a4[kUMT - 1][1], b4[kUMT - 1][1], acc[nt]);
+              acc[nt] = umfma(a4[kUMT - 1][2], b4[kUMT - 1][2], acc[nt]);
+              acc[nt] = umfma(a4[kUMT - 1][3], b4[kUMT - 1][3], acc[nt]);
             }
           }
           if (DP) {
@@ -835,7 +958,7 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
   // ---- evaluations still owed at the end of the launch ------------------------------------------
   if (p.do_eval && !run_aborted(flagp, red, tid)) {
     if (pending_eval >= 0) {
-      if (has_erow) u_owner_eval(p, XS, red, eo, pending_eval, eval_stream(pending_eval, false), a);
+      if (has_erow) u_owner_eval(p, XS, red, eo, pending_eval, u_eval_stream(p, o, pending_eval, false), o.a);
       pending_eval = -1;
     }
     // the evaluation after the last update of the call (a data-parallel rank: in the launch that
@@ -843,8 +966,8 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
     if (step0 + p.n_updates == p.n_total && (!DP || p.n_updates == 0)) {
       const int e = u_evals_before(p.n_total - 1, p.eval_every);
       __syncthreads();
-      if (has_tile) u_tile_eval<NT>(p, Wl, biasl, slot, ks, n0, k0, e);
-      if (has_erow) u_owner_eval(p, XS, red, eo, e, eval_stream(e, true), a);
+      u_tile_eval<NT>(p, Wl, biasl, slot, ks, n0, k0, e);
+      if (has_erow) u_owner_eval(p, XS, red, eo, e, u_eval_stream(p, o, e, true), o.a);
     }
   }
   // ---- write the tile back, advance the engine state -----------------------------------------
@@ -892,11 +1015,54 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem) {
   }
 }
 
+// ---- a workgroup without a tile: row owner (and evaluation owner) only -------------------------
+__device__ __forceinline__ void owner_only_workgroup(const UArgs& p, float* smem, const URole& role, int NBW, bool dp) {
+  float* XS = smem + p.KS * kUFP + NBW * p.WP;      // (the layout of the tile workgroups)
+  float* red = XS + p.xs_floats;
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  int32_t* flagp = p.state + 2;
+  UOwn o;
+  u_own_init(p, o, role.owner, false, XS, red, smem, lane0);
+  const bool has_row = role.owner < p.n_owner;
+  const int eo = (role.owner - p.n_owner + p.T) % p.T;
+  const bool has_erow = p.do_eval && eo < p.NE;
+  int pending_eval = -1;
+  for (int t = 0; t < p.n_updates; ++t) {
+    const int step = o.step0 + t;
+    // (the time-out bit, sampled behind a barrier: every wavefront must take the same way out.  The
+    // round trip sits in this workgroup's wait for the forward product.)
+    if (run_aborted(flagp, red, tid)) break;
+    BSIG_USTAMP(0);
+    if (has_row) u_own_update(p, o, t, w, lane0, wg);
+    if (__builtin_expect(pending_eval >= 0, 0)) {
+      __syncthreads();
+      if (has_erow) u_owner_eval(p, XS, red, eo, pending_eval, u_eval_stream(p, o, pending_eval, false), o.a);
+      pending_eval = -1;
+    }
+    if (__builtin_expect(p.do_eval && step > 0 && (step - 1) % p.eval_every == 0, 0))
+      pending_eval = u_evals_before(step, p.eval_every) - 1;
+    __syncthreads();
+  }
+  if (p.do_eval && !run_aborted(flagp, red, tid)) {
+    if (pending_eval >= 0 && has_erow)
+      u_owner_eval(p, XS, red, eo, pending_eval, u_eval_stream(p, o, pending_eval, false), o.a);
+    if (o.step0 + p.n_updates == p.n_total && (!dp || p.n_updates == 0)) {
+      const int e = u_evals_before(p.n_total - 1, p.eval_every);
+      __syncthreads();
+      if (has_erow) u_owner_eval(p, XS, red, eo, e, u_eval_stream(p, o, e, true), o.a);
+    }
+  }
+}
+
 template <bool DP, int NT>
 __global__ __launch_bounds__(kUT) void linear_head_updates_kernel(UArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifndef BSIG_HOST_SAN_BUILD   // (see fit_persistent_mdnn.hip)
-  unified_workgroup<DP, NT>(p, smem);
+  const URole role = wg_role(blockIdx.x, p.T, p.G);
+  if (role.tile < 0) owner_only_workgroup(p, smem, role, 16 * NT, DP);
+  else unified_workgroup<DP, NT>(p, smem, role);
 #endif
 }
 
@@ -931,8 +1097,9 @@ static bool u_geom_try(const PersistShape& s, int NT, int KS, UGeom* g, double* 
   // spare, else two; else the owners are (also) tile workgroups, one row each.
   const int spare = kXwgMax - g->G;
   bool mixed = false;
-  if (spare >= s.batch) { g->R = 1; g->T = g->G + s.batch; }
-  else if (spare >= ceil_div(s.batch, 2)) { g->R = 2; g->T = g->G + ceil_div(s.batch, 2); }
+  static const bool force_mixed = [] { const char* e = getenv("BSIG_PERSIST_MIXED"); return e && e[0] == '1'; }();   // (A/B runs)
+  if (!force_mixed && spare >= s.batch) { g->R = 1; g->T = g->G + s.batch; }
+  else if (!force_mixed && spare >= ceil_div(s.batch, 2)) { g->R = 2; g->T = g->G + ceil_div(s.batch, 2); }
   else {
     mixed = true;
     g->T = std::max(g->G, std::min(s.batch, kXwgMax));
@@ -986,10 +1153,14 @@ static bool u_geom(const PersistShape& s, UGeom* g) {
   if (ceil_div(s.out_dim, groups) > kElemsPerLane) return false;   // diag_row's register cache
   bool found = false;
   double best = 0.0;
+  // (A/B runs: BSIG_PERSIST_NT / BSIG_PERSIST_KS pin the tiling)
+  static const int force_nt = [] { const char* e = getenv("BSIG_PERSIST_NT"); return e ? atoi(e) : 0; }();
+  static const int force_ks = [] { const char* e = getenv("BSIG_PERSIST_KS"); return e ? atoi(e) : 0; }();
   for (int NT = 1; NT <= 2; ++NT)
     for (int groups6 = 1; groups6 <= kUSteps / kUGroup; ++groups6) {   // k-slices of 96 / 192 / 288 columns
       UGeom c;
       double cost = 0.0;
+      if ((force_nt && NT != force_nt) || (force_ks && 16 * kUGroup * groups6 != force_ks)) continue;
       if (!u_geom_try(s, NT, 16 * kUGroup * groups6, &c, &cost)) continue;
       if (!found || cost < best) { *g = c; best = cost; found = true; }
     }
@@ -1161,6 +1332,10 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
     // (the slab buffers are laid out for this call's passes: [3][eval_passes][k_slices][B][NhP])
   }
   p.prof = reinterpret_cast<long long*>(persist_profile_buffer());
+  if (p.prof) {
+    const char* t0 = getenv("BSIG_PROF_T0");
+    p.prof_t0 = t0 ? atoi(t0) : 0;
+  }
   return g.NT == 1 ? u_launch<1>(g, p, b.grads != nullptr, n, b.do_eval != 0, st)
                    : u_launch<2>(g, p, b.grads != nullptr, n, b.do_eval != 0, st);
 }

@@ -52,7 +52,17 @@ struct HeadArgs {
 // head outputs, yv[D] target.  Out: gradients in tile[K..Nh) and dlg[K]
 // (without the jitter-scale term), the row's logsumexp, sum(u * dL/dsigma),
 // and exp(pre) of the lane's elements (for the jitter-scale correction).
-struct RowOut { float lse, uds; bool bad; float esg0[kElemsPerLane]; };
+struct RowOut {
+  float lse, uds; bool bad; float esg0[kElemsPerLane];
+#ifdef BSIG_ROW_PROF
+  long long ts[10];            // (profiling build) wall-clock stamps inside diag_row
+#endif
+};
+#ifdef BSIG_ROW_PROF
+#define BSIG_ROW_STAMP(i) out.ts[i] = wall_clock64()
+#else
+#define BSIG_ROW_STAMP(i)
+#endif
 
 // `eps_fn()` delivers the jitter scale; it is called (by the whole wave) after
 // everything that does not depend on it -- the Philox draws, exp(pre), the
@@ -60,11 +70,10 @@ struct RowOut { float lse, uds; bool bad; float esg0[kElemsPerLane]; };
 // The row's jitter draws u ~ U[0, 1) (mdnn.py:116), element q of the lane as in diag_row: they
 // depend on (seed, stream, row) only, so a caller that waits for the row's head outputs anyway can
 // draw them during the wait and hand them to diag_row (`eu_pre`).
-__device__ __forceinline__ void diag_row_noise(const HeadArgs& a, int row, bool active, int lane,
-                                               float (&eu)[kElemsPerLane]) {
+__device__ __forceinline__ void diag_row_noise(const HeadArgs& a, int groups, int k, int d0, int row,
+                                               bool active, int lane, float (&eu)[kElemsPerLane]) {
   const int D = a.D, K = a.K;
-  const int groups = 64 / K, TPR = groups * K;
-  const int k = lane % K, d0 = lane / K;
+  const int TPR = groups * K;
   const bool elem = active && lane < TPR;
   const bool jitter = !a.from_tuple && a.eps_noise != 0.f;
   const bool draw = jitter && a.noise == nullptr;
@@ -81,6 +90,7 @@ __device__ __forceinline__ void diag_row_noise(const HeadArgs& a, int row, bool 
   }
 }
 
+#ifdef BSIG_DIAG_ROW_V1
 template <typename EpsFn>
 __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active, int lane,
                                          float* tile, const float* yv, float* rk, float* lpk,
@@ -210,6 +220,290 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
   __builtin_amdgcn_wave_barrier();
   out.lse = lse; out.uds = uds; out.bad = bad;
 }
+
+#else
+// Wavefront maximum through the DPP row shifts / broadcasts (cf. wave_sum_dpp, common.h); every
+// lane gets the result.
+__device__ inline float wave_max_dpp(float v) {
+#define BSIG_DPP_MAX(ctrl, row_mask)                                                        \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), \
+                                             __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false)))
+  BSIG_DPP_MAX(0x111, 0xf);   // row_shr:1
+  BSIG_DPP_MAX(0x112, 0xf);   // row_shr:2
+  BSIG_DPP_MAX(0x114, 0xf);   // row_shr:4
+  BSIG_DPP_MAX(0x118, 0xf);   // row_shr:8
+  BSIG_DPP_MAX(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+  BSIG_DPP_MAX(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef BSIG_DPP_MAX
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// wave_sum_dpp(a * b) with the product's first addition fused (the first version's compile of that
+// expression; with contraction off it has to be spelled out to keep the logit gradients' bits)
+__device__ inline float wave_sum_dpp_prod(float a, float b) {
+  const float p = a * b;
+  float v = __builtin_fmaf(a, b, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                      0, __builtin_bit_cast(int, p), 0x111, 0xf, 0xf, false)));   // row_shr:1
+#define BSIG_DPP_ADD(ctrl, row_mask)                                                        \
+  v += __builtin_bit_cast(                                                                  \
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+  BSIG_DPP_ADD(0x112, 0xf);   // row_shr:2
+  BSIG_DPP_ADD(0x114, 0xf);   // row_shr:4
+  BSIG_DPP_ADD(0x118, 0xf);   // row_shr:8
+  BSIG_DPP_ADD(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+  BSIG_DPP_ADD(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef BSIG_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// The jitter scale as an object: issue() may start a cross-workgroup gather early (its loads stay
+// in flight over the arithmetic that does not depend on the scale), get() delivers the value.
+template <typename F>
+struct EpsNow {
+  F f;
+  __device__ __forceinline__ void issue() {}
+  __device__ __forceinline__ float get() { return f(); }
+};
+
+// Round 4: written for LATENCY.  The row is one wavefront's dependent chain (its 2 x D x K elements
+// are 1-8 per lane), and the first version spent it in waits: ~40 LDS round trips, 39 IEEE
+// divisions, four rounds of two ds_bpermutes for the per-component sums, K exponentials per lane for
+// the logsumexp (4.3 us per row at D = 32, K = 4, the longest piece of every persistent update).  Now:
+// every LDS read of the row is issued before anything waits; the lane geometry (integer divisions
+// by K) comes from the caller; the sums over the dimensions of a component go through LDS (the
+// component lanes read their `groups` partial sums back in one batch, at constant offsets); the
+// logsumexp's K exponentials are one per component lane; the element loops are specialised on the
+// number of sweeps; the jitter scale is requested before the arithmetic that does not need it.
+// The ARITHMETIC stays the reference's: IEEE divisions (a cheaper reciprocal moved cfg3 -- whose
+// 11802-wide first layer turns an ulp into 1e-4 of held-out NLL within a chunk -- from 7e-6 to
+// 1.7e-4 off the oracle), the first version's reduction trees and summation orders, and no
+// contraction of multiplies and adds (below).
+// Where a lane sits in the row: component k, dimension slot d0 (element (d, k), d = d0 + q * groups,
+// of sweep q); groups = 64 / K, TPR = groups * K lanes take part, nq sweeps cover the D dimensions.
+// Four integer divisions by run-time values (~150 instructions): a kernel that runs many rows per
+// lane computes this once (row_geom) and calls diag_row_g.
+struct RowGeom { int k, d0, groups, TPR, nq; };
+__device__ __forceinline__ RowGeom row_geom(int D, int K, int lane) {
+  RowGeom g;
+  g.groups = 64 / K;
+  g.TPR = g.groups * K;
+  g.k = lane % K;
+  g.d0 = lane / K;
+  g.nq = (D + g.groups - 1) / g.groups;
+  return g;
+}
+
+// NQ: compile-time bound of the sweeps (nq <= NQ): the element loops have no run-time test but the
+// validity of the last sweep.
+template <int NQ, typename Eps>
+__device__ __forceinline__ void diag_row_body(const HeadArgs& a, const RowGeom& rg, int row, bool active,
+                                              int lane, float* tile, const float* yv, float* rk,
+                                              float* dlg, Eps& eps_src, RowOut& out, const float* eu_pre) {
+  // Contraction of multiplies and adds is OFF in this function and the three fused operations it
+  // has (sigma0 + u * eps, z^2 - 1, the sum of u * dL/dsigma) are written out: left to the compiler,
+  // the bits of a row changed with unrelated edits of the surrounding code -- which the wide
+  // cross-correlation configs amplify to 1e-4 of held-out NLL within a chunk.  The choices are the
+  // first version's (tools/micro/diag_row_ab.py compares two builds bit by bit).
+#pragma clang fp contract(off)
+  const int D = a.D, K = a.K;
+  const int DK = D * K;
+  const int groups = rg.groups, TPR = rg.TPR, k = rg.k, d0 = rg.d0;
+  const bool elem = active && lane < TPR;
+  const bool comp = active && lane < K;
+  const bool tup = a.from_tuple != 0;
+  const bool jitter = !tup && a.eps_noise != 0.f;
+  const bool draw = jitter && a.noise == nullptr && eu_pre == nullptr;
+  bool bad = false;
+  float (&esg0)[kElemsPerLane] = out.esg0;
+  float pre[NQ], ydf[NQ], eu[NQ], rsg[NQ], ez[NQ], muv[NQ];   // (rsg: the element's sigma)
+  bool valid[NQ];
+
+  BSIG_ROW_STAMP(0);
+  // ---- every LDS read of the row, then the jitter-scale request ------------------------------
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int e = min(lane + q * TPR, DK - 1), d = min(d0 + q * groups, D - 1);
+    valid[q] = elem && d0 + q * groups < D;
+    pre[q] = tile[K + DK + e];
+    muv[q] = tile[K + e];
+    ydf[q] = yv[d];
+  }
+  const float lg_own = tile[min(lane, K - 1)];
+  eps_src.issue();
+  BSIG_ROW_STAMP(1);
+
+  // ---- what does not depend on the jitter scale ---------------------------------------------
+  Philox4 ph{{0u, 0u, 0u, 0u}};
+  const uint64_t rng_seed = a.dyn_rng ? a.dyn_rng[0] : a.seed;
+  const uint64_t rng_sid = a.dyn_rng ? a.dyn_rng[1] : a.stream_id;
+#pragma unroll
+  for (int q = 0; q < kElemsPerLane; ++q) esg0[q] = 1.f;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    eu[q] = 0.f; rsg[q] = 0.f; ez[q] = 0.f;
+    if ((q & 3) == 0 && draw && valid[q])
+      ph = philox4x32_10(rng_seed, rng_sid, ((uint64_t)row * 64 + lane) * 2 + (q >> 2));
+    ydf[q] -= muv[q];
+    if (!tup) {
+      const float ev = expf(pre[q]);
+      esg0[q] = valid[q] ? ev : 1.f;
+      if (jitter && valid[q])
+        eu[q] = eu_pre ? eu_pre[q] : (a.noise ? a.noise[((int64_t)row * D + d0 + q * groups) * K + k] : u01(ph.v[q & 3]));
+    }
+  }
+  BSIG_ROW_STAMP(2);
+  // mixture weights (mdnn.py:109-111): lane j < K owns component j
+  float s_own = 0.f, w_own = 0.f, csum = 1.f;
+  if (active && !tup) {
+    const float mx = wave_max_dpp(comp ? lg_own : -INFINITY);     // (a loop over tile[j]: K dependent LDS round trips)
+    const float e_own = comp ? expf(lg_own - mx) : 0.f;
+    s_own = e_own / wave_sum_dpp(e_own);
+    const float c_own = comp ? fminf(fmaxf(s_own, a.min_w), 1.0f) : 0.f;
+    csum = wave_sum_dpp(c_own);
+    w_own = c_own / csum;
+  } else if (comp) {
+    w_own = lg_own;
+  }
+  const float wc = fminf(fmaxf(w_own, a.min_w), 1.0f);     // the second clamp, mdnn.py:160
+  const float lw = comp ? logf(wc) : 0.f;
+
+  // ---- the row with the jitter scale ----------------------------------------------------------
+  BSIG_ROW_STAMP(3);
+  const float eps = eps_src.get();
+  BSIG_ROW_STAMP(4);
+  float quad = 0.f, logdet = 0.f;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    float sg;
+    if (tup) sg = pre[q];
+    else {
+      sg = esg0[q];
+      if (eps != 0.f) sg = __builtin_fmaf(eu[q], eps, sg);
+      else eu[q] = 0.f;
+    }
+    if (!valid[q]) sg = 1.f;
+    bad |= valid[q] && !(isfinite(muv[q]) && isfinite(sg));
+    const float z = valid[q] ? ydf[q] / sg : 0.f;
+    quad += z * z;
+    logdet += logf(sg);          // (log 1 = 0 for the sweeps beyond D)
+    ez[q] = z; rsg[q] = sg;
+  }
+  // sums over the dimensions of each component: the lanes' partial sums go where the row's
+  // mu / pre values were (all in registers by now), component by component (slot d0 of component k
+  // at k * gp + d0), and lane k < K adds its component's gp values in slot order -- reads at constant
+  // offsets from one address per lane
+  const int gp = min(groups, D);
+  BSIG_ROW_STAMP(5);
+  __builtin_amdgcn_wave_barrier();
+  if (elem && d0 < gp) { tile[K + k * gp + d0] = quad; tile[K + DK + k * gp + d0] = logdet; }
+  __builtin_amdgcn_wave_barrier();
+  float rv = -INFINITY, logp = 0.f;
+  if (comp) {
+    float qs = 0.f, ls = 0.f;
+    const float* bq = tile + K + lane * gp;
+    const float* bl = bq + DK;
+    if (groups <= 16) {
+      // (slots beyond gp: another component's values or the next segment, still inside the row's LDS; zeroed)
+      float tq[16], tl[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { tq[u] = bq[u]; tl[u] = bl[u]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (u >= gp) { tq[u] = 0.f; tl[u] = 0.f; }
+      // the order of the first version's shuffle tree (slot i takes slot i + off, off = 8, 4, 2, 1 below
+      // `groups`, all slots at once): the same bits as before
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        if (off < groups || off == 1) {
+#pragma unroll
+          for (int i = 0; i + off < 16; ++i)
+            if (i + off < groups) { tq[i] += tq[i + off]; tl[i] += tl[i + off]; }
+        }
+      }
+      qs = tq[0]; ls = tl[0];
+    } else {
+      for (int g0 = 0; g0 < gp; g0 += 16) {
+        float tq[16], tl[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { tq[u] = bq[g0 + u]; tl[u] = bl[g0 + u]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (g0 + u < gp) { qs += tq[u]; ls += tl[u]; }
+      }
+    }
+    logp = -0.5f * qs - ls - (float)D * kHalfLog2Pi;
+    const float lp = fminf(fmaxf(logp, -a.ll_limit), a.ll_limit);
+    rv = lp + lw;
+    bad |= !(isfinite(w_own) && isfinite(logp) && isfinite(rv));
+  }
+  BSIG_ROW_STAMP(6);
+  // logsumexp over the components (lanes < K), mdnn.py:163-178
+  float lse = 0.f, sc = 0.f;
+  if (active) {
+    const float m2 = wave_max_dpp(rv);
+    const float ek = comp ? expf(rv - m2) : 0.f;
+    float se = 0.f;                                   // (added in component order, as the first version did)
+    for (int j = 0; j < K; ++j) se += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ek), j));
+    lse = m2 + logf(se);
+    if (comp) sc = -expf(rv - lse) * a.inv_norm;
+  }
+
+  BSIG_ROW_STAMP(7);
+  const bool bwd = a.d_out != nullptr;
+  float uds = 0.f;
+  if (bwd && active) {
+    // d loss / d logp_k (zero where the clamp of mdnn.py:159 is active) for the element lanes
+    __builtin_amdgcn_wave_barrier();
+    if (comp) rk[lane] = (logp >= -a.ll_limit && logp <= a.ll_limit) ? sc : 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const float g_lp = rk[k];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (valid[q]) {
+        const int e = lane + q * TPR;
+        const float dsg = g_lp * __builtin_fmaf(ez[q], ez[q], -1.0f) / rsg[q];
+        uds = __builtin_fmaf(eu[q], dsg, uds);
+        tile[K + e] = g_lp * ez[q] / rsg[q];
+        tile[K + DK + e] = dsg * esg0[q];
+      }
+    }
+    // mixture-weight path, lane = component
+    const float gw = (comp && w_own >= a.min_w && w_own <= 1.0f) ? sc / wc : 0.f;
+    float dlogit = gw;
+    if (!tup) {                             // through the renormalisation, the clamp, the softmax
+      const float s1 = wave_sum_dpp_prod(gw, w_own);
+      const float gs = (comp && s_own >= a.min_w && s_own <= 1.0f) ? (gw - s1) / csum : 0.f;
+      const float s2 = wave_sum_dpp_prod(gs, s_own);
+      dlogit = s_own * (gs - s2);
+    }
+    if (comp) dlg[lane] = dlogit;           // separate slot: the logits stay readable
+  }
+  __builtin_amdgcn_wave_barrier();
+  BSIG_ROW_STAMP(8);
+  out.lse = lse; out.uds = uds; out.bad = bad;
+}
+
+template <typename Eps>
+__device__ __forceinline__ void diag_row_impl(const HeadArgs& a, const RowGeom& rg, int row, bool active,
+                                              int lane, float* tile, const float* yv, float* rk,
+                                              float* lpk, float* dlg, Eps& eps_src, RowOut& out,
+                                              const float* eu_pre) {
+  (void)lpk;
+  if (rg.nq <= 2) diag_row_body<2>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+  else if (rg.nq <= 4) diag_row_body<4>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+  else diag_row_body<kElemsPerLane>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+}
+
+// `eps_fn()` form: the jitter scale from a plain callable; the lane geometry computed here
+template <typename EpsFn>
+__device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active, int lane,
+                                         float* tile, const float* yv, float* rk, float* lpk,
+                                         float* dlg, EpsFn&& eps_fn, RowOut& out,
+                                         const float* eu_pre = nullptr) {
+  EpsNow<EpsFn&> e{eps_fn};
+  const RowGeom rg = row_geom(a.D, a.K, lane);
+  diag_row_impl(a, rg, row, active, lane, tile, yv, rk, lpk, dlg, e, out, eu_pre);
+}
+#endif
 
 // jitter draw of element (row, d, k) for the thread-per-component kernels (full covariance)
 __device__ inline float jitter_u(const HeadArgs& a, int row, int d, int k) {

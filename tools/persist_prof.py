@@ -25,12 +25,13 @@ theta, states, actions = bench.synth_pairs(cfg, 1000, 3, dev)
 bs = bench.build_gpu_model(B, cfg, dev, 77)
 summ = bs._summarize(states, actions)
 bs.model.run_training(summ, theta, 100, 100)          # warm-up (plan, graphs)
-buf = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(2 * 256 * 8 * 16, dtype=torch.int64, device=dev)
 lib.bsig_debug_persist_profile(buf.data_ptr())
 bs.model.run_training(summ, theta, 100, 100)
 torch.cuda.synchronize()
 lib.bsig_debug_persist_profile(None)
-st = buf.cpu().numpy().reshape(256, 8, 16).astype(np.float64) / 100.0   # 100 MHz -> us
+raw = buf.cpu().numpy().reshape(2, 256, 8, 16).astype(np.float64) / 100.0   # 100 MHz -> us
+st, rowst = raw[0], raw[1]
 live = [g for g in range(256) if st[g, 1, 0] > 0]
 v1 = os.environ.get('BSIG_PERSIST_V1') == '1'
 
@@ -59,21 +60,21 @@ if v1:
 else:
     owners = [g for g in live if st[g, 1, 4] > 0]
     tiles = [g for g in live if st[g, 1, 3] > 0]
-    print('%s: %d workgroups with a weight tile, %d of the launch own a minibatch row; updates 1..7 of the last launch'
-          % (name, len(tiles), len(owners)))
+    print('%s: %d workgroups with a weight tile, %d of the launch own a minibatch row; updates %d + 1..7 of the last launch'
+          % (name, len(tiles), len(owners), int(os.environ.get('BSIG_PROF_T0', '0'))))
     both = [g for g in owners if g in tiles]
     only_t = [g for g in tiles if g not in owners]
     for g in both[:1] + both[-1:]:
         print('tile + row wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
         phases(g, (('fwd mfma (wave 0)', 0, 1), ('slab store+flag', 1, 3), ('wait fwd flags', 3, 4),
-                   ('slab sum', 4, 5), ('row: pre-eps part', 5, 6), ('eps gather + row', 6, 7),
+                   ('slab sum', 4, 5), ('row (diag_row)', 5, 7),
                    ('dO/E store+publish', 7, 9), ('next tile requested', 9, 2), ('wait for owners', 2, 10), ('dO^T load', 10, 11),
                    ('dW mfma+adam (wave 0)', 11, 8), ('end barrier', 8, 12)))
     only_o = [g for g in owners if g not in tiles]
     for g in only_o[:1] + only_o[-1:]:
         print('row wg %3d (no tile): update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
-        phases(g, (('wait fwd flags', 0, 4), ('slab sum', 4, 5), ('row: pre-eps part', 5, 6),
-                   ('eps gather + row', 6, 7), ('dO/E store+publish', 7, 9)))
+        phases(g, (('wait fwd flags', 0, 4), ('slab sum', 4, 5), ('row (diag_row)', 5, 7),
+                   ('dO/E store+publish', 7, 9)))
         print('    %-22s %6.2f us' % ('idle until next', (st[g, 2:8, 0] - st[g, 1:7, 9]).mean()))
     for g in only_t[:1] + only_t[-1:]:
         print('tile wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
@@ -88,7 +89,6 @@ print('chip-level timeline, mean over updates 2..6 of the launch (us after the f
 rows += [('first owner released', owners, 4, np.min),
          ('last owner released', owners, 4, np.max),
          ('last owner has its row (slab sum, exp published)', owners, 5, np.max),
-         ('last owner waits for eps', owners, 6, np.max),
          ('last row finished', owners, 7, np.max),
          ('last owner published d_out', owners, 9, np.max),
          ('first tile wg released', tiles, 10, np.min),
@@ -103,3 +103,13 @@ for u in range(2, 7):
         acc[label].append(fn([st[g, u, k] for g in grp]) - t0)
 for label, _, _, _ in rows:
     print('    %-52s %6.2f' % (label, np.mean(acc[label])))
+
+if rowst.any():      # a BSIG_ROW_PROF build: stamps inside diag_row (wave 0 of the first row owner)
+    g = owners[0]
+    names = ['LDS reads issued', 'exp(pre), y - mu, noise', 'mixture weights', 'eps get (gather)', 'sigma, z, log',
+             'sums over d (LDS)', 'logsumexp', 'backward']
+    print('inside diag_row (wg %d):' % g)
+    for i, n in enumerate(names):
+        print('    %-26s %6.2f us' % (n, (rowst[g, 1:8, i + 1] - rowst[g, 1:8, i]).mean()))
+    print('    %-26s %6.2f us' % ('stamp 5 -> diag_row start', (rowst[g, 1:8, 0] - st[g, 1:8, 5]).mean()))
+    print('    %-26s %6.2f us' % ('diag_row end -> stamp 7', (st[g, 1:8, 7] - rowst[g, 1:8, 8]).mean()))
