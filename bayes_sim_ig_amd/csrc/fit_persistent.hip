@@ -195,38 +195,6 @@ __device__ __forceinline__ void u_rows_sum4(const float* slabs, RowOff&& rowoff,
   }
 }
 
-// The jitter scale EPS_NOISE * mean(exp(pre)) of an update from the owners' sum(exp(pre)) granules,
-// for diag_row_impl: the granule loads are issued before the row arithmetic that does not need the
-// scale and looked at after it -- by then the other owners' granules (published about when this
-// owner published its own) have arrived, and the gather costs no round trip of its own.  A granule
-// that was not up yet sends get() through the bounded polling loop.
-struct GranuleEps {
-  const unsigned long long* g; int G; uint32_t tag; int lane; int32_t* flag; float scale; bool on;
-  unsigned long long x[4];
-  __device__ __forceinline__ void issue() {
-    if (on) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        x[u] = __hip_atomic_load(g + min(lane + 64 * u, G - 1) * kGranStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __device__ __forceinline__ float get() {
-    if (!on) return 0.f;
-    float v[4];
-    bool all = true;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool mine = lane + 64 * u < G, up = (uint32_t)(x[u] >> 32) == tag;
-      v[u] = mine && up ? __uint_as_float((uint32_t)x[u]) : 0.f;
-      all = all && (!mine || up);
-    }
-    float sum;
-    if (__all(all)) sum = (wave_sum_dpp(v[0]) + wave_sum_dpp(v[1])) + (wave_sum_dpp(v[2]) + wave_sum_dpp(v[3]));
-    else sum = granule_gather(const_cast<unsigned long long*>(g), G, tag, lane, flag);
-    return scale * sum;
-  }
-};
-
 // ---- tile part of held-out evaluation eidx: held-out rows x this tile's weights (the B operand
 //      straight from memory, six 16-column steps at a time) -> evaluation slab buffer eidx % 3, flag
 template <int NT>
@@ -462,7 +430,7 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
 #pragma unroll
     for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
     if (owner_wave) {
-      GranuleEps ge{p.gran, p.n_owner, tag + 1, lane, flagp, p.eps_noise / norm, p.eps_noise != 0.f, {0ull, 0ull, 0ull, 0ull}};
+      GranuleEps ge{p.gran, p.n_owner, tag + 1, lane, flagp, p.eps_noise, norm, {0ull, 0ull, 0ull, 0ull}};
       diag_row_impl(a, rg, row, active, lane, tile, yv, rk, lpk, dlg, ge, ro, eu_pre);
 #ifdef BSIG_ROW_PROF
       if (p.prof && tid == 0 && t >= p.prof_t0 && t < p.prof_t0 + kUProf)

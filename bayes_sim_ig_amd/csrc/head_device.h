@@ -742,6 +742,38 @@ __device__ inline void granule_wait_one(const unsigned long long* g, int slot, u
   }
 }
 
+// The jitter scale EPS_NOISE * mean(exp(pre)) of an update from the owners' sum(exp(pre)) granules,
+// for diag_row_impl: the granule loads are issued before the row arithmetic that does not need the
+// scale and looked at after it -- by then the other owners' granules (published about when this
+// owner published its own) have arrived, and the gather costs no round trip of its own.  A granule
+// that was not up yet sends get() through the bounded polling loop.
+struct GranuleEps {
+  const unsigned long long* g; int G; uint32_t tag; int lane; int32_t* flag; float eps_noise, norm;
+  unsigned long long x[4];
+  __device__ __forceinline__ void issue() {
+    if (eps_noise != 0.f) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        x[u] = __hip_atomic_load(g + min(lane + 64 * u, G - 1) * kGranStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __device__ __forceinline__ float get() {
+    if (eps_noise == 0.f) return 0.f;
+    float v[4];
+    bool all = true;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool mine = lane + 64 * u < G, up = (uint32_t)(x[u] >> 32) == tag;
+      v[u] = mine && up ? __uint_as_float((uint32_t)x[u]) : 0.f;
+      all = all && (!mine || up);
+    }
+    float sum;
+    if (__all(all)) sum = (wave_sum_dpp(v[0]) + wave_sum_dpp(v[1])) + (wave_sum_dpp(v[2]) + wave_sum_dpp(v[3]));
+    else sum = granule_gather(const_cast<unsigned long long*>(g), G, tag, lane, flag);
+    return eps_noise * (sum / norm);
+  }
+};
+
 // write-through store / cache-bypassing load for data that crosses workgroups
 // inside one launch
 __device__ inline void xwg_store(float* p, float v) {

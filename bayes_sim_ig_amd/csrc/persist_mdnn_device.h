@@ -467,7 +467,11 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
       if (p.prof) { asm volatile("" :: "v"(pf0.x), "v"(pf12.w)); BSIG_MSTAMP(8); }
     }
     // ---- 3. dW1 = dz1^T X on this tile, Adam ---------------------------------------
-    if (w == 0) flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
+    // (quiet waiting, head_device.h: one word until the first owner is through, then the rest)
+    if (w == 0) {
+      flag_wait_one(p.flag_own, 0, epoch, flagp);
+      flags_wait(p.flag_own, p.n_owner, epoch, lane, flagp);
+    }
     __syncthreads();
     BSIG_MSTAMP(10);
     {
@@ -1288,6 +1292,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     __syncthreads();
   };
   const int ev0 = p.do_eval ? mdnn_evals_before(step0, p.eval_every) : 0;
+  const RowGeom rg0 = row_geom(D, K, tid_0 & 63);   // (integer divisions by run-time values: once per launch)
 
   if (w_0 == 0) flags_wait(p.flag_pack, p.n_small, p.launch_tag, tid_0 & 63, flagp);
   __syncthreads();
@@ -1317,6 +1322,14 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       const int64_t yrow = p.ids[(int64_t)step * B + row];
       for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
     }
+    // one jitter stream per update and per evaluation, in program order; the row's draws do not depend
+    // on the forward product: taken here, in the wait
+    a.stream_id = rng_ctr0 + (uint64_t)t +
+                  (uint64_t)(p.do_eval ? mdnn_evals_before(step, p.eval_every) - ev0 : 0);
+    float eu_pre[kElemsPerLane];
+    if constexpr (!FULL) {
+      if (w < MR) diag_row_noise(a, rg0.groups, rg0.k, rg0.d0, row, active, lane, eu_pre);
+    }
     if (!DP && t > 0 && w == 0)
       flags_wait(p.flag_small, WIDE ? kMH / kMNB : p.n_small, epoch - 1u, lane, flagp);
     __syncthreads();
@@ -1334,6 +1347,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y; \
     }
     if (w == 0) {
+      flag_wait_one(p.o_flags, p.G1 - 1, epoch, flagp);
       flags_wait(p.o_flags, p.G1, epoch, lane, flagp);
       BSIG_LOAD_W2F()
     } else {
@@ -1487,17 +1501,18 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     ro.lse = 0.f; ro.uds = 0.f; ro.bad = false;
 #pragma unroll
     for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
-    // one jitter stream per update and per evaluation, in program order
-    a.stream_id = rng_ctr0 + (uint64_t)t +
-                  (uint64_t)(p.do_eval ? mdnn_evals_before(step, p.eval_every) - ev0 : 0);
-    {
+    if constexpr (FULL) {
       auto row_eps = [&] {
         return p.eps_noise != 0.f
                    ? p.eps_noise * (granule_gather(p.gran, p.n_owner, tag + 1, lane, flagp) / norm)
                    : 0.f;
       };
-      if constexpr (FULL) full_row(a, row, active, lane, tile, yv, rk, dlg, dlg + K, row_eps, ro);
-      else diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, row_eps, ro);
+      full_row(a, row, active, lane, tile, yv, rk, dlg, dlg + K, row_eps, ro);
+    } else {
+      // (lane geometry from before the loop, jitter draws from the wait, the jitter-scale gather issued
+      // ahead of the arithmetic that does not need it: head_device.h)
+      GranuleEps ge{p.gran, p.n_owner, tag + 1, lane, flagp, p.eps_noise, norm, {0ull, 0ull, 0ull, 0ull}};
+      diag_row_impl(a, rg0, row, active, lane, tile, yv, rk, lpk, dlg, ge, ro, eu_pre);
     }
     {
       const float uds_w = wave_sum_dpp(ro.uds);
