@@ -18,6 +18,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_ACT, EPI_COS_SIN, EPI_COS_OFF, EPI_MUL_DACT = range
 ACT_TANH, ACT_RELU, ACT_LEAKY_RELU, ACT_SIGMOID, ACT_IDENTITY = range(5)
 MAX_HIDDEN = 8
 FIT_GRAPH, FIT_SPLIT_ADAM = 1, 2
+PLAN_NO_PERSISTENT = 1
 X_ROWS, X_CROSSCORR_FACTORS = 0, 1
 
 i64, i32, u64, f32, vp, sz = (C.c_int64, C.c_int32, C.c_uint64, C.c_float,
@@ -93,6 +94,7 @@ _PROTOS = {
                                      vp, vp, sz, vp]),
     'bsig_fit_create': (C.c_int, [C.POINTER(MdnCfg), i64, i64, i64, C.POINTER(vp)]),
     'bsig_fit_create_sized': (C.c_int, [C.POINTER(MdnCfg), i64, i64, i64, i64, C.POINTER(vp)]),
+    'bsig_fit_create_ex': (C.c_int, [C.POINTER(MdnCfg), i64, i64, i64, i64, C.c_int, C.POINTER(vp)]),
     'bsig_fit_destroy': (None, [vp]),
     'bsig_fit_workspace_bytes': (sz, [vp]),
     'bsig_fit_bind': (C.c_int, [vp, C.POINTER(FitBuffers), C.c_int]),
@@ -105,6 +107,7 @@ _PROTOS = {
     'bsig_fit_is_persistent': (C.c_int, [vp]),
     'bsig_fit_accepts_factors': (C.c_int, [vp]),
     'bsig_fit_accepts_factor_rows': (C.c_int, [vp, C.c_int, C.c_int]),
+    'bsig_fit_evaluates_from_factors': (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
     'bsig_fit_takes_features': (C.c_int, [vp, i64]),
     'bsig_fit_eval': (C.c_int, [vp, vp]),
     'bsig_fit_updates': (C.c_int, [vp, i64, vp]),

@@ -379,6 +379,7 @@ struct bsig_fit_plan {
   size_t persist_bytes;
   hipStream_t cap_stream;
   hipGraphExec_t g_step, g_grad, g_apply, g_eval;
+  bool graphs_ready;           // ensure_graphs has run for this binding (g_eval may legitimately be absent)
   const float* graph_feats;    // the feature block the captured graphs read (kernel argument)
   // data-parallel rank in the persistent kernel of the linear heads: one steady-state update
   // (launch with the pending Adam step -> ncclAllReduce of the gradients) as ONE graph
@@ -596,6 +597,7 @@ static void drop_graphs(bsig_fit_plan* p) {
   for (auto g : gs)
     if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
   p->g_dp_state = 0; p->g_dp_comm = nullptr;
+  p->graphs_ready = false;
 }
 
 template <typename F>
@@ -616,8 +618,8 @@ static int ensure_graphs(bsig_fit_plan* p) {
   PlanMem fm; plan_mem(p, &fm);
   // the graphs carry the feature block's address as a kernel argument: a block handed over in
   // place (bsig_fit_set_features) or taken back (bsig_fit_begin) invalidates them
-  if (p->g_eval && p->graph_feats != fm.feats) drop_graphs(p);
-  if (!p->use_graph || p->g_eval) return BSIG_OK;
+  if (p->graphs_ready && p->graph_feats != fm.feats) drop_graphs(p);
+  if (!p->use_graph || p->graphs_ready) return BSIG_OK;
   p->graph_feats = fm.feats;
   if (p->split_adam) {
     if (!p->persistent && !p->persistent_mdnn) {
@@ -629,7 +631,11 @@ static int ensure_graphs(bsig_fit_plan* p) {
   } else {
     BSIG_TRY(capture(p, &p->g_step, [&](hipStream_t s) { return enqueue_grad(p, s, true); }));
   }
-  BSIG_TRY(capture(p, &p->g_eval, [&](hipStream_t s) { return enqueue_eval(p, s); }));
+  // (a binding without held-out summary rows evaluates from factor rows inside its launches:
+  // bsig_fit_evaluates_from_factors -- there is nothing an evaluation graph could read)
+  if (p->buf.n_test < 1 || p->buf.x_test)
+    BSIG_TRY(capture(p, &p->g_eval, [&](hipStream_t s) { return enqueue_eval(p, s); }));
+  p->graphs_ready = true;
   return BSIG_OK;
 }
 
@@ -725,6 +731,12 @@ extern "C" int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t m
 extern "C" int bsig_fit_create_sized(const bsig_mdn_cfg* cfg, int64_t batch,
                                      int64_t max_train_rows, int64_t max_test_rows,
                                      int64_t n_updates, bsig_fit_plan** plan) {
+  return bsig_fit_create_ex(cfg, batch, max_train_rows, max_test_rows, n_updates, 0, plan);
+}
+
+extern "C" int bsig_fit_create_ex(const bsig_mdn_cfg* cfg, int64_t batch,
+                                  int64_t max_train_rows, int64_t max_test_rows,
+                                  int64_t n_updates, int plan_flags, bsig_fit_plan** plan) {
   BSIG_REQUIRE(cfg && plan && batch >= 1 && max_train_rows >= 0 && max_test_rows >= 0 &&
                n_updates >= 0, "fit_create: bad args");
   bsig_fit_plan* p = new (std::nothrow) bsig_fit_plan();
@@ -750,7 +762,8 @@ extern "C" int bsig_fit_create_sized(const bsig_mdn_cfg* cfg, int64_t batch,
   const char* no_hoist = getenv("BSIG_NO_RFF_HOIST");
   p->hoist = cfg->rff_feats > 0 && n_updates > 0 && feats <= ((size_t)4 << 30) &&
              !(no_hoist && no_hoist[0] == '1');
-  const char* no_persist = getenv("BSIG_NO_PERSISTENT");
+  const char* no_persist_env = getenv("BSIG_NO_PERSISTENT");
+  const char* no_persist = (plan_flags & BSIG_PLAN_NO_PERSISTENT) ? "1" : no_persist_env;
   p->persistent = p->hoist && p->L.n_layers == 0 && cfg->head.full_cov == 0 &&
                   !(no_persist && no_persist[0] == '1') && persist_supported(persist_shape(p));
   if (p->persistent)
@@ -810,7 +823,9 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
                  "fit_bind: factor rows S=%d A=%d do not give the %d inputs of the first layer",
                  b->x_s, b->x_a, p->cfg.input_dim);
     BSIG_REQUIRE(b->ldx_train >= b->x_s + b->x_a + 3, "fit_bind: factor rows need a pitch >= S + A + 3");
-    BSIG_REQUIRE(b->n_test == 0 || b->ldx_test >= p->cfg.input_dim,
+    // (no held-out summary rows at all where the launch evaluates from the held-out FACTOR rows)
+    const bool eval_fac = b->x_test_factors && bsig_fit_evaluates_from_factors(p, b->x_s, b->x_a, flags);
+    BSIG_REQUIRE(b->n_test == 0 || (eval_fac && !b->x_test) || b->ldx_test >= p->cfg.input_dim,
                  "fit_bind: the held-out rows are summary rows (ldx_test >= input_dim)");
     if (!bsig_fit_accepts_factor_rows(p, b->x_s, b->x_a)) {
       set_error("fit_bind: this plan runs kernels that read materialised summary rows "
@@ -820,7 +835,10 @@ extern "C" int bsig_fit_bind(bsig_fit_plan* p, const bsig_fit_buffers* b, int fl
   }
   BSIG_REQUIRE((fac || b->ldx_train >= p->cfg.input_dim) && b->ldy_train >= p->cfg.head.out_dim,
                "fit_bind: leading dims too small");
-  BSIG_REQUIRE(!(b->n_test > 0 && !(b->x_test && b->y_test)), "fit_bind: null test buffers");
+  BSIG_REQUIRE(!(b->n_test > 0 && !b->y_test), "fit_bind: null test buffers");
+  BSIG_REQUIRE(!(b->n_test > 0 && !b->x_test &&
+                 !(fac && b->x_test_factors && bsig_fit_evaluates_from_factors(p, b->x_s, b->x_a, flags))),
+               "fit_bind: null test buffers");
   const bool graph = (flags & BSIG_FIT_GRAPH) != 0, split = (flags & BSIG_FIT_SPLIT_ADAM) != 0;
   const bool same = p->bound && std::memcmp(&p->buf, b, sizeof(*b)) == 0 &&
                     p->use_graph == graph && p->split_adam == split;
@@ -979,6 +997,19 @@ extern "C" int bsig_fit_accepts_factor_rows(const bsig_fit_plan* p, int s_dim, i
                  persist_mdnn_accepts_factors(persist_mdnn_shape(p), s_dim, a_dim) ? 1 : 0;
 }
 
+// Would a call bound with these factor rows and bind flags evaluate its held-out pairs from their
+// FACTOR rows inside the launch (a streamed first layer, single rank)?  Then nothing reads
+// materialised held-out summary rows and the caller need not build them (bsig_fit_buffers.x_test
+// may be null).
+extern "C" int bsig_fit_evaluates_from_factors(const bsig_fit_plan* p, int s_dim, int a_dim, int bind_flags) {
+  if (!p || !p->persistent_mdnn_cap || !p->mdnn_streams || p->n_updates < 1) return 0;
+  if (bind_flags & BSIG_FIT_SPLIT_ADAM) return 0;      // a data-parallel rank evaluates between its launches
+  const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
+  if (no_ike && no_ike[0] == '1') return 0;
+  return persist_mdnn_accepts_factors(persist_mdnn_shape(p), s_dim, a_dim) &&
+                 persist_mdnn_eval_supported(persist_mdnn_shape(p)) ? 1 : 0;
+}
+
 extern "C" int bsig_fit_is_persistent(const bsig_fit_plan* p) {
   if (!p) return 0;
   if (p->persistent) return 1;
@@ -1003,6 +1034,8 @@ extern "C" int bsig_fit_eval(bsig_fit_plan* p, bsig_stream_t stream) {
     return p->persistent ? enqueue_persistent(p, 0, as_stream(stream), total)
                          : enqueue_persistent_mdnn(p, 0, as_stream(stream), total);
   }
+  BSIG_REQUIRE(p->buf.n_test < 1 || p->buf.x_test,
+               "fit_eval: this binding has no held-out summary rows (its evaluations run inside bsig_fit_run)");
   BSIG_TRY(bsig_fit_flush(p, stream));
   if (p->use_graph) { BSIG_TRY(ensure_graphs(p)); BSIG_HIP(hipGraphLaunch(p->g_eval, as_stream(stream))); return BSIG_OK; }
   return enqueue_eval(p, as_stream(stream));

@@ -789,6 +789,40 @@ int mdnn_stream_launch(const MdnnArgs& p, bool dp, bool wide, bool full, int gri
       BSIG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsLimit));
     attr_set = true;
   }
+  // Every workgroup of the launch must be resident at once: the runtime's occupancy answer for THE
+  // instantiation that is launched, at the LDS size it is launched with (known only now: it depends
+  // on the factor dimensions), must admit a workgroup per CU.  Asked once per (device, variant, size).
+  {
+    struct Seen { int dev, variant; size_t lds; bool ok; };
+    static thread_local Seen seen[8];
+    static thread_local int n_seen = 0;
+    const int variant = (dp ? 1 : 0) | (wide ? 2 : 0) | (full ? 4 : 0);
+    bool known = false, ok = false;
+    for (int i = 0; i < n_seen; ++i)
+      if (seen[i].dev == dev && seen[i].variant == variant && seen[i].lds == lds) { known = true; ok = seen[i].ok; }
+    if (!known) {
+      int per_cu = 0;
+      hipError_t e = hipErrorUnknown;
+#define BSIG_O(a, b, c) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mdnn_stream_updates_kernel<a, b, c>, kMT, lds)
+      switch (variant) {
+        case 0: BSIG_O(false, false, false); break; case 1: BSIG_O(true, false, false); break;
+        case 2: BSIG_O(false, true, false); break;  case 3: BSIG_O(true, true, false); break;
+        case 4: BSIG_O(false, false, true); break;  case 5: BSIG_O(true, false, true); break;
+        case 6: BSIG_O(false, true, true); break;   default: BSIG_O(true, true, true); break;
+      }
+#undef BSIG_O
+      hipDeviceProp_t prop;
+      ok = e == hipSuccess && per_cu >= 1 && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+           (size_t)prop.maxSharedMemoryPerMultiProcessor >= lds && prop.multiProcessorCount >= grid;
+      seen[n_seen % 8] = Seen{dev, variant, lds, ok};
+      n_seen = std::min(n_seen + 1, 8);
+    }
+    if (!ok) {
+      set_error("mdnn_stream_updates: the device cannot hold the launch's %d workgroups (%zu bytes of LDS each) at once",
+                grid, lds);
+      return BSIG_EUNSUPPORTED;
+    }
+  }
 #define BSIG_L(a, b, c) hipLaunchKernelGGL((mdnn_stream_updates_kernel<a, b, c>), dim3(grid), dim3(kMT), lds, st, p)
   if (dp) {
     if (wide && full) BSIG_L(true, true, true); else if (wide) BSIG_L(true, true, false);

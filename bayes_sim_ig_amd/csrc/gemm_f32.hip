@@ -59,6 +59,47 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
   }
 }
 
+// Debug instantiation (BSIG_DEBUG_F64_ACC_MIN_K=<k>): a product whose contraction is at least <k>
+// long is formed by one thread per output element with the products and their sum in fp64, rounded
+// to fp32 once -- the value every fp32 summation order of the same operands approximates.  Same
+// operand addressing (gathers, k-major operands, device-resolved row offsets), same epilogues and
+// side outputs as the MFMA kernel; 100x slower.  SURVEY.md section 7 ("hard parts") asks for it to
+// extend the horizon of the ill-conditioned wide first layers (cfg/anymal.yaml: 56 402 terms per
+// output, cfg/shadow_hand_more.yaml: 105 002): with it the per-phase path's chunk stays with the
+// fp64 chunk where fp32 accumulation orders leave each other
+// (tests/test_gpu_fit.py::test_wide_chunk_with_fp64_first_layer_sums_stays_with_fp64).
+__global__ __launch_bounds__(256) void gemm_f64acc_kernel(GemmParams p) {
+  const int64_t total = (int64_t)p.m * p.n;
+  const int64_t dstep = p.dyn ? (int64_t)(p.dyn[0] + p.dyn_delta) : 0;
+  const int64_t a_off = dstep * p.a_dyn_stride + p.a_dyn_base, b_off = dstep * p.b_dyn_stride + p.b_dyn_base;
+  float exp_acc = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(e / p.n), col = (int)(e % p.n);
+    // k-contiguous operand: the gathered dimension is its row; k-major: its contraction index
+    const int64_t ar = p.a_kmajor ? 0 : (p.a_rows ? p.a_rows[row + a_off] : row + a_off);
+    const int64_t br = p.b_kmajor ? 0 : (p.b_rows ? p.b_rows[col + b_off] : col + b_off);
+    double acc = 0.0;
+    for (int kk = 0; kk < p.k; ++kk) {
+      const float av = p.a_kmajor ? p.a[(p.a_rows ? (int64_t)p.a_rows[kk + a_off] : kk + a_off) * p.lda + row]
+                                  : p.a[ar * p.lda + kk];
+      const float bv = p.b_kmajor ? p.b[(p.b_rows ? (int64_t)p.b_rows[kk + b_off] : kk + b_off) * p.ldb + col]
+                                  : p.b[br * p.ldb + kk];
+      acc += (double)av * (double)bv;
+    }
+    const float v = (float)acc;
+    epilogue_store(p, row, col, v);
+    if (p.expsum && p.epilogue == BSIG_EPI_BIAS && col >= p.expsum_col0 &&
+        col < p.expsum_col0 + p.expsum_ncols)
+      exp_acc += expf(v + p.bias[col]);
+  }
+  if (p.expsum) {
+    __shared__ float red[8];
+    const float s = block_sum(exp_acc, red);
+    if (threadIdx.x == 0) p.expsum[blockIdx.x] = s;
+  }
+}
+
 enum { TILE_64 = 0, TILE_128 = 1, TILE_128x32 = 2, TILE_128x64 = 3, TILE_128x96 = 4,
        TILE_96x128 = 5, TILE_128x288 = 6, TILE_288x128 = 7, N_TILES = 8 };
 static const int kTileM[N_TILES] = {64, 128, 128, 128, 128, 96, 128, 288};
@@ -197,6 +238,17 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
   if (n_expsum) *n_expsum = 0;
   BSIG_REQUIRE(!(p.expsum && e != BSIG_EPI_BIAS), "gemm: expsum needs the bias epilogue");
   if (p.m == 0 || p.n == 0) return BSIG_OK;
+  {
+    const char* f64_env = getenv("BSIG_DEBUG_F64_ACC_MIN_K");     // (read per call: tests switch it)
+    const int f64_min_k = f64_env ? atoi(f64_env) : 0;
+    if (f64_min_k > 0 && p.k >= f64_min_k) {
+      const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>((int64_t)p.m * p.n, 256), 2048);
+      hipLaunchKernelGGL(gemm_f64acc_kernel, dim3(blocks), dim3(256), 0, st, p);
+      BSIG_CHECK_LAUNCH("gemm_f64acc");
+      if (n_expsum && p.expsum) *n_expsum = blocks;
+      return BSIG_OK;
+    }
+  }
   const GemmPlan pl = plan_gemm(p.m, p.n, p.k, workspace ? workspace_bytes : 0);
   p.splits = pl.splits; p.k_chunk = pl.k_chunk;
   p.partial = reinterpret_cast<float*>(workspace);

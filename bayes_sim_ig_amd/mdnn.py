@@ -484,18 +484,11 @@ class MDNN(nn.Module):
             if self._plan:
                 lib.bsig_fit_destroy(self._plan)
             handle = C.c_void_p()
-            old_env = os.environ.get('BSIG_NO_PERSISTENT')
-            if getattr(self, '_no_persistent', False):
-                os.environ['BSIG_NO_PERSISTENT'] = '1'      # (read when the plan is created)
-            try:
-                _lib.check(lib.bsig_fit_create_sized(C.byref(cfg), batch_size, key[7], key[1],
-                                                     n_updates, C.byref(handle)))
-            finally:
-                if getattr(self, '_no_persistent', False):
-                    if old_env is None:
-                        os.environ.pop('BSIG_NO_PERSISTENT', None)
-                    else:
-                        os.environ['BSIG_NO_PERSISTENT'] = old_env
+            # (a model that met a persistent-launch time-out stays on the per-phase kernels: a plan
+            # option, not the process-wide environment switch)
+            flags = _lib.PLAN_NO_PERSISTENT if getattr(self, '_no_persistent', False) else 0
+            _lib.check(lib.bsig_fit_create_ex(C.byref(cfg), batch_size, key[7], key[1],
+                                              n_updates, flags, C.byref(handle)))
             self._plan, self._plan_key = handle, key
             self._bufs['cap_test'], self._bufs['cap_train'] = key[1], key[7]
         # a cross-correlation summary may arrive as factor rows (summarizers.CrossCorrFactors):
@@ -514,8 +507,13 @@ class MDNN(nn.Module):
             # bound where they lie: 1.3 KB per Ant row instead of a 47 KB summary row
             x_stage, _ = _lib.as_f32_rows(x_data.factors, dev)
             ldx = x_stage.stride(0) if n_tot > 1 else x_stage.shape[1]
-            # the held-out rows, read once per evaluation, as summary rows
-            x_held = x_data[n_train:].materialize() if n_test > 0 else None
+            # the held-out rows, read once per evaluation, as summary rows -- unless the launch
+            # evaluates from the held-out pairs' factor rows too (a streamed first layer): then no
+            # [n, I] block exists at all
+            bind_flags = (_lib.FIT_GRAPH if type(self).USE_GRAPH else 0) | \
+                (_lib.FIT_SPLIT_ADAM if self._dp is not None else 0)
+            eval_fac = bool(lib.bsig_fit_evaluates_from_factors(self._plan, x_data.s_dim, x_data.a_dim, bind_flags))
+            x_held = x_data[n_train:].materialize() if n_test > 0 and not eval_fac else None
             self._bufs['x_keepalive'] = (x_stage, x_held)
         else:
             # chunk staging: fixed addresses (graph replay) and 16-B aligned rows
@@ -586,7 +584,10 @@ class MDNN(nn.Module):
         fb.y_train, fb.ldy_train = y_stage.data_ptr(), ldy
         fb.x_test, fb.ldx_test, fb.n_test = x_stage.data_ptr() + 4 * n_train * ldx, ldx, n_test
         if factored and n_test > 0:
-            fb.x_test, fb.ldx_test = x_held.data_ptr(), x_held.stride(0)
+            if x_held is not None:
+                fb.x_test, fb.ldx_test = x_held.data_ptr(), x_held.stride(0)
+            else:
+                fb.x_test, fb.ldx_test = None, 0
         fb.y_test, fb.ldy_test = y_stage.data_ptr() + 4 * n_train * ldy, ldy
         fb.ids_table = ids_dev.data_ptr()
         fb.train_loss, fb.test_loss = train_loss.data_ptr(), test_loss.data_ptr()

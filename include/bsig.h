@@ -288,6 +288,13 @@ int bsig_fit_create(const bsig_mdn_cfg* cfg, int64_t batch, int64_t max_test_row
  * projecting inside every update. */
 int bsig_fit_create_sized(const bsig_mdn_cfg* cfg, int64_t batch, int64_t max_train_rows,
                           int64_t max_test_rows, int64_t n_updates, bsig_fit_plan** plan);
+/* The same with per-plan options.  BSIG_PLAN_NO_PERSISTENT: this plan's updates run on the per-phase
+ * kernels whatever its shape (a model that met a persistent-launch time-out on a shared GPU stays on
+ * them) -- an argument, not the process-wide BSIG_NO_PERSISTENT environment switch, which other
+ * threads' plans would see. */
+#define BSIG_PLAN_NO_PERSISTENT 1
+int bsig_fit_create_ex(const bsig_mdn_cfg* cfg, int64_t batch, int64_t max_train_rows,
+                       int64_t max_test_rows, int64_t n_updates, int plan_flags, bsig_fit_plan** plan);
 void bsig_fit_destroy(bsig_fit_plan* plan);
 size_t bsig_fit_workspace_bytes(const bsig_fit_plan* plan);
 /* Bind buffers (re-captures graphs only if something changed).  flags:
@@ -351,6 +358,11 @@ int bsig_fit_accepts_factor_rows(const bsig_fit_plan* plan, int s_dim, int a_dim
 /* 1: the plan's updates run in the persistent kernel for linear heads on cached
  * features (MDRFF), 2: in the one for the two-layer MDNN trunk (as bound), 0: as
  * per-phase kernels (diagnostics / tests). */
+/* 1 if a call bound with these factor rows (S, A) and bind flags evaluates its held-out pairs from
+ * their FACTOR rows inside the launch (streamed first layer, single rank): nothing then reads
+ * held-out summary rows -- bsig_fit_buffers.x_test may be NULL, and the caller need not expand the
+ * held-out fifth of the chunk (84 MB per 1000-pair chunk of cfg/shadow_hand_more.yaml). */
+int bsig_fit_evaluates_from_factors(const bsig_fit_plan* plan, int s_dim, int a_dim, int bind_flags);
 int bsig_fit_is_persistent(const bsig_fit_plan* plan);
 int bsig_fit_eval(bsig_fit_plan* plan, bsig_stream_t stream);
 

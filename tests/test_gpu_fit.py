@@ -3,6 +3,8 @@ reference-generated golden vectors (EPS_NOISE=0, same start weights, same
 minibatch id table), BayesSim end to end on the reference's own pendulum
 fixture, graph replay == direct launches, and size-independent properties at
 BASELINE sizes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -612,7 +614,7 @@ def _fp64_oracle(bench, cfg, in_dim, w0, freqs):
     return o
 
 
-def _bracket_chunk(B, name, seed, lazy, n_updates=100, must_factor=None, f32_threads=(8,)):
+def _bracket_chunk(B, name, seed, lazy, n_updates=100, must_factor=None, f32_threads=(8,), hip_env=None):
     """One teacher-forced chunk three ways: HIP, the fp32 oracle, the fp64 oracle (same start
     weights, same ids, EPS_NOISE = 0).  Returns the three log dicts and the GPU model (with
     several f32_threads: a list of fp32 oracle logs, one per thread count -- each thread count is
@@ -629,7 +631,13 @@ def _bracket_chunk(B, name, seed, lazy, n_updates=100, must_factor=None, f32_thr
     summ = bs._summarize(states, actions, lazy=lazy)
     if lazy:      # the factor rows must reach the kernel as factor rows (f2), not expanded
         assert isinstance(summ, B.summarizers.CrossCorrFactors)
-    hip = bs.model.run_training(summ, theta, n_updates, 100, ids_table=ids)
+    os.environ.update(hip_env or {})
+    try:
+        hip = bs.model.run_training(summ, theta, n_updates, 100, ids_table=ids)
+        torch.cuda.synchronize()
+    finally:
+        for k in (hip_env or {}):
+            os.environ.pop(k, None)
     if lazy if must_factor is None else must_factor:
         lib = B._lib.load()
         assert lib.bsig_fit_is_persistent(bs.model._plan) == 2
@@ -702,30 +710,145 @@ def _horizon(x, r, theta):
     return int(off[0]) if off.size else len(r)
 
 
-@pytest.mark.parametrize('name,seed', [('anymal_yaml', 3), ('anymal_yaml', 4), ('shadow_more', 4)])
-def test_wide_crosscorr_chunk_stays_with_fp64_as_long_as_the_reference_does(B, name, seed):
+def _reference_orders(bench, cfg, s_cpu, theta_cpu, w0, ids, n_updates, n_perms):
+    """The reference's fp32 arithmetic on one teacher-forced chunk in 1 + n_perms EVALUATION ORDERS: as
+    it is, and with the input columns (and the first layer's weight columns with them) permuted -- the
+    same network, the same fp32 operations, another grouping of the 56-105 k-term sums.  (8 threads
+    against 1 is NOT another order: same blocking, the logs agree to three digits.)  Returns the log
+    dicts and the end weights (first-layer columns back in the original order)."""
+    k1 = [k for k, v in w0.items() if v.dim() == 2 and v.shape[1] == s_cpu.shape[1]][0]
+    logs, weights = [], []
+    for i in range(1 + n_perms):
+        o = bench.build_oracle(cfg, s_cpu.shape[1], 77, 0.0)
+        w, x = dict(w0), s_cpu
+        perm = None
+        if i > 0:
+            perm = torch.from_numpy(np.random.RandomState(100 + i).permutation(s_cpu.shape[1]))
+            w[k1] = w0[k1][:, perm].contiguous()
+            x = s_cpu[:, perm].contiguous()
+        o.load_state_dict(w)
+        logs.append(o.run_training(x, theta_cpu, n_updates, 100, ids_table=ids))
+        sd = {k: v.double() for k, v in o.state_dict().items()}
+        if perm is not None:
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel())
+            sd[k1] = sd[k1][:, inv]
+        weights.append(sd)
+        del o
+    return logs, weights
+
+
+def _wide_chunk(B, name, seed, n_updates, n_perms, hip_env=None, lazy=True):
+    """HIP, the reference's fp32 arithmetic in 1 + n_perms evaluation orders, and the fp64 oracle on one
+    teacher-forced chunk (same start weights, same ids, EPS_NOISE = 0)."""
+    import bench
+    from oracle import summarize as osum
+    B.MDNN.EPS_NOISE = 0.0
+    cfg = dict(bench.CONFIGS[name])
+    torch.set_num_threads(8)
+    theta, states, actions = bench.synth_pairs(cfg, 1000, seed, DEV)
+    ids = np.random.RandomState(5).randint(0, 800, (100, 100))[:n_updates]
+    bs = bench.build_gpu_model(B, cfg, DEV, 77)
+    w0 = {k: v.cpu().clone() for k, v in bs.model.state_dict().items()}
+    summ = bs._summarize(states, actions, lazy=lazy)
+    os.environ.update(hip_env or {})
+    try:
+        hip = bs.model.run_training(summ, theta, n_updates, 100, ids_table=ids)
+        torch.cuda.synchronize()
+    finally:
+        for k in (hip_env or {}):
+            os.environ.pop(k, None)
+    persistent = int(B._lib.load().bsig_fit_is_persistent(bs.model._plan))
+    w_hip = {k: v.cpu().double() for k, v in bs.model.state_dict().items()}
+    s_cpu = osum.SUMMARIZERS[cfg['summarizer']](states.cpu(), actions.cpu())
+    f32_logs, f32_w = _reference_orders(bench, cfg, s_cpu, theta.cpu(), w0, ids, n_updates, n_perms)
+    o64 = _fp64_oracle(bench, cfg, s_cpu.shape[1], w0, None)
+    f64 = o64.run_training(s_cpu.double(), theta.cpu().double(), n_updates, 100, ids_table=ids)
+    w64 = {k: v.clone() for k, v in o64.state_dict().items()}
+    del bs, o64
+    return hip, f32_logs, f64, w_hip, f32_w, w64, persistent
+
+
+def _assert_envelope(hip, f32_logs, f64, factor=3.0):
+    """At every logging point:  |hip - f64| <= factor * max over the reference's fp32 evaluation orders
+    of |cpu_f32 - f64|  +  1e-4 |f64|.  (factor: the orders are a sample of four, not the bound.)"""
+    for key in ('test_loss', 'train_loss'):
+        r = np.asarray(f64[key], dtype=np.float64)
+        h = np.abs(np.asarray(hip[key], dtype=np.float64) - r)
+        env = np.max([np.abs(np.asarray(f[key], dtype=np.float64) - r) for f in f32_logs], axis=0)
+        print('  %-10s |hip-f64|/|f64| %s\n  %-10s max over the reference orders %s' %
+              (key, h / np.abs(r), '', env / np.abs(r)))
+        assert (h <= factor * env + 1e-4 * np.abs(r) + 1e-6).all(), (key, h / np.abs(r), env / np.abs(r))
+
+
+@pytest.mark.parametrize('name,seed', [('anymal_yaml', 3), ('shadow_more', 4)])
+def test_wide_crosscorr_chunk_stays_inside_the_reference_fp32_envelope(B, name, seed):
     """cfg/anymal.yaml (I = 56402) and cfg/shadow_hand_more.yaml (I = 105002) as shipped, 100
-    teacher-forced updates through the path BayesSim.fit takes (factor rows into the streamed
-    first layer).  These chunks are ill-conditioned in fp32: most of the 56-105 k inputs are
-    near-zero products whose first-layer gradients are rounding noise, Adam turns a noise-level
-    gradient into a full-size step, and ANY two fp32 evaluation orders of the same chunk --
-    the reference's own CPU path run with 8 threads and with 1 -- leave the fp64 trajectory
-    after 40-80 updates, by amounts that differ tenfold from order to order at the same
-    logging point (tools/parity_inputs_probe.py, tools/parity_weights_probe.py: after 1 and 5
-    updates the HIP weights are as close to the fp64 ones as the fp32 oracle's).  A pointwise
-    tolerance against one fp32 run is therefore a coin toss; what is asserted is the HORIZON:
-    the HIP path stays within 1e-3 of the fp64 chunk at least as long as the reference's fp32
-    path does (the earlier of two thread counts), to one logging interval of 20 updates -- and
-    every loss of the first 20 updates within the north-star 1e-4 of the fp32 oracle
+    teacher-forced updates through the path BayesSim.fit takes (factor rows into the streamed first
+    layer).  These chunks are ill-conditioned in fp32: most of the 56-105 k inputs are near-zero
+    products whose first-layer gradients are sums with heavy cancellation, Adam turns a noise-level
+    gradient into a full-size step, and the deviation from the fp64 chunk grows 20- to 100-fold per 20
+    updates -- for the reference's OWN fp32 arithmetic: with the input columns permuted (another
+    grouping of the same fp32 sums) its held-out NLL is 5e-5 .. 1e-3 from the fp64 chunk after 40 and
+    60 updates where the unpermuted run happens to sit at 2e-6 and 3e-4 (tools/parity_wide_diag.py;
+    8 threads against 1 is no second order, the logs agree to three digits).  What is asserted:
+      * the ENVELOPE -- at every logging point HIP is no further from the fp64 chunk than three times
+        the furthest of four reference evaluation orders (+ the north-star 1e-4);
+      * the HORIZON -- HIP stays within 1e-3 of the fp64 chunk at least as long as the earliest of
+        those orders (no slack), and never leaves before update 40;
+    and, with 20 updates, every loss within 1e-4 of the fp32 oracle
     (test_wide_crosscorr_chunk_20_updates_matches_oracle)."""
-    hip, f32s, f64, _ = _bracket_chunk(B, name, seed, lazy=True, must_factor=True, f32_threads=(8, 1))
+    hip, f32_logs, f64, _, _, _, persistent = _wide_chunk(B, name, seed, 100, n_perms=3)
+    assert persistent == 2
+    _assert_envelope(hip, f32_logs, f64)
     for key in ('test_loss', 'train_loss'):
         t_hip = _horizon(hip[key], f64[key], 1e-3)
-        t_ref = min(_horizon(f[key], f64[key], 1e-3) for f in f32s)
-        print('%s seed %d %s: horizon hip %d, fp32 oracle %d; hip - f64 %s' %
-              (name, seed, key, t_hip, t_ref, np.asarray(hip[key]) - np.asarray(f64[key])))
-        assert t_hip >= t_ref - 1, (key, t_hip, t_ref, hip[key], [f[key] for f in f32s], f64[key])
+        t_f32 = [_horizon(f[key], f64[key], 1e-3) for f in f32_logs]
+        print('%s seed %d %s: horizon hip %d, reference orders %s' % (name, seed, key, t_hip, t_f32))
+        assert t_hip >= min(t_f32), (key, t_hip, t_f32)
         assert t_hip >= 2, (key, hip[key], f64[key])       # never before update 40
+
+
+@pytest.mark.parametrize('name,seed', [('anymal_yaml', 4), ('shadow_more', 4)])
+def test_wide_chunk_weights_as_close_to_fp64_as_the_reference_orders(B, name, seed):
+    """The other half of the argument, as an assertion (it used to live in
+    tools/parity_weights_probe.py): BEFORE the fp32 paths part, the HIP weights are as close to the
+    fp64 chunk's as the reference's fp32 weights are -- per parameter tensor,
+        mean|W_hip - W_f64| <= c * max over three reference evaluation orders of mean|W_cpu32 - W_f64|
+    with c = 2 after 1 and 5 updates and c = 4 after 20 (the chunk's amplification has set in: the
+    orders themselves differ four-fold there); + 1e-9 for tensors every path gets right to the last
+    bit.  Measured: after 1 update every ratio is 0.7-1.2; after 5, 0.6-1.3 (shadow_hand_more) and
+    1.1-1.9 (anymal); after 20, 1.1 and 3.2 at worst."""
+    for n_up, c in ((1, 2.0), (5, 2.0), (20, 4.0)):
+        _, _, _, w_hip, f32_w, w64, persistent = _wide_chunk(B, name, seed, n_up, n_perms=2)
+        assert persistent == 2
+        for k in w_hip:
+            dh = float((w_hip[k] - w64[k]).abs().mean())
+            dcs = [float((w[k] - w64[k]).abs().mean()) for w in f32_w]
+            print('%s seed %d, %2d updates, %-16s mean|hip-f64| %.3e  reference orders %s' %
+                  (name, seed, n_up, k, dh, ' '.join('%.3e' % d for d in dcs)))
+            assert dh <= c * max(dcs) + 1e-9, (name, seed, n_up, k, dh, dcs)
+
+
+@pytest.mark.parametrize('name,seed', [('anymal_yaml', 3)])
+def test_wide_chunk_with_fp64_sums_is_no_closer_to_fp64(B, name, seed):
+    """SURVEY.md section 7 ("hard parts") asks for an instantiation of the wide first-layer products
+    that accumulates in fp64, to extend the horizon.  Built (BSIG_DEBUG_F64_ACC_MIN_K=64: every product
+    of the per-phase path with a contraction of 64 terms or more -- the 56 402-term forward sums, the
+    100-term dW sums -- has its products and its sum in fp64, rounded to fp32 once:
+    csrc/gemm_f32.hip gemm_f64acc_kernel) and MEASURED: the chunk leaves the fp64 trajectory exactly as
+    the fp32 paths do (held-out NLL 7e-5 / 9e-4 off after 40 / 60 updates against 4e-5 / 8e-4 with fp32
+    sums).  The summation ORDER is therefore not what the chunk amplifies: the cancelling sums amplify
+    the rounding of their fp32 INPUTS (the back-propagated dz1, the activations), which only a run with
+    everything in fp64 -- the oracle's -- removes.  Asserted: that run is one more member of the
+    reference's fp32 envelope (and the debug path computes the same chunk: first logging points at
+    1e-4)."""
+    env = {'BSIG_NO_PERSISTENT': '1', 'BSIG_DEBUG_F64_ACC_MIN_K': '64'}
+    hip, f32_logs, f64, _, _, _, persistent = _wide_chunk(B, name, seed, 100, n_perms=3, hip_env=env, lazy=False)
+    assert persistent == 0
+    _assert_envelope(hip, f32_logs, f64)
+    for key in ('test_loss', 'train_loss'):
+        np.testing.assert_allclose(hip[key][:2], f64[key][:2], rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize('name', ['anymal_yaml', 'shadow_more'])
