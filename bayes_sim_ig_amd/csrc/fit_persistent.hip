@@ -164,7 +164,7 @@ __device__ __forceinline__ void u_rows_sum4(const float* slabs, RowOff&& rowoff,
                                             int n_cols, int ld, float* out, int out_pitch, float* part, int tid,
                                             F&& fn) {
   const __amdgpu_buffer_rsrc_t sr = xwg_buffer(slabs);
-  const int ncq = ld >> 2, Q = nrows * ncq;
+  const int ncq = (n_cols + 3) >> 2, Q = nrows * ncq;      // (only the quads that hold head outputs: 260 of 288 columns)
   const int SG = max(1, min(min(k_slices, kUT / Q), 8));
   const int qc = tid % Q, sg = tid / Q;
   if (sg < SG) {

@@ -1347,7 +1347,9 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       w2f[4 * tt + 0] = lo.x; w2f[4 * tt + 1] = lo.y; w2f[4 * tt + 2] = hi.x; w2f[4 * tt + 3] = hi.y; \
     }
     if (w == 0) {
-      flag_wait_one(p.o_flags, p.G1 - 1, epoch, flagp);
+      // (no quiet wait here: the other wavefronts are pulling the head matrix through this CU's
+      // memory pipe, a sentinel poll would queue behind it and cost a second round trip -- measured:
+      // flags seen 2.8 us after the last one went up instead of 0.9)
       flags_wait(p.o_flags, p.G1, epoch, lane, flagp);
       BSIG_LOAD_W2F()
     } else {

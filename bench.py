@@ -274,11 +274,36 @@ def largest_size_leg(pkg, cfg, device, n=1_000_000):
     return out
 
 
+def _profile_head(path):
+    """The commit a committed profile was taken on: its '# head: <sha>' line (tools/round_profiles.sh)."""
+    for line in open(path):
+        if line.startswith('# head:'):
+            return line.split(':', 1)[1].strip().split()[0]
+        if not line.startswith('#'):
+            break
+    return None
+
+
+def _is_ancestor(sha):
+    """Is `sha` an ancestor of HEAD?  None where that cannot be asked (no git, no history: the GPU
+    boxes receive a snapshot of the tree without .git)."""
+    import subprocess
+    try:
+        if subprocess.run(['git', '-C', ROOT, 'rev-parse', '--git-dir'], capture_output=True).returncode != 0:
+            return None
+        return subprocess.run(['git', '-C', ROOT, 'merge-base', '--is-ancestor', sha, 'HEAD'],
+                              capture_output=True).returncode == 0
+    except OSError:
+        return None
+
+
 def pmc_traffic(kernel_substr):
     """Per-launch HBM traffic of a kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_FETCH_SIZE.txt / *_pmc_WRITE_SIZE.txt, latest round):
-    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950."""
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.  A profile carries the
+    commit it was taken on; one whose commit is not an ancestor of HEAD (a profile of other code)
+    is refused, one that cannot be checked (no git history on the box) is named as unverified."""
     import glob
     out = {}
     for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -289,13 +314,24 @@ def pmc_traffic(kernel_substr):
                 if kernel_substr in line and ctr in line:
                     out[ctr] = float(line.split(ctr)[1].split()[1])
                     out['src_' + ctr] = os.path.basename(path)
+                    out['head_' + ctr] = _profile_head(path)
                     break
             if ctr in out:
                 break
         else:
             return None, None
+    heads = {out['head_FETCH_SIZE'], out['head_WRITE_SIZE']}
+    note = ''
+    for h in heads:
+        if h is None:
+            note = ' (no commit stamp: a profile of an earlier round)'
+            continue
+        ok = _is_ancestor(h)
+        if ok is False:
+            return None, 'refused: %s was taken on %s, not an ancestor of HEAD' % (out['src_FETCH_SIZE'], h)
+        note = ' (taken on %s%s)' % (h, '' if ok else ', ancestry not checkable here')
     return (2.0 * out['FETCH_SIZE'] + out['WRITE_SIZE']) * 1024.0, \
-        '%s, %s' % (out['src_FETCH_SIZE'], out['src_WRITE_SIZE'])
+        '%s, %s%s' % (out['src_FETCH_SIZE'], out['src_WRITE_SIZE'], note)
 
 
 def _event_time(fn, reps, warm=5):
@@ -413,7 +449,13 @@ def time_update_kernel(pkg, cfg, bsim, device):
         flops += 2.0 * f_in * nh * n_test * n_evals   # forward products of the evaluations
     ach = flops / (us * 1e-6) / 1e12
     traffic, tsrc = pmc_traffic('linear_head_updates_kernel') if not dp else (None, None)
-    return {'bound': 'mfma',
+    geo = (C.c_int32 * 16)()
+    tiling = None
+    if lib.bsig_debug_persist_geometry(batch, f_in, cfg['d'], cfg['k'], n_test, geo):
+        tiling = {'tile_rows': 16 * geo[0], 'k_slice': geo[1], 'head_blocks': geo[2], 'k_slices': geo[3],
+                  'tile_workgroups': geo[4], 'workgroups': geo[5], 'row_owners': geo[6], 'rows_per_owner': geo[7],
+                  'owners_that_hold_a_tile': geo[12], 'lds_bytes': geo[11]}
+    return {'bound': 'mfma', 'tiling': tiling,
             'kernel': 'linear_head_updates_kernel: persistent update kernel, heads %dx%d on cached '
                       'RFF features, minibatch %d, %s per launch: forward '
                       'product, NLL fwd/bwd, dW, Adam%s'
@@ -432,8 +474,10 @@ def time_update_kernel(pkg, cfg, bsim, device):
                                            '' if dp else ' + 2*F*Nh x %d rows x %d evaluations'
                                            % (n_test, n_evals), flops),
             'note': 'latency-bound by design of the reference protocol (minibatch 100): each update '
-                    'is a chain of 4 cross-workgroup hand-offs (~1.5-3 us each) around ~6 us of '
-                    'fp32-MFMA work per CU; see DESIGN.md and scaled_batch_mode for the MFMA-bound regime'}
+                    'is a chain of 4 cross-workgroup hand-offs (~1 us each) and the row owners\' work '
+                    '(k-slice sums + one wavefront per row: ~7 us) around ~7 us of fp32-MFMA work per '
+                    'tile CU (16x16x4, head matrix tiled over 198 CUs); see DESIGN.md and '
+                    'scaled_batch_mode for the MFMA-bound regime'}
 
 
 def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp=False, n_evals=0, n_test=0):

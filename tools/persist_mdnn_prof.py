@@ -66,9 +66,15 @@ for u in range(2, 7):
     t0 = min(st[g, u, 0] for g in tiles)
     per.append(min(st[g, u + 1, 0] for g in tiles) - t0)
     for label, grp, k, fn in rows:
-        acc[label].append(fn([st[g, u, k] for g in grp]) - t0)
+        vals = [st[g, u, k] for g in grp]
+        # (a stamp this instantiation never writes -- the factor-row prefetch of a plan on summary rows --
+        # stays 0: not a time)
+        acc[label].append(fn(vals) - t0 if vals and min(vals) > 0 else float('nan'))
 print('update period %.2f us' % np.mean(per) + ('   per update: ' + ' '.join('%.2f' % x for x in per) if os.environ.get('PER_UPDATE') == '1' else ''))
 for label, _, _, _ in rows:
+    if np.isnan(acc[label]).any():
+        print('    %-68s    n/a' % label)
+        continue
     print('    %-68s %6.2f' % (label, np.mean(acc[label])) + ('   [' + ' '.join('%.2f' % x for x in acc[label]) + ']' if os.environ.get('PER_UPDATE') == '1' else ''))
 if os.environ.get('DETAIL') == '1':
     u = 4
