@@ -217,3 +217,49 @@ def test_narrow_two_layer_trunk_is_stored_zero_padded():
     assert MDNN(hidden_layers=(24, 24, 24), **kw)._hidden_stored == [24, 24, 24]
     assert MDNN(hidden_layers=(24, 24), **dict(kw, activation=torch.nn.ReLU))._hidden_stored == [24, 24]
     assert MDNN(hidden_layers=(256, 64), **kw)._hidden_stored == [256, 64]
+
+
+def test_linear_head_tiling_planner():
+    """The tiling of the persistent kernel of the linear heads (csrc/fit_persistent.hip, host
+    arithmetic: bsig_debug_persist_geometry): the ShadowHand head gets 32 x 192 tiles on 198 CUs and
+    two rows per owner on 50 of the CUs to spare; every covered shape respects the chip (<= 256
+    workgroups, <= 160 KB of LDS each), owns every minibatch row and every held-out row."""
+    import ctypes as C
+    import numpy as np
+    lib = _lib.load()
+    names = ['NT', 'KS', 'n_blocks', 'k_slices', 'G', 'T', 'n_owner', 'R', 'NE', 'RE', 'eval_passes', 'lds', 'mixed']
+
+    def geom(batch, feat, d, k, max_test):
+        out = (C.c_int32 * 16)()
+        ok = lib.bsig_debug_persist_geometry(batch, feat, d, k, max_test, out)
+        return ok, dict(zip(names, list(out)[:13]))
+
+    ok, g = geom(100, 4096, 32, 4, 200)          # cfg5: 260 x 4096 heads
+    assert ok and (g['NT'], g['KS'], g['n_blocks'], g['k_slices']) == (2, 192, 9, 22)
+    assert (g['G'], g['T'], g['n_owner'], g['R'], g['mixed']) == (198, 248, 50, 2, 0)
+    ok, g = geom(100, 1024, 13, 10, 200)         # cfg2: 270 x 1024
+    assert ok and g['NT'] == 1 and g['KS'] == 96 and g['mixed'] == 0
+    rng = np.random.RandomState(0)
+    n_ok = 0
+    for _ in range(300):
+        batch, k = int(rng.randint(1, 113)), int(rng.randint(1, 17))
+        d = int(rng.randint(1, min(40, 8 * (64 // k)) + 1))
+        feat = int(rng.choice([96, 200, 300, 500, 512, 1024, 2048, 4096, 8192]))
+        max_test = int(rng.randint(0, 400))
+        ok, g = geom(batch, feat, d, k, max_test)
+        if not ok:
+            continue
+        n_ok += 1
+        nh = k * (1 + 2 * d)
+        assert g['KS'] in (96, 192, 288) and g['NT'] in (1, 2)
+        assert g['n_blocks'] * 16 * g['NT'] >= nh and g['k_slices'] * g['KS'] >= feat
+        assert g['G'] == g['n_blocks'] * g['k_slices'] <= 256 and g['G'] <= g['T'] <= 256
+        assert g['n_owner'] * g['R'] >= batch and 1 <= g['R'] <= 8 and g['n_owner'] <= g['T']
+        assert g['lds'] <= 160 * 1024
+        if g['eval_passes'] > 0:
+            assert g['NE'] * g['RE'] >= max_test and g['RE'] <= 8 and g['NE'] <= g['T']
+            assert g['eval_passes'] * batch >= max_test
+        # owners on workgroups of their own unless the chip has none to spare
+        assert g['mixed'] == max(0, g['n_owner'] - (g['T'] - g['G']))
+    assert n_ok > 200
+    assert geom(200, 4096, 32, 4, 0)[0] == 0        # minibatches beyond 112 rows: the v1 kernel / per-phase kernels
