@@ -128,11 +128,13 @@ class BayesSim(object):
         pre-recorded pairs: consecutive chunks of at most
         NUM_TRAIN_TRAJ_PER_BATCH pairs, ``run_training`` on each.
         Returns the list of per-chunk log dicts."""
-        dp = getattr(self.model, '_dp', None)
-        if dp is None and self.model._flat.is_cuda and self.model._may_time_out():
+        if self.model._flat.is_cuda and self.model._may_time_out():
             # the chunks' logs are read after the last chunk is enqueued: if a persistent launch
             # turns out not to have had the GPU to itself (its bounded polls gave up), the whole
-            # loop is repeated from here on the per-phase kernels
+            # loop is repeated from here on the per-phase kernels.  A data-parallel group does the
+            # same TOGETHER: the time-out bit travels in the logs every call sums over the ranks
+            # (bsig_fit_run_dp), the rank that timed out keeps enqueueing its all-reduces, so every
+            # rank reads the same flag at the same chunk, restores and repeats
             from .mdnn import PersistentTimeout
             snap = self.model._snapshot()
             try:

@@ -442,7 +442,7 @@ class MDNN(nn.Module):
         'test_loss': [...]} with the same 6 logging points.  ``ids_table``
         [n_updates, batch] (optional) overrides the numpy-RNG minibatch draw
         (teacher forcing for parity tests)."""
-        if _defer or self._dp is not None or not self._flat.is_cuda:
+        if _defer or not self._flat.is_cuda:
             # (deferred logs: the caller -- BayesSim.fit -- holds the snapshot and repeats its loop)
             return self._run_training_once(x_data, y_data, n_updates, batch_size, test_frac,
                                            ids_table, _defer, _feats)
@@ -451,6 +451,8 @@ class MDNN(nn.Module):
             return self._run_training_once(x_data, y_data, n_updates, batch_size, test_frac,
                                            ids_table, False, _feats)
         except PersistentTimeout:
+            # (a data-parallel rank: the flag is the SUM over the ranks of the call's logs -- every
+            # rank of the group arrives here in the same call and repeats it with its peers)
             if snap is None:
                 raise
             self._restore(snap)

@@ -274,3 +274,47 @@ def test_time_out_is_recovered_on_the_phase_kernels(B):
     ok = bench.build_gpu_model(B, cfg, DEV, 77)
     ok.fit(theta, states, actions)
     assert lib.bsig_fit_is_persistent(ok.model._plan) == 1 and not getattr(ok.model, '_no_persistent', False)
+
+
+def test_time_out_of_a_data_parallel_rank_is_recovered_by_the_group(B):
+    """The same with a data-parallel rank (one launch per update, RCCL exchange, here a 1-rank group): the
+    time-out bit travels in the logs bsig_fit_run_dp sums over the ranks, so EVERY rank of a group reads it
+    at the same chunk -- the rank that timed out has kept enqueueing its all-reduces meanwhile, nobody
+    hangs --, restores its snapshot and repeats the loop on the per-phase kernels with its peers: bit for
+    bit the per-phase data-parallel fit."""
+    import ctypes as C
+    import bench
+    import torch.distributed as dist
+    cfg = dict(task='synthetic', model='MDRFF', summarizer='summary_start', t=11, sd=5, ad=2,
+               d=3, k=4, hidden=[], n_feat=512, pairs=2000)
+    theta, states, actions = bench.synth_pairs(cfg, 2000, 3, DEV)
+    lib = B._lib.load()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29579')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        os.environ['BSIG_NO_PERSISTENT'] = '1'
+        try:
+            ref = bench.build_gpu_model(B, cfg, DEV, 77)
+            ref.model.enable_data_parallel()
+            np.random.seed(11); torch.manual_seed(11)
+            ref_logs = ref.fit(theta, states, actions)
+        finally:
+            os.environ.pop('BSIG_NO_PERSISTENT', None)
+        bs = bench.build_gpu_model(B, cfg, DEV, 77)
+        bs.model.enable_data_parallel()
+        np.random.seed(11); torch.manual_seed(11)
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        B._lib.check(lib.bsig_debug_spin(200, 160 * 1024, 1500, C.c_void_p(side.cuda_stream)))
+        logs = bs.fit(theta, states, actions)
+        torch.cuda.synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert getattr(bs.model, '_no_persistent', False), 'the launches were expected to time out'
+    assert lib.bsig_fit_is_persistent(bs.model._plan) == 0
+    assert [lg['test_loss'] for lg in logs] == [lg['test_loss'] for lg in ref_logs]
+    assert torch.equal(bs.model._flat, ref.model._flat)
