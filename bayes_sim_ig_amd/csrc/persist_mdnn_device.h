@@ -241,12 +241,22 @@ __device__ __forceinline__ void mdnn_tile_eval(const MdnnArgs& p, const float* W
     __syncthreads();
     if (kh == 0) {
       const float bias = ks == 0 ? biasl[l31] : 0.f;
-      float* dst = fresh_ptr(p.eval_slabs + ((((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B + mt * 32 + 4 * h) * kMH + n0 + l31);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = mt * 32 + acc_row(i, h);
-        const float v = acc[i] + X[row * kMPbuf + l31] + bias;
-        if (row < rows) xwg_store(dst + acc_row0(i) * kMH, v);
+        float* x = X + (mt * 32 + acc_row(i, h)) * kMPbuf + l31;
+        *x = acc[i] + *x + bias;
+      }
+    }
+    __syncthreads();
+    {   // (rows of 16-byte quads, as the update's slab)
+      const __amdgpu_buffer_rsrc_t sr = xwg_buffer(p.eval_slabs + (((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B * kMH + n0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = u * kMT + tid, b = idx >> 3, c4 = (idx & 7) * 4;
+        if (b < rows) {
+          const float* x = X + b * kMPbuf + c4;
+          xwg_store4(sr, b * kMH + c4, x[0], x[1], x[2], x[3]);
+        }
       }
     }
   }
@@ -428,14 +438,29 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
       if (bias_pending && w == kMT / 64 - 1 && lane < kMNB) bias_step(lane);
       bias_pending = false;
       __syncthreads();
+      // The two k-halves meet in X (same operation order as ever: (first half + second half) + bias),
+      // and the block goes out as rows of 16-byte quads, one or two per thread: an accumulator lane
+      // holds four ROWS of one column -- stored from there the slab was 16 dword stores per lane, and a
+      // cross-workgroup payload costs by the number of memory transactions, not by its bytes
+      // (tools/micro/handoff_bench.hip; flag up 3.1 us after the last MFMA, the linear heads' kernel: 0.8).
       if (kh == 0) {
         const float bias = ks == 0 ? biasl[l31_l] : 0.f;
-        float* dst = fresh_ptr(p.slabs + ((int64_t)ks * B + mt * 32 + 4 * h_l) * kMH + n0 + l31_l);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int row = mt * 32 + acc_row(i, h_l);
-          const float v = acc[i] + X[row * kMPbuf + l31_l] + bias;
-          if (row < B) xwg_store(dst + acc_row0(i) * kMH, v);
+          float* x = X + (mt * 32 + acc_row(i, h_l)) * kMPbuf + l31_l;
+          *x = acc[i] + *x + bias;
+        }
+      }
+      __syncthreads();
+      {
+        const __amdgpu_buffer_rsrc_t sr = xwg_buffer(p.slabs + (int64_t)ks * B * kMH + n0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int idx = u * kMT + tid_l, b = idx >> 3, c4 = (idx & 7) * 4;
+          if (b < B) {
+            const float* x = X + b * kMPbuf + c4;
+            xwg_store4(sr, b * kMH + c4, x[0], x[1], x[2], x[3]);
+          }
         }
       }
       __builtin_amdgcn_s_waitcnt(0);
