@@ -38,7 +38,8 @@ namespace bsig {
 // DP: data-parallel rank (gradients out, pending Adam step in; see MdnnArgs)
 // FAC: the summary rows arrive as cross-correlation factor rows
 // WIDE: heads wider than the owners' LDS: head outputs formed by the head-block workgroups
-template <bool DP, bool FAC, bool WIDE, bool FULL>
+// MR: minibatch rows per owner workgroup
+template <bool DP, bool FAC, bool WIDE, bool FULL, int MR = kMR>
 __global__ __launch_bounds__(kMT) void mdnn_updates_kernel(MdnnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // (BSIG_HOST_SAN_BUILD: tools/build_host_san.sh checks the HOST side under the sanitizers and
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(kMT) void mdnn_updates_kernel(MdnnArgs p) {
 #ifndef BSIG_HOST_SAN_BUILD
   const int wg = blockIdx.x;
   if (wg < p.G1) mdnn_tile_workgroup<DP, FAC>(p, smem);
-  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP, WIDE, FULL>(p, smem);
+  else if (wg < p.G1 + p.n_owner) mdnn_owner_workgroup<DP, WIDE, FULL, MR>(p, smem);
   else mdnn_small_workgroup<DP, WIDE>(p, smem);
 #endif
 }
@@ -78,9 +79,17 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   g->NhP = (int)round_up(g->Nh, kMNB);
   g->k_slices = ceil_div(s.input_dim, kMC);
   g->G1 = (kMH / kMNB) * g->k_slices;
-  g->mr = kMR;
-  g->n_owner = ceil_div(s.batch, kMR);
   g->n_small = kMH / kMNB + g->NhP / kMNB;
+  // Rows per owner: an owner pulls its rows of every k-slice's slab through ONE CU's vector-memory
+  // pipe (~40 GB/s of cache-bypassing loads: 47 slices x 4 rows x 512 B = 96 KB = 2.4 us for the Ant
+  // summaries) -- two rows each where the chip has the CUs for twice the owners (diagonal covariance;
+  // same sums in the same order: slab_quads_sum).  BSIG_MDNN_MR=4: A/B runs, tests.
+  g->mr = kMR;
+  {
+    static const int force_mr = [] { const char* e = getenv("BSIG_MDNN_MR"); return e ? atoi(e) : 0; }();
+    if (!s.full_cov && force_mr != 4 && g->k_slices > 1 && g->G1 + ceil_div(s.batch, 2) + g->n_small <= kXwgMax) g->mr = 2;
+  }
+  g->n_owner = ceil_div(s.batch, g->mr);
   g->stream = 0; g->s_chunks = 0;
   const char* no_stream = getenv("BSIG_NO_STREAMED_W1");
   if (g->G1 > kXwgMax || g->G1 + g->n_owner + g->n_small > kXwgMax) {
@@ -340,14 +349,16 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   }
   p.prof = reinterpret_cast<long long*>(persist_profile_buffer());
   const dim3 grid(g.G1 + g.n_owner + g.n_small);
-#define BSIG_MDNN_LAUNCH(DP_, FAC_, WIDE_, FULL_) \
-  hipLaunchKernelGGL((mdnn_updates_kernel<DP_, FAC_, WIDE_, FULL_>), grid, dim3(kMT), g.lds, st, p)
+#define BSIG_MDNN_LAUNCH(DP_, FAC_, WIDE_, FULL_, MR_) \
+  hipLaunchKernelGGL((mdnn_updates_kernel<DP_, FAC_, WIDE_, FULL_, MR_>), grid, dim3(kMT), g.lds, st, p)
 #define BSIG_MDNN_LAUNCH_WF(DP_, FAC_)                                      \
   do {                                                                       \
-    if (g.wide && full) BSIG_MDNN_LAUNCH(DP_, FAC_, true, true);             \
-    else if (g.wide) BSIG_MDNN_LAUNCH(DP_, FAC_, true, false);               \
-    else if (full) BSIG_MDNN_LAUNCH(DP_, FAC_, false, true);                 \
-    else BSIG_MDNN_LAUNCH(DP_, FAC_, false, false);                          \
+    if (g.wide && full) BSIG_MDNN_LAUNCH(DP_, FAC_, true, true, kMR);        \
+    else if (g.wide && g.mr == 2) BSIG_MDNN_LAUNCH(DP_, FAC_, true, false, 2);   \
+    else if (g.wide) BSIG_MDNN_LAUNCH(DP_, FAC_, true, false, kMR);          \
+    else if (full) BSIG_MDNN_LAUNCH(DP_, FAC_, false, true, kMR);            \
+    else if (g.mr == 2) BSIG_MDNN_LAUNCH(DP_, FAC_, false, false, 2);        \
+    else BSIG_MDNN_LAUNCH(DP_, FAC_, false, false, kMR);                     \
   } while (0)
   const bool dp = b.grads != nullptr, full = s.full_cov != 0;
   if (g.stream) return mdnn_stream_launch(p, dp, g.wide != 0, full, (int)grid.x, std::max(g.lds, s_lds), st);

@@ -21,7 +21,7 @@ constexpr int kMPitch = kMC + 4;    // LDS row pitch of the summary / weight til
 constexpr int kMNB = 32;            // weight rows per tile / small-weight workgroup
 constexpr int kMH = 128;            // hidden width (both layers)
 constexpr int kMHP = kMH + 4;       // LDS pitch of a 128-wide activation row
-constexpr int kMR = 4;              // minibatch rows per owner workgroup (power of two <= 8)
+constexpr int kMR = 4;              // minibatch rows per owner workgroup (power of two <= 8; 2 where the chip has the CUs)
 constexpr int kStreamMR = 8;        // ... of a plan with a streamed first layer
 constexpr int kMPbuf = 33;
 constexpr int kMLdsLimit = 160 * 1024;
@@ -1010,11 +1010,14 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
 // Returns the item's sum to the threads tid < kSumItems.  Ends on a workgroup barrier.
 constexpr int kSumFlight = 12;
 constexpr int sum_items(int mr) { return mr * (kMH / 4); }
-constexpr int sum_sub(int mr) { return kMT / sum_items(mr); }
+// (owners of fewer than four rows keep the four-way split of the k-slices -- and with it the bits of
+// every sum -- on the first sum_items * 4 threads; the bytes a CU has to pull are what the rows cost)
+constexpr int sum_sub(int mr) { return mr >= 4 ? kMT / sum_items(mr) : 4; }
 constexpr int kSumItems = sum_items(kMR), kSumSub = sum_sub(kMR);   // (host-side LDS sizing of the default)
 template <int MR>
 __device__ __forceinline__ f32x4 slab_quads_sum(const float* slabs, int k_slices, int zs, int row, int tid,
                                                 float* part) {
+  constexpr int SUB = sum_sub(MR);
   const int item = tid & ((MR * (kMH / 4)) - 1), sub = tid / (MR * (kMH / 4));
   const int c4 = (item & 31) * 4;
   const __amdgpu_buffer_rsrc_t sr = xwg_buffer(slabs);
@@ -1024,8 +1027,8 @@ __device__ __forceinline__ f32x4 slab_quads_sum(const float* slabs, int k_slices
     __syncthreads();
     return one;
   }
-  const int per = ceil_div(k_slices, (kMT / (MR * (kMH / 4))));
-  const int z_lo = sub * per, z_hi = min(z_lo + per, k_slices);
+  const int per = ceil_div(k_slices, SUB);
+  const int z_lo = sub * per, z_hi = sub < SUB ? min(z_lo + per, k_slices) : z_lo;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   for (int z = z_lo; z < z_hi; z += kSumFlight) {
     f32x4 q[kSumFlight];
@@ -1035,11 +1038,11 @@ __device__ __forceinline__ f32x4 slab_quads_sum(const float* slabs, int k_slices
     for (int u = 0; u < kSumFlight; ++u)
       if (z + u < z_hi) v += q[u];
   }
-  if (sub > 0) *reinterpret_cast<f32x4*>(part + ((sub - 1) * (MR * (kMH / 4)) + item) * 4) = v;
+  if (sub > 0 && sub < SUB) *reinterpret_cast<f32x4*>(part + ((sub - 1) * (MR * (kMH / 4)) + item) * 4) = v;
   __syncthreads();
   if (sub == 0) {
 #pragma unroll
-    for (int q = 1; q < (kMT / (MR * (kMH / 4))); ++q) v += *reinterpret_cast<const f32x4*>(part + ((q - 1) * (MR * (kMH / 4)) + item) * 4);
+    for (int q = 1; q < SUB; ++q) v += *reinterpret_cast<const f32x4*>(part + ((q - 1) * (MR * (kMH / 4)) + item) * 4);
   }
   return v;
 }
@@ -1093,6 +1096,9 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
   const int po = Nh16 + 4;                   // pitch of a head-output row
   const int per_wave = D + 3 * K + (FULL ? 3 * DK : 0);
+  // rows of a 16-row MFMA result this owner keeps (lanes g == 0 hold result rows 0..3: with fewer than
+  // four rows per owner the others repeat its rows -- `rowA` wraps -- and belong to nobody here)
+  constexpr int RQ = MR < 4 ? MR : 4;
   float* Whs = smem;                         // [Nh16][128], element (n, i) at n*128 + (i ^ 4(n & 15))
   float* H1s = Whs + (WIDE ? 0 : Nh16 * kMH);   // [MR][kMHP]  (wide heads: no head matrix here)
   float* H2s = H1s + MR * kMHP;             // [MR][kMHP]  h2, later dz2 in place
@@ -1200,14 +1206,14 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
           const float bias = b2s[n];
           if constexpr (WIDE) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RQ; ++r) {
               const float v = tanhf(acc[r] + bias);
               H2s[(4 * g + r) * kMHP + n] = v;
               if (r0 + 4 * g + r < B) xwg_store(p.h2e + (int64_t)(r0 + 4 * g + r) * kMH + n, v);
             }
           } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) H2s[(4 * g + r) * kMHP + n] = tanhf(acc[r] + bias);
+            for (int r = 0; r < RQ; ++r) H2s[(4 * g + r) * kMHP + n] = tanhf(acc[r] + bias);
           }
         }
       }
@@ -1237,7 +1243,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         if (4 * g < MR) {
           const float bias = bhs[n];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
+          for (int r = 0; r < RQ; ++r) {
             const int rr = 4 * g + r;
             const float v = acc[r] + bias;
             Os[rr * po + n] = v;
@@ -1437,7 +1443,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         const int n = 16 * w + c16;
         const float bias = b2s[n];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RQ; ++r) {
           const int rr = 4 * g + r;
           const float v = tanhf(acc[r] + bias);
           H2s[rr * kMHP + n] = v;
@@ -1506,7 +1512,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       if (4 * g < MR) {
         const float bias = bhs[n];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RQ; ++r) {
           const int rr = 4 * g + r;
           const float v = acc[r] + bias;
           Os[rr * po + n] = v;
@@ -1640,7 +1646,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       }
       if (4 * g < MR) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RQ; ++r) {
           const int rr = 4 * g + r;
           const float hv = H2s[rr * kMHP + i];
           const float v = acc[r] * (1.0f - hv * hv);
@@ -1665,7 +1671,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       }
       if (4 * g < MR) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RQ; ++r) {
           const int rr = 4 * g + r;
           const float hv = H1s[rr * kMHP + i];
           if (r0 + rr < B) xwg_store(p.dz1 + (int64_t)(r0 + rr) * kMH + i, acc[r] * (1.0f - hv * hv));

@@ -371,3 +371,27 @@ def test_full_covariance_persistent_equals_phase_kernels(B, eps, n, batch, n_upd
         assert np.allclose(a[0][key], b[0][key], rtol=1e-4, atol=1e-4), (key, a[0], b[0])
     assert torch.allclose(a[1], b[1], atol=1e-4, rtol=1e-3)
     assert a[0] == a2[0] and torch.equal(a[1], a2[1])            # reruns bitwise
+
+
+@pytest.mark.parametrize('config', ['cfg3', 'ant_yaml'])
+def test_two_rows_per_owner_is_bitwise_the_four_row_layout(config):
+    """Where the chip has the CUs, an owner workgroup takes two minibatch rows instead of four (half the
+    slab bytes through its CU's memory pipe: fit_persistent_mdnn.hip, mdnn_geom).  The k-slice sums keep
+    their four-way split and their order (slab_quads_sum), every other per-row product is unchanged: the
+    trained weights of a teacher-forced chunk (EPS_NOISE = 0) are bit for bit those of the four-row layout
+    (BSIG_MDNN_MR=4, read once per process: two fresh processes), on summary rows from factor rows (cfg3)
+    and with wide heads (cfg/ant.yaml)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for mr in ('4', '0'):
+        env = dict(os.environ, BSIG_MDNN_MR=mr)
+        res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'ab_bitwise.py'), config], env=env,
+                             capture_output=True, text=True, timeout=600)
+        m = re.search(r'weights ([0-9a-f]{16}) logs [0-9a-f]{16} test_loss\[-1\] (\S+)', res.stdout)
+        assert res.returncode == 0 and m, res.stdout[-2000:] + res.stderr[-3000:]
+        out.append((m.group(1), float(m.group(2))))
+    assert out[0][0] == out[1][0], out
+    assert abs(out[0][1] - out[1][1]) <= 2e-6 * max(1.0, abs(out[0][1])), out
