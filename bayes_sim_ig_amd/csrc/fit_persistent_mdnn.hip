@@ -82,12 +82,14 @@ static bool mdnn_geom(const PersistMdnnShape& s, MdnnGeom* g) {
   g->n_small = kMH / kMNB + g->NhP / kMNB;
   // Rows per owner: an owner pulls its rows of every k-slice's slab through ONE CU's vector-memory
   // pipe (~40 GB/s of cache-bypassing loads: 47 slices x 4 rows x 512 B = 96 KB = 2.4 us for the Ant
-  // summaries) -- two rows each where the chip has the CUs for twice the owners (diagonal covariance;
-  // same sums in the same order: slab_quads_sum).  BSIG_MDNN_MR=4: A/B runs, tests.
+  // summaries), and the per-row loops of its chain shrink with its rows -- one row each where the chip has
+  // the CUs for B owners, else two, else four (diagonal covariance; same sums in the same order:
+  // slab_quads_sum).  BSIG_MDNN_MR=1|2|4: A/B runs, tests.
   g->mr = kMR;
   {
     static const int force_mr = [] { const char* e = getenv("BSIG_MDNN_MR"); return e ? atoi(e) : 0; }();
-    if (!s.full_cov && force_mr != 4 && g->k_slices > 1 && g->G1 + ceil_div(s.batch, 2) + g->n_small <= kXwgMax) g->mr = 2;
+    for (int mr = 1; mr <= 2 && !s.full_cov && force_mr != 4; ++mr)
+      if ((force_mr == 0 || force_mr == mr) && g->G1 + ceil_div(s.batch, mr) + g->n_small <= kXwgMax) { g->mr = mr; break; }
   }
   g->n_owner = ceil_div(s.batch, g->mr);
   g->stream = 0; g->s_chunks = 0;
@@ -354,9 +356,11 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
 #define BSIG_MDNN_LAUNCH_WF(DP_, FAC_)                                      \
   do {                                                                       \
     if (g.wide && full) BSIG_MDNN_LAUNCH(DP_, FAC_, true, true, kMR);        \
+    else if (g.wide && g.mr == 1) BSIG_MDNN_LAUNCH(DP_, FAC_, true, false, 1);   \
     else if (g.wide && g.mr == 2) BSIG_MDNN_LAUNCH(DP_, FAC_, true, false, 2);   \
     else if (g.wide) BSIG_MDNN_LAUNCH(DP_, FAC_, true, false, kMR);          \
     else if (full) BSIG_MDNN_LAUNCH(DP_, FAC_, false, true, kMR);            \
+    else if (g.mr == 1) BSIG_MDNN_LAUNCH(DP_, FAC_, false, false, 1);        \
     else if (g.mr == 2) BSIG_MDNN_LAUNCH(DP_, FAC_, false, false, 2);        \
     else BSIG_MDNN_LAUNCH(DP_, FAC_, false, false, kMR);                     \
   } while (0)

@@ -373,14 +373,14 @@ def test_full_covariance_persistent_equals_phase_kernels(B, eps, n, batch, n_upd
     assert a[0] == a2[0] and torch.equal(a[1], a2[1])            # reruns bitwise
 
 
-@pytest.mark.parametrize('config', ['cfg3', 'ant_yaml'])
-def test_two_rows_per_owner_is_bitwise_the_four_row_layout(config):
-    """Where the chip has the CUs, an owner workgroup takes two minibatch rows instead of four (half the
-    slab bytes through its CU's memory pipe: fit_persistent_mdnn.hip, mdnn_geom).  The k-slice sums keep
-    their four-way split and their order (slab_quads_sum), every other per-row product is unchanged: the
-    trained weights of a teacher-forced chunk (EPS_NOISE = 0) are bit for bit those of the four-row layout
-    (BSIG_MDNN_MR=4, read once per process: two fresh processes), on summary rows from factor rows (cfg3)
-    and with wide heads (cfg/ant.yaml)."""
+@pytest.mark.parametrize('config', ['cfg3', 'ant_yaml', 'cfg4'])
+def test_fewer_rows_per_owner_is_bitwise_the_four_row_layout(config):
+    """Where the chip has the CUs, an owner workgroup takes two minibatch rows, or one, instead of four (less
+    slab bytes through its CU's memory pipe, shorter per-row loops: fit_persistent_mdnn.hip, mdnn_geom).  The
+    k-slice sums keep their four-way split and their order (slab_quads_sum), every other per-row product is
+    unchanged: the trained weights of a teacher-forced chunk (EPS_NOISE = 0) are bit for bit those of the
+    four-row layout (BSIG_MDNN_MR=4, read once per process: two fresh processes) -- two rows on summary rows
+    from factor rows (cfg3) and with wide heads (cfg/ant.yaml), one row on a narrow first layer (cfg4)."""
     import re
     import subprocess
     import sys
