@@ -15,7 +15,7 @@ for c in anymal_yaml shadow_more; do
   n=${c%_yaml}
   WIDE_DETAIL=1 python3 tools/persist_stream_prof.py $c 2>&1 | grep -v "amdgpu.ids" > "$OUT/${TAG}_${n}_update_timeline.txt"
 done
-python3 tools/persist_mdnn_prof.py cfg3 2>&1 | grep -v "amdgpu.ids" > "$OUT/${TAG}_cfg3_update_timeline.txt"
+PER_UPDATE=1 LAZY=1 python3 tools/persist_mdnn_prof.py cfg3 2>&1 | grep -v "amdgpu.ids" > "$OUT/${TAG}_cfg3_update_timeline.txt"
 python3 tools/persist_prof.py 2>&1 | grep -v "amdgpu.ids" > "$OUT/${TAG}_cfg5_update_timeline.txt"
 python3 tools/summarizer_bench.py 2>&1 | grep -v "amdgpu.ids" > "$OUT/${TAG}_summarizer_bench.txt"
 [ -x tools/micro/bin/fill_bench ] && tools/micro/bin/fill_bench > "$OUT/${TAG}_fill_bench.txt" 2>&1
