@@ -1091,6 +1091,38 @@ __device__ __attribute__((noinline)) float mdnn_owner_eval_heads(unsigned* flag_
   return eacc;
 }
 
+// Head outputs h2 Wh^T of an owner with one or two rows, on the vector ALU.  A 16x16x4 fp32 MFMA is a
+// chain of four fused multiply-adds in ascending k (= lane group) order -- tools/micro/mfma_order_probe.hip:
+// 256 of 256 outputs bit-equal to fmaf chains, also over 32 chained instructions -- so the product of the
+// MFMA path below (instruction (tt, j) contracts k = 16 tt + 4 g + j over g = 0..3) is the fmaf chain
+// over (tt, j, g) in that order, whoever computes it.  With MR rows of the 16 an MFMA forms, the matrix
+// unit is 1/16 .. 1/8 used and a wavefront runs 32 dependent instructions per 16 columns (17 column
+// blocks for the ShadowHand head: three rounds on 8 wavefronts, 1.5 us); one lane per COLUMN runs the 128
+// fmas of its column once (32 conflict-free 16-byte reads of its row of Wh, h2 broadcast): 0.4 us.
+template <int MR>
+__device__ __forceinline__ void heads_fma_chain(const float* H2s, const float* Whs, int n, float (&acc)[MR]) {
+  const float* bp = Whs + n * kMH;
+  const int sw = 4 * (n & 15);
+#pragma unroll
+  for (int r = 0; r < MR; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 8; ++tt) {
+    f32x4 b[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(bp + ((16 * tt + 4 * g) ^ sw));
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+      f32x4 a[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) a[g] = *reinterpret_cast<const f32x4*>(H2s + r * kMHP + 16 * tt + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[r] = __builtin_fmaf(a[g][j], b[g][j], acc[r]);
+    }
+  }
+}
+
 template <bool DP, bool WIDE, bool FULL, int MR = kMR>
 __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
   const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
@@ -1225,7 +1257,20 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         eacc += mdnn_owner_eval_heads<MR>(p.flag_h2e, p.flag_oe, p.oe, flagp, Os, po, o, p.n_hb, B, r0, Nh, Nh16,
                                           K, DK, p.n_test, gp, eidx);
       }
-      for (int cb = w; !WIDE && cb * 16 < Nh16; cb += 8) {
+      if constexpr (!WIDE && MR <= 2) {     // (one lane per column: heads_fma_chain)
+        for (int n = tid; n < Nh16; n += kMT) {
+          float hacc[MR];
+          heads_fma_chain<MR>(H2s, Whs, n, hacc);
+          const float bias = bhs[n];
+#pragma unroll
+          for (int r = 0; r < MR; ++r) {
+            const float v = hacc[r] + bias;
+            Os[r * po + n] = v;
+            if (r0 + r < B && gp * B + r0 + r < p.n_test && n >= K + DK && n < K + 2 * DK) eacc += expf(v);
+          }
+        }
+      }
+      for (int cb = w; !WIDE && MR > 2 && cb * 16 < Nh16; cb += 8) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int n = 16 * cb + c16;
         const float* ap = H2s + rowA * kMHP + 4 * g;
@@ -1493,8 +1538,22 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
         }
       }
     }
-    // ---- head outputs = h2 Wh^T + bh: column blocks w, w+8, w+16 -----------------------
-    for (int cb = w; !WIDE && cb * 16 < Nh16; cb += 8) {
+    // ---- head outputs = h2 Wh^T + bh: one lane per column (one or two rows per owner), else
+    //      column blocks w, w+8, w+16 on the MFMA units ------------------------------------
+    if constexpr (!WIDE && MR <= 2) {
+      for (int n = tid; n < Nh16; n += kMT) {
+        float hacc[MR];
+        heads_fma_chain<MR>(H2s, Whs, n, hacc);
+        const float bias = bhs[n];
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+          const float v = hacc[r] + bias;
+          Os[r * po + n] = v;
+          if (r0 + r < B && n >= K + DK && n < K + 2 * DK) eacc += expf(v);
+        }
+      }
+    }
+    for (int cb = w; !WIDE && MR > 2 && cb * 16 < Nh16; cb += 8) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const int n = 16 * cb + c16;
       const float* ap = H2s + rowA * kMHP + 4 * g;
