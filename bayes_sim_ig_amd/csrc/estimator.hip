@@ -1248,6 +1248,12 @@ extern "C" int bsig_debug_spin(int blocks, size_t lds_bytes, int ms, bsig_stream
 
 // diagnostics (tools/persist_prof.py): phase time stamps of the persistent kernel
 extern "C" void bsig_debug_persist_profile(void* buffer) { persist_set_profile_buffer(buffer); }
+extern "C" int bsig_debug_persist_mdnn_geometry(int batch, int input_dim, int out_dim, int n_comp, int full_cov,
+                                                int max_test, int32_t* out) {
+  if (!out) return 0;
+  return persist_mdnn_geometry(PersistMdnnShape{batch, input_dim, 128, 128, BSIG_ACT_TANH, out_dim, n_comp,
+                                                full_cov, max_test}, out);
+}
 extern "C" int bsig_debug_persist_geometry(int batch, int feat_dim, int out_dim, int n_comp, int max_test,
                                            int32_t* out) {
   if (!out) return 0;

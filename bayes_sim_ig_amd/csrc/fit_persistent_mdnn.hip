@@ -165,6 +165,16 @@ static bool mdnn_device_can_host(const MdnnGeom& g) {
   return per_cu >= 1;
 }
 
+int persist_mdnn_geometry(const PersistMdnnShape& s, int32_t* out) {
+  MdnnGeom g;
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  if (!mdnn_geom(s, &g)) return 0;
+  const int32_t v[10] = {g.k_slices, g.G1, g.n_owner, g.mr, g.n_small, g.wide, g.stream, g.eval_passes,
+                         (int32_t)g.lds, g.Nh};
+  for (int i = 0; i < 10; ++i) out[i] = v[i];
+  return 1;
+}
+
 bool persist_mdnn_supported(const PersistMdnnShape& s) {
   MdnnGeom g;
   return mdnn_geom(s, &g) && mdnn_device_can_host(g);

@@ -42,6 +42,8 @@ struct PersistMdnnBuffers {
 struct PersistHyper;   // persist.h
 
 bool persist_mdnn_supported(const PersistMdnnShape& s);
+// (diagnostics) the decomposition fit_persistent_mdnn.hip plans for a shape, bsig.h: bsig_debug_persist_mdnn_geometry
+int persist_mdnn_geometry(const PersistMdnnShape& s, int32_t* out);
 // ... with the first layer STREAMED by the tile workgroups (it does not fit the chip): such a plan
 // takes cross-correlation factor rows only, its Adam step of a data-parallel rank and its held-out
 // evaluations run outside the launches

@@ -439,6 +439,16 @@ int bsig_debug_spin(int blocks, size_t lds_bytes, int ms, bsig_stream_t stream);
  * Returns 1 if the shape is covered, 0 if not. */
 int bsig_debug_persist_geometry(int batch, int feat_dim, int out_dim, int n_comp, int max_test,
                                 int32_t* out);
+/* ... and how the persistent update kernel of the two-layer MDNN (trunk [128, 128], tanh; the reference's
+ * default, models/mdnn.py:68-75) would lay out its workgroups for input_dim summary columns:
+ * out[16] = { first-layer k-slices of 256 columns, first-layer tile workgroups, row-owner workgroups,
+ * minibatch rows per owner (1, 2 or 4; 8 with a streamed first layer), small-weight / head-block
+ * workgroups, wide heads (head outputs formed by the head-block workgroups), first layer streamed,
+ * evaluation passes (0: evaluations outside the launches), LDS bytes per workgroup (a streamed plan:
+ * without its tile workgroups, whose need depends on the factor dimensions), head width Nh, 0... }.
+ * Returns 1 if the shape is covered, 0 if not. */
+int bsig_debug_persist_mdnn_geometry(int batch, int input_dim, int out_dim, int n_comp, int full_cov,
+                                     int max_test, int32_t* out);
 
 #ifdef __cplusplus
 }

@@ -263,3 +263,52 @@ def test_linear_head_tiling_planner():
         assert g['mixed'] == max(0, g['n_owner'] - (g['T'] - g['G']))
     assert n_ok > 200
     assert geom(200, 4096, 32, 4, 0)[0] == 0        # minibatches beyond 112 rows: the v1 kernel / per-phase kernels
+
+
+def test_mdnn_kernel_workgroup_planner():
+    """The layout of the persistent kernel of the two-layer MDNN (csrc/fit_persistent_mdnn.hip, host
+    arithmetic: bsig_debug_persist_mdnn_geometry): an owner workgroup takes ONE minibatch row where the
+    chip has the CUs for a workgroup per row (narrow first layers), else two, else four; first layers with
+    more tiles than CUs are streamed (8 rows per owner); every covered shape respects the chip."""
+    import ctypes as C
+    import numpy as np
+    lib = _lib.load()
+    names = ['k_slices', 'G1', 'n_owner', 'mr', 'n_small', 'wide', 'stream', 'eval_passes', 'lds', 'Nh']
+
+    def geom(batch, inp, d, k, full=0, max_test=200):
+        out = (C.c_int32 * 16)()
+        ok = lib.bsig_debug_persist_mdnn_geometry(batch, inp, d, k, full, max_test, out)
+        return ok, dict(zip(names, list(out)[:10]))
+
+    ok, g = geom(100, 232, 32, 4)                 # cfg4: one k-slice, a workgroup per row
+    assert ok and (g['k_slices'], g['G1'], g['mr'], g['n_owner'], g['wide'], g['stream']) == (1, 4, 1, 100, 0, 0)
+    ok, g = geom(100, 11802, 10, 5)               # cfg3-like: 47 k-slices, two rows per owner
+    assert ok and (g['k_slices'], g['G1'], g['mr'], g['n_owner'], g['stream']) == (47, 188, 2, 50, 0)
+    ok, g = geom(100, 11802, 17, 10)              # cfg/ant.yaml: wide heads
+    assert ok and g['wide'] == 1 and g['mr'] == 2 and g['G1'] + g['n_owner'] + g['n_small'] <= 256
+    ok, g = geom(100, 56402, 13, 10)              # cfg/anymal.yaml: streamed first layer
+    assert ok and g['stream'] == 1 and g['mr'] == 8 and g['n_owner'] == 13
+    ok, g = geom(100, 232, 4, 4, full=1)          # full covariance keeps four rows per owner
+    assert ok and g['mr'] == 4 and g['n_owner'] == 25
+    rng = np.random.RandomState(1)
+    n_ok = 0
+    for _ in range(300):
+        batch, k = int(rng.randint(1, 105)), int(rng.randint(1, 17))
+        d = int(rng.randint(1, min(40, 8 * (64 // k)) + 1))
+        inp = int(rng.choice([3, 40, 190, 256, 257, 1290, 2310, 11154, 11802, 12300, 13000, 56402]))
+        ok, g = geom(batch, inp, d, k, 0, int(rng.randint(0, 400)))
+        if not ok:
+            continue
+        n_ok += 1
+        assert g['Nh'] == k * (1 + 2 * d) and g['k_slices'] * 256 >= inp
+        assert g['G1'] + g['n_owner'] + g['n_small'] <= 256 and g['lds'] <= 160 * 1024
+        assert g['n_owner'] * g['mr'] >= batch and g['mr'] in (1, 2, 4, 8)
+        if not g['stream']:
+            assert g['G1'] == 4 * g['k_slices']
+            # the fewest rows per owner the chip has CUs for
+            for mr in (1, 2):
+                if mr < g['mr']:
+                    assert 4 * g['k_slices'] + -(-batch // mr) + g['n_small'] > 256
+        else:
+            assert g['mr'] == 8 and inp % 2 == 0
+    assert n_ok > 150
