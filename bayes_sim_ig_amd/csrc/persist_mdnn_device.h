@@ -130,6 +130,23 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// 4 x 4 transpose across the four lanes of a quad (lanes 4q .. 4q+3, a = lane & 3): lane a comes in with
+// column a of a 4 x 4 block, c[r] = M[r][a], and leaves with row a, M[a][0..3].  A 32x32 accumulator lane
+// holds four consecutive ROWS of one column; a cross-workgroup payload is stored 16 bytes per lane along a
+// row (it costs by the number of memory transactions): two butterfly steps turn the one into the other.
+__device__ __forceinline__ f32x4 quad_transpose4(float c0, float c1, float c2, float c3, int a) {
+  const bool odd = a & 1, hi = a & 2;
+  // step 1, partner a ^ 1: even lanes end with rows 0 and 2 of columns (a, a + 1), odd ones with rows 1 and 3
+  const float r0 = __shfl_xor(odd ? c0 : c1, 1, 64), r1 = __shfl_xor(odd ? c2 : c3, 1, 64);
+  const float pA0 = odd ? r0 : c0, pA1 = odd ? c1 : r0;      // row 0 / 1, the lane pair's two columns
+  const float pB0 = odd ? r1 : c2, pB1 = odd ? c3 : r1;      // row 2 / 3
+  // step 2, partner a ^ 2: lanes 0, 1 keep their row 0 / 1 pair and take the other pair's, lanes 2, 3 rows 2 / 3
+  const float q0 = __shfl_xor(hi ? pA0 : pB0, 2, 64), q1 = __shfl_xor(hi ? pA1 : pB1, 2, 64);
+  f32x4 out;
+  out[0] = hi ? q0 : pA0; out[1] = hi ? q1 : pA1; out[2] = hi ? pB0 : q0; out[3] = hi ? pB1 : q1;
+  return out;
+}
+
 // First-layer inputs from cross-correlation FACTOR rows (summarizers.py:106-119; layout in
 // bsig.h): x[i*A + j] = sf[i] * af[j] -- the one fp32 multiply the summarizer itself would
 // do --, x[S*A] = mean * 1, x[S*A + 1] = std * 1; columns beyond that come out as 1 * 1 and
@@ -666,11 +683,19 @@ __device__ __attribute__((noinline)) void mdnn_serve_eval(float* Hs, const float
     __syncthreads();
     if (kh == 0) {
       const float bias = bsh[l31];
-      float* dst = fresh_ptr(oe + ((int64_t)hb * B + mt * 32 + 4 * h) * kMNB + l31);
+      const __amdgpu_buffer_rsrc_t orr = xwg_buffer(oe + (int64_t)hb * B * kMNB);
+      const int a = l31 & 3, c4 = l31 & ~3;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = mt * 32 + acc_row(i, h);
-        if (row < B) xwg_store(dst + acc_row0(i) * kMNB, acc[i] + Xo[row * kMPbuf + l31] + bias);
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = mt * 32 + acc_row(4 * q + e, h);
+          v[e] = acc[4 * q + e] + Xo[row * kMPbuf + l31] + bias;
+        }
+        const f32x4 t = quad_transpose4(v[0], v[1], v[2], v[3], a);
+        const int row = mt * 32 + 8 * q + 4 * h + a;
+        if (row < B) xwg_store4(orr, row * kMNB + c4, t[0], t[1], t[2], t[3]);
       }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -868,12 +893,21 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
         BSIG_MSTAMP(2);
         if (kh == 0) {
           const float bias = bsh[l31];
-          // block-major: [n_hb][B][32]
-          float* dst = fresh_ptr(p.o_wide + ((int64_t)hb * B + mt * 32 + 4 * h) * kMNB + l31);
+          // block-major: [n_hb][B][32]; four rows of a column per lane -> four columns of a row
+          // (quad_transpose4): 4 stores of 16 bytes per lane instead of 16 of 4
+          const __amdgpu_buffer_rsrc_t orr = xwg_buffer(p.o_wide + (int64_t)hb * B * kMNB);
+          const int a = l31 & 3, c4 = l31 & ~3;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int row = mt * 32 + acc_row(i, h);
-            if (row < B) xwg_store(dst + acc_row0(i) * kMNB, acc[i] + Xo[row * kMPbuf + l31] + bias);
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int row = mt * 32 + acc_row(4 * q + e, h);
+              v[e] = acc[4 * q + e] + Xo[row * kMPbuf + l31] + bias;
+            }
+            const f32x4 t = quad_transpose4(v[0], v[1], v[2], v[3], a);
+            const int row = mt * 32 + 8 * q + 4 * h + a;
+            if (row < B) xwg_store4(orr, row * kMNB + c4, t[0], t[1], t[2], t[3]);
           }
         }
         BSIG_MSTAMP(11);
@@ -906,11 +940,13 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
                                                          acc, 0, 0, 0);
             }
           }
-          float* dst = fresh_ptr(p.dz2_part + ((int64_t)hb * B + mt * 32 + 4 * h) * kMH + col);
+          const __amdgpu_buffer_rsrc_t zr = xwg_buffer(p.dz2_part + (int64_t)hb * B * kMH);
+          const int a = l31 & 3, c4 = col & ~3;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int row = mt * 32 + acc_row(i, h);
-            if (row < B) xwg_store(dst + acc_row0(i) * kMH, acc[i]);
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 t = quad_transpose4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], a);
+            const int row = mt * 32 + 8 * q + 4 * h + a;
+            if (row < B) xwg_store4(zr, row * kMH + c4, t[0], t[1], t[2], t[3]);
           }
         }
         __builtin_amdgcn_s_waitcnt(0);
