@@ -256,24 +256,19 @@ __device__ __forceinline__ void mdnn_tile_eval(const MdnnArgs& p, const float* W
       for (int i = 0; i < 16; ++i) X[(mt * 32 + acc_row(i, h)) * kMPbuf + l31] = acc[i];
     }
     __syncthreads();
-    if (kh == 0) {
+    if (kh == 0) {     // (rows of 16-byte quads, as the update's slab)
       const float bias = ks == 0 ? biasl[l31] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* x = X + (mt * 32 + acc_row(i, h)) * kMPbuf + l31;
-        *x = acc[i] + *x + bias;
-      }
-    }
-    __syncthreads();
-    {   // (rows of 16-byte quads, as the update's slab)
       const __amdgpu_buffer_rsrc_t sr = xwg_buffer(p.eval_slabs + (((int64_t)(eidx & 1) * p.eval_passes + pass) * p.k_slices + ks) * B * kMH + n0);
+      const int a = l31 & 3, c4 = l31 & ~3;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int idx = u * kMT + tid, b = idx >> 3, c4 = (idx & 7) * 4;
-        if (b < rows) {
-          const float* x = X + b * kMPbuf + c4;
-          xwg_store4(sr, b * kMH + c4, x[0], x[1], x[2], x[3]);
-        }
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = acc[4 * q + e] + X[(mt * 32 + acc_row(4 * q + e, h)) * kMPbuf + l31] + bias;
+        const f32x4 t = quad_transpose4(v[0], v[1], v[2], v[3], a);
+        const int row = mt * 32 + 8 * q + 4 * h + a;
+        if (row < rows) xwg_store4(sr, row * kMH + c4, t[0], t[1], t[2], t[3]);
       }
     }
   }
@@ -455,29 +450,24 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
       if (bias_pending && w == kMT / 64 - 1 && lane < kMNB) bias_step(lane);
       bias_pending = false;
       __syncthreads();
-      // The two k-halves meet in X (same operation order as ever: (first half + second half) + bias),
-      // and the block goes out as rows of 16-byte quads, one or two per thread: an accumulator lane
-      // holds four ROWS of one column -- stored from there the slab was 16 dword stores per lane, and a
-      // cross-workgroup payload costs by the number of memory transactions, not by its bytes
-      // (tools/micro/handoff_bench.hip; flag up 3.1 us after the last MFMA, the linear heads' kernel: 0.8).
+      // The two k-halves meet (same operation order as ever: (first half + second half) + bias), and
+      // the block goes out as rows of 16-byte quads: an accumulator lane holds four ROWS of one column
+      // -- stored from there the slab was 16 dword stores per lane, and a cross-workgroup payload costs
+      // by the number of memory transactions, not by its bytes (tools/micro/handoff_bench.hip) -- a
+      // 4 x 4 transpose inside each lane quad (quad_transpose4) turns them into four columns of a row.
       if (kh == 0) {
         const float bias = ks == 0 ? biasl[l31_l] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float* x = X + (mt * 32 + acc_row(i, h_l)) * kMPbuf + l31_l;
-          *x = acc[i] + *x + bias;
-        }
-      }
-      __syncthreads();
-      {
         const __amdgpu_buffer_rsrc_t sr = xwg_buffer(p.slabs + (int64_t)ks * B * kMH + n0);
+        const int a = l31_l & 3, c4 = l31_l & ~3;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int idx = u * kMT + tid_l, b = idx >> 3, c4 = (idx & 7) * 4;
-          if (b < B) {
-            const float* x = X + b * kMPbuf + c4;
-            xwg_store4(sr, b * kMH + c4, x[0], x[1], x[2], x[3]);
-          }
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = acc[4 * q + e] + X[(mt * 32 + acc_row(4 * q + e, h_l)) * kMPbuf + l31_l] + bias;
+          const f32x4 t = quad_transpose4(v[0], v[1], v[2], v[3], a);
+          const int row = mt * 32 + 8 * q + 4 * h_l + a;
+          if (row < B) xwg_store4(sr, row * kMH + c4, t[0], t[1], t[2], t[3]);
         }
       }
       __builtin_amdgcn_s_waitcnt(0);
