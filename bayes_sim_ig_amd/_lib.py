@@ -114,6 +114,7 @@ _PROTOS = {
     'bsig_debug_persist_profile': (None, [vp]),
     'bsig_debug_spin': (C.c_int, [C.c_int, sz, C.c_int, vp]),
     'bsig_debug_persist_geometry': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    'bsig_debug_mfma_vs_fma': (C.c_int, [vp, vp, C.c_int, vp, vp]),
     'bsig_debug_persist_mdnn_geometry': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     'bsig_comm_unique_id': (C.c_int, [vp]),
     'bsig_comm_init': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),

@@ -56,7 +56,7 @@ void range_pop() {
 }  // namespace bsig
 
 extern "C" const char* bsig_last_error(void) { return bsig::g_err; }
-extern "C" int bsig_version(void) { return 105; }
+extern "C" int bsig_version(void) { return 106; }
 
 // What the library was compiled against, for a binding to compare with its own view
 // (bayes_sim_ig_amd/_lib.py: ctypes mirrors of the structs; a stale object built against an

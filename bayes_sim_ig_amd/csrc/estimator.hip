@@ -1248,6 +1248,36 @@ extern "C" int bsig_debug_spin(int blocks, size_t lds_bytes, int ms, bsig_stream
 
 // diagnostics (tools/persist_prof.py): phase time stamps of the persistent kernel
 extern "C" void bsig_debug_persist_profile(void* buffer) { persist_set_profile_buffer(buffer); }
+namespace bsig {
+// (tests) The owners' fma-chain head outputs (persist_mdnn_device.h: heads_fma_chain) rest on one property
+// of the hardware: v_mfma_f32_16x16x4_f32 adds its four products as a chain of fused multiply-adds in
+// ascending k (= lane group).  One wavefront: D = A [16][K] B [K][16] by a chain of K / 4 MFMAs, and the
+// same sums as fmaf chains on the vector ALU; counts the outputs whose bits differ.
+__global__ void mfma_vs_fma_kernel(const float* A, const float* B, int K, int32_t* mismatches) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const int l = threadIdx.x, r = l & 15, g = l >> 4;
+  v4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 4)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * K + k0 + g], B[(k0 + g) * 16 + r], acc, 0, 0, 0);
+  int bad = 0;
+  for (int v = 0; v < 4; ++v) {
+    const int i = 4 * g + v;           // D[i][r]
+    float c = 0.f;
+    for (int k = 0; k < K; ++k) c = __builtin_fmaf(A[i * K + k], B[k * 16 + r], c);
+    bad += __float_as_uint(c) != __float_as_uint(acc[v]) ? 1 : 0;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace bsig
+
+extern "C" int bsig_debug_mfma_vs_fma(const float* a, const float* b, int k, int32_t* mismatches,
+                                      bsig_stream_t stream) {
+  BSIG_REQUIRE(a && b && mismatches && k >= 4 && k % 4 == 0, "debug_mfma_vs_fma: null / K not a multiple of 4");
+  hipLaunchKernelGGL(bsig::mfma_vs_fma_kernel, dim3(1), dim3(64), 0, as_stream(stream), a, b, k, mismatches);
+  BSIG_CHECK_LAUNCH("mfma_vs_fma");
+  return BSIG_OK;
+}
+
 extern "C" int bsig_debug_persist_mdnn_geometry(int batch, int input_dim, int out_dim, int n_comp, int full_cov,
                                                 int max_test, int32_t* out) {
   if (!out) return 0;

@@ -450,6 +450,12 @@ int bsig_debug_persist_geometry(int batch, int feat_dim, int out_dim, int n_comp
 int bsig_debug_persist_mdnn_geometry(int batch, int input_dim, int out_dim, int n_comp, int full_cov,
                                      int max_test, int32_t* out);
 
+/* Tests: the property the MDNN kernel's fma-chain head outputs rest on -- a 16x16x4 fp32 MFMA adds its four
+ * products as a chain of fused multiply-adds in ascending k.  D = A [16][k] B [k][16] (device pointers, k a
+ * multiple of 4) by a chain of MFMAs and by fmaf chains; *mismatches (device, caller-zeroed) += the number
+ * of the 256 outputs whose bits differ. */
+int bsig_debug_mfma_vs_fma(const float* a, const float* b, int k, int32_t* mismatches, bsig_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
