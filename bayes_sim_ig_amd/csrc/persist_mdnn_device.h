@@ -175,17 +175,23 @@ __device__ __forceinline__ float4 fac_load4(const float* __restrict__ rowp, cons
                      rowp[c.oi[2]] * rowp[c.oj[2]], rowp[c.oi[3]] * rowp[c.oj[3]]);
 }
 
-// one [<=104, 256] summary tile = 13 float4 per thread in named registers
+// one [<=104, 256] summary tile = 13 float4 per thread in named registers.  Wavefront w holds -- and later
+// writes to LDS -- the tile's columns 32w .. 32w+31 (lane: row 8u + (lane >> 3), the quad at column
+// 32w + 4 (lane & 7)): the same 32 columns whose dW1 block it forms, so it can put the NEXT minibatch's
+// columns into LDS as soon as its own dW1 product has read the old ones, without waiting for the other
+// wavefronts (the tile used to go in at the top of the next update, 0.9 us in front of its forward MFMAs:
+// 104 KB through ds_write_b128 at ~80 B/clk, then a barrier).
 #define BSIG_MPF_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
 #define BSIG_MPF_DECL(u) float4 pf##u;
+#define BSIG_MPF_COL() (32 * (tid >> 6) + 4 * (tid & 7))
 #define BSIG_MPF_LOAD(u)                                                                    \
   {                                                                                         \
-    const int idx = min((u) * kMT + tid, nvec - 1);                                         \
-    const int64_t fr = (int64_t)p.ids[pf_row0 + (idx >> 6)];                                \
+    const int prow = min(8 * (u) + ((tid & 63) >> 3), B - 1);                               \
+    const int64_t fr = (int64_t)p.ids[pf_row0 + prow];                                      \
     if constexpr (FAC) {                                                                    \
       pf##u = fac_load4(p.x + fr * p.ldx, fcols);                                           \
     } else {                                                                                \
-      const int64_t col = min((int64_t)k0 + (idx & 63) * 4, p.ldx - 4);                     \
+      const int64_t col = min((int64_t)k0 + BSIG_MPF_COL(), p.ldx - 4);                     \
       pf##u = *reinterpret_cast<const float4*>(p.x + fr * p.ldx + col);                     \
     }                                                                                       \
   }
@@ -193,13 +199,13 @@ __device__ __forceinline__ float4 fac_load4(const float* __restrict__ rowp, cons
 // columns >= I (row padding, the tail of the last k-slice) enter as zeros
 #define BSIG_MPF_STORE(u)                                                                   \
   {                                                                                         \
-    const int idx = (u) * kMT + tid;                                                        \
-    if (idx < nvec) {                                                                       \
-      const int col = k0 + (idx & 63) * 4;                                                  \
+    const int prow = 8 * (u) + ((tid & 63) >> 3);                                           \
+    if (prow < B) {                                                                         \
+      const int col = k0 + BSIG_MPF_COL();                                                  \
       float4 v = pf##u;                                                                     \
       v.x = col + 0 < p.I ? v.x : 0.f; v.y = col + 1 < p.I ? v.y : 0.f;                     \
       v.z = col + 2 < p.I ? v.z : 0.f; v.w = col + 3 < p.I ? v.w : 0.f;                     \
-      *reinterpret_cast<float4*>(Fl + (idx >> 6) * kMPitch + (idx & 63) * 4) = v;           \
+      *reinterpret_cast<float4*>(Fl + prow * kMPitch + BSIG_MPF_COL()) = v;                 \
     }                                                                                       \
   }
 
@@ -406,8 +412,9 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   if (p.n_updates > 0) {
     const int64_t pf_row0 = (int64_t)step0 * B;
     FacCols fcols{};
-    if constexpr (FAC) fcols = fac_cols(k0 + (tid & 63) * 4, p.xS, p.xA);
+    if constexpr (FAC) fcols = fac_cols(k0 + BSIG_MPF_COL(), p.xS, p.xA);
     BSIG_MPF_LIST(BSIG_MPF_LOAD)
+    BSIG_MPF_LIST(BSIG_MPF_STORE)          // the first update's tile (later ones: behind the dW1 product)
   } else {
     BSIG_MPF_LIST(BSIG_MPF_ZERO)
   }
@@ -420,9 +427,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     const unsigned epoch = (unsigned)step + 1u;
     if (red[63] != 0.f) break;   // time-out bit as sampled during the previous update's wait
     BSIG_MSTAMP(0);
-    // ---- 1. summary tile -> LDS ------------------------------------------------
-    BSIG_MPF_LIST(BSIG_MPF_STORE)
-    __syncthreads();
+    // ---- 1. (the summary tile is in LDS: written behind the previous update's dW1 product) ----
     BSIG_MSTAMP(1);
 
     // ---- 2. partial forward: P[b, n] = sum_{k in slice} X[b, k] W1[n, k] ---------
@@ -488,7 +493,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     if (t + 1 < p.n_updates) {
       const int64_t pf_row0 = (int64_t)(step + 1) * B;
       FacCols fcols{};
-      if constexpr (FAC) fcols = fac_cols(k0 + (tid_l & 63) * 4, p.xS, p.xA);
+      if constexpr (FAC) fcols = fac_cols(k0 + BSIG_MPF_COL(), p.xS, p.xA);
       BSIG_MPF_LIST(BSIG_MPF_LOAD)
     }
     b1t *= p.beta1; b2t *= p.beta2;
@@ -566,6 +571,8 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
         }
       }
     }
+    // this wavefront's 32 columns of the NEXT minibatch tile (requested in the wait window above)
+    if (t + 1 < p.n_updates) { BSIG_MPF_LIST(BSIG_MPF_STORE) }
     bias_pending = ks == 0 && !DP;
     __syncthreads();
     if (DP && ks == 0 && tid_l < kMNB) {
