@@ -1287,5 +1287,9 @@ extern "C" int bsig_debug_persist_mdnn_geometry(int batch, int input_dim, int ou
 extern "C" int bsig_debug_persist_geometry(int batch, int feat_dim, int out_dim, int n_comp, int max_test,
                                            int32_t* out) {
   if (!out) return 0;
-  return persist_geometry(PersistShape{batch, feat_dim, out_dim, n_comp, max_test}, out);
+  const PersistShape s{batch, feat_dim, out_dim, n_comp, max_test};
+  const int rc = persist_geometry(s, out);
+  // which kernel a launch of this shape would really be (asks the device; 0 / 1 where there is none)
+  out[13] = persist_variant(s);
+  return rc;
 }

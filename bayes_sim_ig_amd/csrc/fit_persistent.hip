@@ -6,11 +6,13 @@
 // Round 4: UNIFIED workgroups.  The head matrix W [Nh, F] is tiled over the WHOLE chip:
 // workgroup (nb, ks) owns the 16 x KS tile W[16nb.., KS*ks..] (NT = 1; 32 rows with NT = 2
 // for heads whose 16-row tiles would need more than 256 workgroups), keeps it in LDS and
-// both Adam moments in registers for the whole run -- cfg5: 17 x 15 = 255 workgroups of
-// 16 x 288 instead of the 9 x 16 = 144 of 32 x 256 (+ 100 row-owner workgroups) of
-// fit_persistent_v1.hip, which left 112 CUs without matrix work.  The first `n_owner`
-// workgroups ALSO own one minibatch row each: the row work sits in what used to be the
-// tile workgroups' wait.  Per update:
+// both Adam moments in registers for the whole run.  The host's cost model (u_geom_try) picks the
+// tiling and where the minibatch rows live: cfg5 (260 x 4096) runs 9 x 22 = 198 tile workgroups
+// of 32 x 192 + 50 row owners of two rows each on CUs of their own (owner_only_workgroup), cfg2
+// (270 x 1024) 187 tiles of 16 x 96 + 50 owners -- instead of the 9 x 16 = 144 tiles of 32 x 256
+// (+ 100 row-owner workgroups) of fit_persistent_v1.hip.  Where the chip has no CUs to spare the
+// first `n_owner` tile workgroups ALSO own minibatch rows (the row work then sits in what used to
+// be their wait; BSIG_PERSIST_MIXED=1 forces that layout).  Per update:
 //   1. forward: the minibatch tile [B, KS] arrives in REGISTERS (fetched during the
 //      previous update's wait, already in the MFMA operand layout: wavefront w holds
 //      rows 16w..16w+15), so the product P^T = W_tile F^T (fp32 MFMA 16x16x4, W from
@@ -462,11 +464,11 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
       float sl = 0.f, su = 0.f;
       for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
       granule_publish(p.gran + kGranArr, own, tag + 2, su);
-      granule_publish(p.gran + 2 * kGranArr, own, tag + 3, sl);
+      granule_publish(loss_granules(p.gran, epoch), own, tag + 3, sl);
     }
     BSIG_USTAMP(9);
     if (own == 0 && w == 0) {
-      const float s = granule_gather(p.gran + 2 * kGranArr, p.n_owner, tag + 3, lane, flagp);
+      const float s = granule_gather(loss_granules(p.gran, epoch), p.n_owner, tag + 3, lane, flagp);
       if (lane == 0) {
         const float l = -s / (float)B;
         p.train_loss[step] = l;
@@ -663,7 +665,11 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
       }
     }
   }
-  if (tid == 0) red[63] = 0.f;
+  // the sticky time-out bit of an EARLIER launch of this call (a data-parallel rank makes one launch per
+  // update): sampled at entry, so that such a launch leaves at once instead of running its forward
+  // product into the bounded polls of owners that have already left
+  if (tid == 0)
+    red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
   if (has_tile && p.MT < kUMT)      // F^T columns of the m-tiles no wavefront writes (minibatches of <= 96 rows)
     for (int idx = tid; idx < p.KS * (kUFP / 4); idx += kUT) {
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -1201,7 +1207,7 @@ bool persist_eval_supported(const PersistShape& s) {
 static size_t u_data_bytes(const UGeom& g) {
   return round_up<size_t>((g.slab_floats + 2 * g.dout_floats + g.eval_floats) * sizeof(float), 256);
 }
-static size_t u_sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
+static size_t u_sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + 6 * kGranArr * 8; }
 
 size_t persist_workspace_bytes(const PersistShape& s) {
   const int v = persist_variant(s);

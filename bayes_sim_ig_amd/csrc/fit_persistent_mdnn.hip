@@ -213,7 +213,7 @@ static size_t mdnn_data_bytes(const MdnnGeom& g) {
   return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats + 2 * kPackFloats +
                            g.eval_floats + mdnn_wide_floats(g) + (g.stream ? g.act_floats : 0)) * sizeof(float), 256);
 }
-static size_t mdnn_sync_bytes() { return 14 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
+static size_t mdnn_sync_bytes() { return 14 * kFlagArr * sizeof(unsigned) + 6 * kGranArr * 8; }
 
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
   MdnnGeom g;

@@ -365,7 +365,11 @@ __device__ __forceinline__ void tile_workgroup(const PersistArgs& p, float* smem
     biasl[64 + n] = bv;
   };
 
-  if (tid == 0) red[63] = 0.f;
+  // the sticky time-out bit of an EARLIER launch of this call (a data-parallel rank makes one launch per
+  // update): sampled at entry, so that such a launch leaves at once instead of running its forward
+  // product into the bounded polls of owners that have already left
+  if (tid == 0)
+    red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
   // feature tile of the first update (later ones are fetched during the waits)
   BSIG_PF_LIST(BSIG_PF_DECL)
   if (p.n_updates > 0) {
@@ -752,11 +756,11 @@ __device__ __forceinline__ void owner_workgroup(const PersistArgs& p, float* sme
       float sl = 0.f, su = 0.f;
       for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
       granule_publish(p.gran + kGranArr, o, tag + 2, su);
-      granule_publish(p.gran + 2 * kGranArr, o, tag + 3, sl);
+      granule_publish(loss_granules(p.gran, epoch), o, tag + 3, sl);
     }
     BSIG_STAMP(9);
     if (o == 0 && w == 0) {
-      const float s = granule_gather(p.gran + 2 * kGranArr, p.n_owner, tag + 3, lane, flagp);
+      const float s = granule_gather(loss_granules(p.gran, epoch), p.n_owner, tag + 3, lane, flagp);
       if (lane == 0) {
         const float l = -s / (float)B;
         p.train_loss[step] = l;
@@ -882,7 +886,7 @@ bool persist_v1_eval_supported(const PersistShape& s) {
 static size_t data_bytes(const PersistGeom& g) {
   return round_up<size_t>((g.slab_floats + 2 * g.dout_floats + g.eval_floats) * sizeof(float), 256);
 }
-static size_t sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + 5 * kGranArr * 8; }
+static size_t sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + 6 * kGranArr * 8; }
 
 size_t persist_v1_workspace_bytes(const PersistShape& s) {
   PersistGeom g;

@@ -17,6 +17,7 @@ struct GemmParams {
   int epilogue = BSIG_EPI_NONE, act = 0;
   const float* bias = nullptr; const float* aux = nullptr; int64_t ldaux = 0; float alpha = 1.f;
   float* partial = nullptr;
+  int64_t partial_ld = 0, partial_slab = 0;   // split-K slabs with a row pitch (0: dense [m, n])
   // Row offsets resolved on the device (graph replay): logical row i of the
   // gathered / offset operand reads source index i + (dyn[0]+dyn_delta)*stride + base
   // (A: its M rows, or its contraction rows when k-major; same for B).

@@ -20,33 +20,37 @@
 // them in a fixed order and applies the epilogue: bitwise reproducible.
 #include <cstdlib>
 #include "gemm_kernel.h"
+#include "gemm_lean.h"
+#include "gemm_wide.h"
 
 namespace bsig {
 
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
   const int64_t total = (int64_t)p.m * p.n;
+  const int64_t slab = p.partial_ld ? p.partial_slab : total;
   float exp_acc = 0.f;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(e / p.n), col = (int)(e % p.n);
+    const int64_t pe = p.partial_ld ? (int64_t)row * p.partial_ld + col : e;   // (pitched slabs: gemm_wide.h)
     float v = 0.f;
     int z = 0;
     for (; z + 16 <= p.splits; z += 16) {   // 16 slab loads in flight, summed in slab order
       float q[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) q[u] = p.partial[(int64_t)(z + u) * total + e];
+      for (int u = 0; u < 16; ++u) q[u] = p.partial[(int64_t)(z + u) * slab + pe];
 #pragma unroll
       for (int u = 0; u < 16; ++u) v += q[u];
     }
     if (z + 8 <= p.splits) {
       float q[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) q[u] = p.partial[(int64_t)(z + u) * total + e];
+      for (int u = 0; u < 8; ++u) q[u] = p.partial[(int64_t)(z + u) * slab + pe];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v += q[u];
       z += 8;
     }
-    for (; z < p.splits; ++z) v += p.partial[(int64_t)z * total + e];
-    const int row = (int)(e / p.n), col = (int)(e % p.n);
+    for (; z < p.splits; ++z) v += p.partial[(int64_t)z * slab + pe];
     epilogue_store(p, row, col, v);
     if (p.expsum && p.epilogue == BSIG_EPI_BIAS && col >= p.expsum_col0 &&
         col < p.expsum_col0 + p.expsum_ncols)
@@ -249,6 +253,59 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
       return BSIG_OK;
     }
   }
+  // Large-minibatch products of a few-hundred-wide head (the scaled-batch update): whole-width tiles
+  // of 16x16x4 MFMAs (gemm_wide.h) -- forward O = X[ids] W^T and the gradient dW = dO^T X[ids] with
+  // dO at a pitch of ceil16(Nh) floats.  Split K so that the launch is one round of ~256 workgroups;
+  // the slabs are reduced (and the epilogue applied) by gemm_reduce_kernel as for every split product.
+  if (env_int("BSIG_GEMM_WIDE", 1) && workspace && p.k >= 1024 && p.k % BK == 0 && !p.a_unal && !p.b_unal) {
+    WideParams wp;
+    wp.dyn = p.dyn; wp.dyn_delta = p.dyn_delta; wp.k = p.k;
+    int rc = BSIG_EUNSUPPORTED;
+    auto split = [&](int64_t tiles, int64_t slab_floats) {
+      int64_t s = std::max<int64_t>((256 + tiles / 2) / tiles, 1);
+      s = std::min<int64_t>(s, std::max<int64_t>(p.k / (8 * BK), 1));
+      s = std::min<int64_t>(s, (int64_t)(workspace_bytes / (sizeof(float) * (size_t)slab_floats)));
+      if (s < 1) return false;
+      const int64_t chunk = round_up<int64_t>(ceil_div<int64_t>(p.k, s), BK);
+      wp.k_chunk = (int)chunk; wp.splits = (int)ceil_div<int64_t>(p.k, chunk);
+      wp.slab = slab_floats;
+      return true;
+    };
+    if (!p.a_kmajor && !p.b_kmajor && !p.b_rows && p.m >= 2048 && gemm_wide_covers(p.n) &&
+        pick_vec(p.a, p.lda) == 4 && pick_vec(p.b, p.ldb) == 4 && !p.b_dyn_stride && !p.b_dyn_base &&
+        (p.epilogue == BSIG_EPI_NONE || p.epilogue == BSIG_EPI_BIAS)) {
+      const int wide = ceil_div(p.n, 16) * 16;
+      if (split(ceil_div<int64_t>(p.m, 64), (int64_t)p.m * wide)) {
+        wp.wide = p.b; wp.ld_wide = p.ldb; wp.n_wide = p.n;
+        wp.x = p.a; wp.ldx = p.lda; wp.ids = p.a_rows; wp.n_narrow = p.m;
+        wp.dyn_stride = p.a_dyn_stride; wp.dyn_base = p.a_dyn_base;
+        wp.out = reinterpret_cast<float*>(workspace); wp.ld_out = wide;
+        rc = gemm_wide_forward(wp, st);
+        if (rc == BSIG_OK) { p.partial_ld = wide; p.partial_slab = wp.slab; }
+      }
+    } else if (p.a_kmajor && p.b_kmajor && !p.a_rows && p.k >= 2048 && gemm_wide_covers(p.m) &&
+               p.lda == ceil_div(p.m, 16) * 16 && p.n % 64 == 0 && pick_vec(p.a, p.lda) == 4 &&
+               pick_vec(p.b, p.ldb) == 4 && !p.a_dyn_stride && !p.a_dyn_base) {
+      if (split(p.n / 64, (int64_t)p.m * p.n)) {
+        wp.wide = p.a; wp.ld_wide = p.lda; wp.n_wide = p.m;
+        wp.x = p.b; wp.ldx = p.ldb; wp.ids = p.b_rows; wp.n_narrow = p.n;
+        wp.dyn_stride = p.b_dyn_stride; wp.dyn_base = p.b_dyn_base;
+        wp.out = reinterpret_cast<float*>(workspace); wp.ld_out = p.n;
+        rc = gemm_wide_gradient(wp, st);
+      }
+    }
+    if (rc == BSIG_OK) {
+      p.splits = wp.splits; p.k_chunk = wp.k_chunk;
+      p.partial = reinterpret_cast<float*>(workspace);
+      const int64_t total = (int64_t)p.m * p.n;
+      const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total, 256), 2048);
+      hipLaunchKernelGGL(gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+      BSIG_CHECK_LAUNCH("gemm_reduce");
+      if (n_expsum && p.expsum) *n_expsum = blocks;
+      return BSIG_OK;
+    }
+    if (rc != BSIG_EUNSUPPORTED) return rc;
+  }
   const GemmPlan pl = plan_gemm(p.m, p.n, p.k, workspace ? workspace_bytes : 0);
   p.splits = pl.splits; p.k_chunk = pl.k_chunk;
   p.partial = reinterpret_cast<float*>(workspace);
@@ -260,7 +317,24 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
   p.a_unal = unaligned_quads(p.a, p.lda, p.a_kmajor, p.k);
   p.b_unal = unaligned_quads(p.b, p.ldb, p.b_kmajor, p.k);
   const int avec = p.a_unal ? 4 : pick_vec(p.a, p.lda), bvec = p.b_unal ? 4 : pick_vec(p.b, p.ldb);
-  int rc;
+  int rc = BSIG_EUNSUPPORTED;
+  // the lean main loop (gemm_lean.h: bit-identical, no vector-ALU work in the K loop) wherever
+  // both operands move as aligned 16-byte items
+  const int lean = env_int("BSIG_GEMM_LEAN", 1);   // (read per call: tests compare the two kernels)
+  if (lean && avec == 4 && bvec == 4 && !p.a_unal && !p.b_unal) {
+    const bool akm = p.a_kmajor != 0, bkm = p.b_kmajor != 0;
+    switch (pl.tile) {
+      case TILE_64: rc = launch_lean_64(p, akm, bkm, st); break;
+      case TILE_128: rc = launch_lean_128(p, akm, bkm, st); break;
+      case TILE_128x32: rc = launch_lean_128x32(p, akm, bkm, st); break;
+      case TILE_128x64: rc = launch_lean_128x64(p, akm, bkm, st); break;
+      case TILE_128x96: rc = launch_lean_128x96(p, akm, bkm, st); break;
+      case TILE_96x128: rc = launch_lean_96x128(p, akm, bkm, st); break;
+      default: break;
+    }
+  }
+  if (rc != BSIG_EUNSUPPORTED) {
+  } else
   if (pl.tile == TILE_128)
     rc = launch_tile_128(p, p.a_kmajor != 0, p.b_kmajor != 0, avec, bvec, st);
   else if (pl.tile == TILE_128x32)

@@ -21,6 +21,14 @@ constexpr int kFlagStride = BSIG_XWG_STRIDE_BYTES / 4;   // dwords between two f
 constexpr int kGranStride = BSIG_XWG_STRIDE_BYTES / 8;   // 8-byte granules between two granules
 constexpr int kFlagArr = kXwgMax * kFlagStride;       // dwords of one flag array
 constexpr int kGranArr = kXwgMax * kGranStride;       // granule slots of one granule array
+// The per-update loss granules alternate between two arrays by update parity (arrays 2 and 5 of a
+// plan's six: Sigma exp | Sigma u dL/dsigma | loss (even updates) | evaluation x 2 | loss (odd)):
+// owner 0 gathers them by exact tag AFTER it has released the tile workgroups, so with one array a
+// delayed owner 0 could find a slot already carrying the next update's tag; the slot of update t is
+// now rewritten by update t + 2, which cannot start before owner 0 has published update t + 1.
+__device__ __forceinline__ unsigned long long* loss_granules(unsigned long long* gran, unsigned epoch) {
+  return gran + ((epoch & 1u) ? 5 : 2) * kGranArr;
+}
 
 struct HeadArgs {
   const float* seg_w; int64_t ld_w;    // logits (fused) or weights (tuple), K / row

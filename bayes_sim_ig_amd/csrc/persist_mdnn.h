@@ -45,8 +45,9 @@ bool persist_mdnn_supported(const PersistMdnnShape& s);
 // (diagnostics) the decomposition fit_persistent_mdnn.hip plans for a shape, bsig.h: bsig_debug_persist_mdnn_geometry
 int persist_mdnn_geometry(const PersistMdnnShape& s, int32_t* out);
 // ... with the first layer STREAMED by the tile workgroups (it does not fit the chip): such a plan
-// takes cross-correlation factor rows only, its Adam step of a data-parallel rank and its held-out
-// evaluations run outside the launches
+// takes cross-correlation factor rows only; the Adam step of a data-parallel rank runs outside the
+// launches (flat kernel after the all-reduce); a single rank's held-out evaluations run INSIDE its
+// one launch, from the held-out pairs' factor rows (bsig_fit_evaluates_from_factors)
 int persist_mdnn_streams(const PersistMdnnShape& s);
 // ... and S x A cross-correlation factor rows are covered (bsig.h: x_kind)
 bool persist_mdnn_accepts_factors(const PersistMdnnShape& s, int S, int A);

@@ -407,7 +407,11 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     biasl[64 + n] = bv;
   };
 
-  if (tid == 0) red[63] = 0.f;
+  // the sticky time-out bit of an EARLIER launch of this call (a data-parallel rank makes one launch per
+  // update): sampled at entry, so that such a launch leaves at once instead of running its forward
+  // product into the bounded polls of owners that have already left
+  if (tid == 0)
+    red[63] = (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) ? 1.f : 0.f;
   BSIG_MPF_LIST(BSIG_MPF_DECL)
   if (p.n_updates > 0) {
     const int64_t pf_row0 = (int64_t)step0 * B;
@@ -1648,7 +1652,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       float sl = 0.f, su = 0.f;
       for (int q = 0; q < MR; ++q) { sl += red[16 + q]; su += red[32 + q]; }
       granule_publish(p.gran + kGranArr, o, tag + 2, su);
-      granule_publish(p.gran + 2 * kGranArr, o, tag + 3, sl);
+      granule_publish(loss_granules(p.gran, epoch), o, tag + 3, sl);
     }
     BSIG_MSTAMP(13);
     float w2b[32];
@@ -1776,7 +1780,7 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       flag_raise(p.flag_own, o, epoch);
     BSIG_MSTAMP(15);
     if (o == 0 && w == 0) {
-      const float s = granule_gather(p.gran + 2 * kGranArr, p.n_owner, tag + 3, lane, flagp);
+      const float s = granule_gather(loss_granules(p.gran, epoch), p.n_owner, tag + 3, lane, flagp);
       if (lane == 0) {
         const float l = -s / (float)B;
         p.train_loss[step] = l;

@@ -284,6 +284,28 @@ def _profile_head(path):
     return None
 
 
+def _profile_csrc(path):
+    """The kernel-source hash a profile was taken on: its '# csrc: <hash>' line (tools/csrc_hash.py)."""
+    for line in open(path):
+        if line.startswith('# csrc:'):
+            return line.split(':', 1)[1].strip().split()[0]
+        if not line.startswith('#'):
+            break
+    return None
+
+
+def _csrc_changed_since(sha):
+    """Did bayes_sim_ig_amd/csrc or include/bsig.h change after commit `sha`?  None where git
+    cannot say (the GPU boxes have no history)."""
+    import subprocess
+    try:
+        r = subprocess.run(['git', '-C', ROOT, 'diff', '--quiet', sha, 'HEAD', '--',
+                            'bayes_sim_ig_amd/csrc', 'include/bsig.h'], capture_output=True)
+        return {0: False, 1: True}.get(r.returncode)
+    except OSError:
+        return None
+
+
 def _is_ancestor(sha):
     """Is `sha` an ancestor of HEAD?  None where that cannot be asked (no git, no history: the GPU
     boxes receive a snapshot of the tree without .git)."""
@@ -324,12 +346,30 @@ def pmc_traffic(kernel_substr):
     note = ''
     for h in heads:
         if h is None:
-            note = ' (no commit stamp: a profile of an earlier round)'
-            continue
+            return None, 'refused: %s carries no commit stamp (a profile of an earlier round)' % out['src_FETCH_SIZE']
         ok = _is_ancestor(h)
         if ok is False:
             return None, 'refused: %s was taken on %s, not an ancestor of HEAD' % (out['src_FETCH_SIZE'], h)
         note = ' (taken on %s%s)' % (h, '' if ok else ', ancestry not checkable here')
+    # an ancestor is not the same code: the profile must be OF these kernel sources -- by content
+    # hash where the profile carries one ("# csrc:", tools/csrc_hash.py; works without git), else
+    # by asking git whether csrc changed after the profile's commit
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from csrc_hash import csrc_hash
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        path = os.path.join(ROOT, 'profiles', out['src_' + ctr])
+        stamp = _profile_csrc(path)
+        if stamp is not None:
+            if stamp != csrc_hash():
+                return None, 'refused: %s is a profile of other kernel sources (csrc %s, tree %s)' % (
+                    out['src_' + ctr], stamp, csrc_hash())
+        else:
+            changed = _csrc_changed_since(out['head_' + ctr])
+            if changed:
+                return None, 'refused: kernel sources changed after %s was taken (on %s)' % (
+                    out['src_' + ctr], out['head_' + ctr])
+            if changed is None:
+                note += ' (UNVERIFIED: no source hash in the profile and no git history here)'
     return (2.0 * out['FETCH_SIZE'] + out['WRITE_SIZE']) * 1024.0, \
         '%s, %s%s' % (out['src_FETCH_SIZE'], out['src_WRITE_SIZE'], note)
 
@@ -451,7 +491,8 @@ def time_update_kernel(pkg, cfg, bsim, device):
     traffic, tsrc = pmc_traffic('linear_head_updates_kernel') if not dp else (None, None)
     geo = (C.c_int32 * 16)()
     tiling = None
-    if lib.bsig_debug_persist_geometry(batch, f_in, cfg['d'], cfg['k'], n_test, geo):
+    if lib.bsig_debug_persist_geometry(batch, f_in, cfg['d'], cfg['k'], n_test, geo) and geo[13] == 2:
+        # (geo[13]: the kernel that really runs -- 1 = fit_persistent_v1.hip, which this tiling does not describe)
         tiling = {'tile_rows': 16 * geo[0], 'k_slice': geo[1], 'head_blocks': geo[2], 'k_slices': geo[3],
                   'tile_workgroups': geo[4], 'workgroups': geo[5], 'row_owners': geo[6], 'rows_per_owner': geo[7],
                   'owners_that_hold_a_tile': geo[12], 'lds_bytes': geo[11]}

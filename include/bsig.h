@@ -355,14 +355,14 @@ int bsig_fit_accepts_factors(const bsig_fit_plan* plan);
  * Summary rows of that width run the per-phase kernels.  (summarizers.py:112-119 into
  * mdnn.py:71,108.) */
 int bsig_fit_accepts_factor_rows(const bsig_fit_plan* plan, int s_dim, int a_dim);
-/* 1: the plan's updates run in the persistent kernel for linear heads on cached
- * features (MDRFF), 2: in the one for the two-layer MDNN trunk (as bound), 0: as
- * per-phase kernels (diagnostics / tests). */
 /* 1 if a call bound with these factor rows (S, A) and bind flags evaluates its held-out pairs from
  * their FACTOR rows inside the launch (streamed first layer, single rank): nothing then reads
  * held-out summary rows -- bsig_fit_buffers.x_test may be NULL, and the caller need not expand the
  * held-out fifth of the chunk (84 MB per 1000-pair chunk of cfg/shadow_hand_more.yaml). */
 int bsig_fit_evaluates_from_factors(const bsig_fit_plan* plan, int s_dim, int a_dim, int bind_flags);
+/* 1: the plan's updates run in the persistent kernel for linear heads on cached
+ * features (MDRFF), 2: in the one for the two-layer MDNN trunk (as bound), 0: as
+ * per-phase kernels (diagnostics / tests). */
 int bsig_fit_is_persistent(const bsig_fit_plan* plan);
 int bsig_fit_eval(bsig_fit_plan* plan, bsig_stream_t stream);
 
@@ -435,8 +435,10 @@ int bsig_debug_spin(int blocks, size_t lds_bytes, int ms, bsig_stream_t stream);
  * host arithmetic only, no device is asked.  out[16] = { NT (16-row blocks per tile), k-slice
  * width, head blocks, k-slices, tile workgroups G, workgroups of the launch T, row owners, rows per
  * owner, evaluation owners, rows per evaluation owner, evaluation passes (0: evaluations outside
- * the launches), LDS bytes per workgroup, owners that also hold a tile, 0, 0, 0 }.
- * Returns 1 if the shape is covered, 0 if not. */
+ * the launches), LDS bytes per workgroup, owners that also hold a tile, the kernel a launch of this
+ * shape would run on THIS process's device (2: this tiling, 1: the round-1..3 kernel
+ * fit_persistent_v1.hip -- the tiling above then does not describe it --, 0: per-phase kernels or
+ * no device), 0, 0 }.  Returns 1 if the shape is covered, 0 if not. */
 int bsig_debug_persist_geometry(int batch, int feat_dim, int out_dim, int n_comp, int max_test,
                                 int32_t* out);
 /* ... and how the persistent update kernel of the two-layer MDNN (trunk [128, 128], tanh; the reference's

@@ -16,7 +16,7 @@ Two independent evaluations are given so they can check each other:
   * ``signature``       — Chen's identity, S <- S (x) exp(delta) per segment
   * ``signature_brute`` — numpy fp64 iterated sums straight from the
                           definition for piecewise-linear paths (depth <= 3)
-Known-answer vectors are in tests/test_oracle_signature.py.
+Known-answer vectors are in tests/test_oracle_summaries.py.
 """
 import numpy as np
 import torch

@@ -7,6 +7,7 @@ TAG=${1:-rXX}
 HEADSHA=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
+CSRC=$(python3 "$R/tools/csrc_hash.py")
 mkdir -p "$OUT"
 cd "$R"
 python3 bench.py > "$OUT/${TAG}_bench_line.json" 2> "$OUT/${TAG}_bench_stderr.log"
@@ -24,6 +25,6 @@ BSIG_PROF_T0=50 python3 tools/persist_prof.py 2>&1 | grep -v "amdgpu.ids" > "$OU
 python3 tools/persist_prof.py cfg2 2>&1 | grep -v "amdgpu.ids" > "$OUT/${TAG}_cfg2_update_timeline.txt"
 for f in bench_line.json yaml_configs.txt anymal_update_timeline.txt shadow_more_update_timeline.txt cfg3_update_timeline.txt \
          cfg5_update_timeline.txt cfg5_update_timeline_warm.txt cfg2_update_timeline.txt summarizer_bench.txt fill_bench.txt gemm_heldout_sweep.txt; do
-  [ -f "$OUT/${TAG}_$f" ] && [ "${f##*.}" = txt ] && sed -i "1i # head: $HEADSHA" "$OUT/${TAG}_$f"
+  [ -f "$OUT/${TAG}_$f" ] && [ "${f##*.}" = txt ] && sed -i "1i # head: $HEADSHA\n# csrc: $CSRC" "$OUT/${TAG}_$f"
 done
 bash tools/round_profiles.sh "$TAG" "$HEADSHA"

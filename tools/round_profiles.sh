@@ -16,6 +16,7 @@ TAG=${1:-rXX}
 HEADSHA=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
+CSRC=$(python3 "$R/tools/csrc_hash.py")
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, program, args...
@@ -25,7 +26,7 @@ run_stats() {   # name, program, args...
   local db=$(find /tmp/p_$name -name "*.db" | head -1)
   python3 $R/tools/rocprof_summary.py "$db" $OUT/${TAG}_${name}_kernel_stats.txt \
     "$TAG: rocprofv3 --kernel-trace --stats -- python $prog $*"
-  sed -i "1i # head: $HEADSHA" $OUT/${TAG}_${name}_kernel_stats.txt
+  sed -i "1i # head: $HEADSHA\n# csrc: $CSRC" $OUT/${TAG}_${name}_kernel_stats.txt
   if [ "$prog" = bench.py ]; then
     python3 $R/tools/chunk_timeline.py "$db" $OUT/${TAG}_${name}_chunk_timeline.txt > /dev/null 2>&1 || true
   fi
@@ -37,7 +38,7 @@ run_pmc() {     # name, counter, program, args...
   local db=$(find /tmp/c_${name}_$ctr -name "*.db" | head -1)
   python3 $R/tools/pmc_dump.py "$db" $OUT/${TAG}_${name}_pmc_$ctr.txt \
     "rocprofv3 --pmc $ctr --kernel-trace -- python $prog $*"
-  sed -i "1i # head: $HEADSHA" $OUT/${TAG}_${name}_pmc_$ctr.txt
+  sed -i "1i # head: $HEADSHA\n# csrc: $CSRC" $OUT/${TAG}_${name}_pmc_$ctr.txt
 }
 B5="--steps 1 --warmup 1 --no-cpu-baseline --no-scaled-batch --no-per-config --no-largest-size"
 run_stats cfg5 bench.py $B5
