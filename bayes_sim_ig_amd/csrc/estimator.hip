@@ -88,13 +88,17 @@ struct Scratch {
   float* feat;                      // [B, F] RFF features (MDRFF, not hoisted)
   float* h[BSIG_MAX_HIDDEN];        // trunk activations [B, hidden_l]
   float* dz[2];                     // ping-pong [B, max hidden]
-  float* o;                         // [B, Nh] raw head outputs
-  float* d_o;                       // [B, Nh]
+  float* o;                         // [B, ld_o] raw head outputs
+  float* d_o;                       // [B, ld_o]
+  int64_t ld_o;                     // Nh -- or ceil16(Nh) where the whole-width products take these buffers (gemm_wide.h)
+  int32_t* tickets;                 // kWideTickets zeroed words: in-launch combine of the head product's K slices
   float* head_ws; size_t head_ws_bytes;
   float* gemm_ws; size_t gemm_ws_bytes;
   float* colsum_ws; size_t colsum_ws_bytes;
   size_t total_bytes;
 };
+
+constexpr int kWideTickets = 1024;
 
 static size_t gemm_ws_need(const bsig_mdn_cfg* c, const Layout& L, int64_t B) {
   size_t need = 0;
@@ -128,8 +132,12 @@ static void carve(const bsig_mdn_cfg* c, const Layout& L, int64_t B, void* base,
   }
   s->dz[0] = hmax ? take((size_t)B * hmax) : nullptr;
   s->dz[1] = hmax ? take((size_t)B * hmax) : nullptr;
-  s->o = take((size_t)B * L.nh);
-  s->d_o = take((size_t)B * L.nh);
+  // large minibatches of a head the whole-width kernels cover: pitch ceil16(Nh) (dO is their k-major
+  // operand at exactly that pitch; the forward product stores the padded width)
+  s->ld_o = (B >= 2048 && gemm_wide_covers((int)L.nh) && B <= 64 * (int64_t)kWideTickets) ? round_up<int64_t>(L.nh, 16) : L.nh;
+  s->o = take((size_t)B * s->ld_o);
+  s->d_o = take((size_t)B * s->ld_o);
+  s->tickets = reinterpret_cast<int32_t*>(take(kWideTickets));
   s->head_ws_bytes = bsig_head_workspace_bytes(&c->head, B);
   s->head_ws = take(s->head_ws_bytes / sizeof(float) + 1);
   s->gemm_ws_bytes = gemm_ws_need(c, L, B);
@@ -212,6 +220,7 @@ static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* par
   g.c = o; g.ldc = ldo;
   g.m = (int)B; g.n = (int)L.nh; g.k = (int)L.feat_dim;
   g.epilogue = BSIG_EPI_BIAS; g.bias = params + L.head_b_off;
+  if (o == s.o) g.combine_tickets = s.tickets;   // (the scratch buffer has the padded pitch the combine stores)
   if (n_sig && c->head.eps_noise != 0.f) {   // sum(exp(pre_diag)) partials for the jitter scale
     g.expsum = s.head_ws;
     g.expsum_col0 = c->head.n_comp + c->head.out_dim * c->head.n_comp;
@@ -225,12 +234,12 @@ static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* par
 }
 
 // dW[nout, nin] = dY^T X (+ fused Adam) for one layer
-static int weight_grad(const float* dy, int64_t nout, const float* xin, int64_t ldin,
+static int weight_grad(const float* dy, int64_t nout, int64_t ld_dy, const float* xin, int64_t ldin,
                        const Inputs* src, int delta, int64_t nin, int64_t B, float* params,
                        float* grads, int64_t w_off, int64_t b_off, const AdamFuse* fuse,
                        const Scratch& s, hipStream_t st) {
   GemmParams g;
-  g.a = dy; g.lda = nout; g.a_kmajor = 1;
+  g.a = dy; g.lda = ld_dy; g.a_kmajor = 1;
   set_src_b_kmajor(g, xin, ldin, src, delta);
   g.m = (int)nout; g.n = (int)nin; g.k = (int)B; g.ldc = nin;
   if (fuse) {
@@ -260,7 +269,7 @@ static int backward_pass(const bsig_mdn_cfg* c, const Layout& L, float* params,
   int cur = 0;
   if (L.n_layers > 0) {   // dz_L = (dO W_heads) * act'(h_L)   [reads W_heads]
     GemmParams g;
-    g.a = s.d_o; g.lda = L.nh;
+    g.a = s.d_o; g.lda = s.ld_o;
     g.b = params + L.head_w_off; g.ldb = L.feat_dim; g.b_kmajor = 1;
     g.c = s.dz[cur]; g.ldc = L.feat_dim;
     g.m = (int)B; g.n = (int)L.feat_dim; g.k = (int)L.nh;
@@ -268,7 +277,7 @@ static int backward_pass(const bsig_mdn_cfg* c, const Layout& L, float* params,
     BSIG_TRY(gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st));
   }
   // heads: dW = dO^T feat (bias gradient = column sums of dO, from the finish kernel)
-  BSIG_TRY(weight_grad(s.d_o, L.nh, feat, ldf, fsrc, delta, L.feat_dim, B, params, grads,
+  BSIG_TRY(weight_grad(s.d_o, L.nh, s.ld_o, feat, ldf, fsrc, delta, L.feat_dim, B, params, grads,
                        L.head_w_off, L.head_b_off, fuse, s, st));
   for (int l = L.n_layers - 1; l >= 0; --l) {
     const int64_t hw = c->hidden[l];
@@ -286,7 +295,7 @@ static int backward_pass(const bsig_mdn_cfg* c, const Layout& L, float* params,
       g.epilogue = BSIG_EPI_MUL_DACT; g.act = c->activation; g.aux = xin; g.ldaux = ldin;
       BSIG_TRY(gemm_run(g, s.gemm_ws, s.gemm_ws_bytes, st));
     }
-    BSIG_TRY(weight_grad(s.dz[cur], hw, xin, ldin, xsrc, delta, L.in_dim[l], B, params, grads,
+    BSIG_TRY(weight_grad(s.dz[cur], hw, hw, xin, ldin, xsrc, delta, L.in_dim[l], B, params, grads,
                          L.w_off[l], L.b_off[l], fuse, s, st));
     cur ^= 1;
   }
@@ -300,10 +309,10 @@ static int head_nll(const bsig_mdn_cfg* c, const Layout& L, const Scratch& s, co
                     float* head_bias_grad, int32_t* nonfinite, const HeadDyn* dyn,
                     hipStream_t st) {
   const int64_t D = c->head.out_dim, K = c->head.n_comp;
-  return mdn_head_nll_launch(&c->head, s.o, L.nh, s.o + K, L.nh, s.o + K + D * K, L.nh,
-                             c->head.full_cov ? s.o + K + 2 * D * K : nullptr, L.nh, 0, y, ldy,
+  return mdn_head_nll_launch(&c->head, s.o, s.ld_o, s.o + K, s.ld_o, s.o + K + D * K, s.ld_o,
+                             c->head.full_cov ? s.o + K + 2 * D * K : nullptr, s.ld_o, 0, y, ldy,
                              y_rows, B, norm_batch, noise, seed, stream_id, dyn_rng, loss,
-                             loss_slot, bwd ? s.d_o : nullptr, L.nh,
+                             loss_slot, bwd ? s.d_o : nullptr, s.ld_o,
                              bwd ? head_bias_grad : nullptr, nonfinite, s.head_ws,
                              s.head_ws_bytes, st, dyn);
 }
@@ -369,6 +378,7 @@ struct bsig_fit_plan {
   int64_t norm_batch;
   size_t train_ws_bytes, test_ws_bytes, feats_bytes, big_gemm_ws_bytes, iota_bytes;
   bool use_graph, split_adam;
+
   bool persistent;             // updates run in the persistent kernel (persist.h)
   bool persistent_mdnn;        // single-rank MDNN [128, 128] updates: fit_persistent_mdnn.hip
   bool persistent_mdnn_cap;    // ... the plan's shape is covered (persistent_mdnn: this binding is)
@@ -397,6 +407,15 @@ static size_t plan_ws_bytes(const bsig_fit_plan* p) {
 
 struct PlanMem { Scratch tr, te; float* feats; float* big_ws; int32_t* iota; void* persist_ws; };
 
+// fit_begin_kernel clears up to four regions: the persistent kernels' exchange areas (2), the Adam
+// moments (2; not where a single-rank persistent plan starts them in registers) -- and, where that
+// leaves room, the combine tickets of the two scratch areas (gemm_wide.h; else: no combine)
+static int begin_regions(const bsig_fit_plan* p) {
+  const bool pers = p->persistent || p->persistent_mdnn;
+  return (pers ? 2 : 0) + (!(pers && !p->split_adam) ? 2 : 0);
+}
+static bool tickets_zeroed(const bsig_fit_plan* p) { return begin_regions(p) + 2 <= 4; }
+
 static void plan_mem(const bsig_fit_plan* p, PlanMem* m) {
   char* base = reinterpret_cast<char*>(p->buf.workspace);
   carve(&p->cfg, p->L, p->batch, base, &m->tr);
@@ -408,6 +427,7 @@ static void plan_mem(const bsig_fit_plan* p, PlanMem* m) {
   m->big_ws = reinterpret_cast<float*>(base); base += p->big_gemm_ws_bytes;
   m->iota = reinterpret_cast<int32_t*>(base); base += p->iota_bytes;
   m->persist_ws = base;
+  if (!tickets_zeroed(p)) m->tr.tickets = m->te.tickets = nullptr;
 }
 
 static PersistShape persist_shape(const bsig_fit_plan* p) {
@@ -533,7 +553,7 @@ static int enqueue_grad(bsig_fit_plan* p, hipStream_t st, bool fuse_adam) {
                 p->cfg.beta1, p->cfg.beta2, p->cfg.adam_eps};
   const uint64_t* rng = reinterpret_cast<const uint64_t*>(b.state + ST_RNG);
   int n_sig = 0;
-  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, p->batch, m.tr, m.tr.o, p->L.nh, st,
+  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, p->batch, m.tr, m.tr.o, m.tr.ld_o, st,
                         &n_sig));
   hd.n_sig_ready = n_sig;
   BSIG_TRY(head_nll(&p->cfg, p->L, m.tr, b.y_train, b.ldy_train, b.ids_table, p->batch,
@@ -562,7 +582,7 @@ static int enqueue_eval(bsig_fit_plan* p, hipStream_t st) {
   }
   const Inputs in = eval_inputs(p, m);
   int n_sig = 0;
-  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, b.n_test, m.te, m.te.o, p->L.nh, st,
+  BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, b.n_test, m.te, m.te.o, m.te.ld_o, st,
                         &n_sig));
   hd.n_sig_ready = n_sig;
   return head_nll(&p->cfg, p->L, m.te, b.y_test, b.ldy_test, nullptr, b.n_test, b.n_test,
@@ -686,6 +706,7 @@ extern "C" int bsig_mdn_head_forward(const bsig_mdn_cfg* cfg, const float* param
   BSIG_REQUIRE(workspace && workspace_bytes >= s.total_bytes,
                "head_forward: workspace %zu < %zu", workspace_bytes, s.total_bytes);
   carve(cfg, L, batch, workspace, &s);
+  s.tickets = nullptr;   // (nobody zeroes a caller's workspace: the head product reduces in its own kernel)
   Inputs in;
   in.x = x; in.ldx = ldx; in.rows = x_rows;
   in.rff_coeff = rff_coeff; in.ld_coeff = ld_coeff; in.rff_offset = rff_offset;
@@ -710,12 +731,13 @@ extern "C" int bsig_mdn_loss_grad(const bsig_mdn_cfg* cfg, const float* params,
   BSIG_REQUIRE(workspace && workspace_bytes >= s.total_bytes, "loss_grad: workspace %zu < %zu",
                workspace_bytes, s.total_bytes);
   carve(cfg, L, batch, workspace, &s);
+  s.tickets = nullptr;   // (nobody zeroes a caller's workspace: the head product reduces in its own kernel)
   hipStream_t st = as_stream(stream);
   Inputs in;
   in.x = x; in.ldx = ldx; in.rows = rows;
   in.rff_coeff = rff_coeff; in.ld_coeff = ld_coeff; in.rff_offset = rff_offset;
   int n_sig = 0;
-  BSIG_TRY(forward_pass(cfg, L, params, in, batch, s, s.o, L.nh, st, &n_sig));
+  BSIG_TRY(forward_pass(cfg, L, params, in, batch, s, s.o, s.ld_o, st, &n_sig));
   HeadDyn hd;
   hd.n_sig_ready = n_sig;
   BSIG_TRY(head_nll(cfg, L, s, y, ldy, rows, batch, norm_batch, noise, seed, stream_id, nullptr,
@@ -930,6 +952,14 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
                  "fit_begin: the Adam moment buffers must be 16-byte aligned");
     add_zero(p->buf.exp_avg, (size_t)p->L.total * sizeof(float));
     add_zero(p->buf.exp_avg_sq, (size_t)p->L.total * sizeof(float));
+  }
+  // the combine tickets of the whole-width head products (left zeroed by every launch that uses
+  // them; zeroed here once more per call -- where the kernel's four regions have room)
+  if (tickets_zeroed(p)) {
+    BSIG_REQUIRE(nz == begin_regions(p), "fit_begin: region count out of step with begin_regions()");
+    PlanMem tm; plan_mem(p, &tm);
+    add_zero(tm.tr.tickets, kWideTickets * sizeof(int32_t));
+    add_zero(tm.te.tickets, kWideTickets * sizeof(int32_t));
   }
   const int blocks = (int)std::min<int64_t>(std::max<int64_t>(ceil_div<int64_t>(total4, 256 * 4), 1), 1024);
   hipLaunchKernelGGL(fit_begin_kernel, dim3(blocks), dim3(256), 0, st, p->buf.state, seed, bz);

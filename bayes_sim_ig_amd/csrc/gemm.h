@@ -18,6 +18,10 @@ struct GemmParams {
   const float* bias = nullptr; const float* aux = nullptr; int64_t ldaux = 0; float alpha = 1.f;
   float* partial = nullptr;
   int64_t partial_ld = 0, partial_slab = 0;   // split-K slabs with a row pitch (0: dense [m, n])
+  // whole-width forward product (gemm_wide.h) with BSIG_EPI_BIAS: combine the K slices inside the
+  // launch instead of in gemm_reduce_kernel.  >= ceil(m / 64) zeroed int32 (left zeroed); c must
+  // have a pitch of at least ceil16(n) floats (every column of the padded width is stored).
+  int32_t* combine_tickets = nullptr;
   // Row offsets resolved on the device (graph replay): logical row i of the
   // gathered / offset operand reads source index i + (dyn[0]+dyn_delta)*stride + base
   // (A: its M rows, or its contraction rows when k-major; same for B).
@@ -41,6 +45,9 @@ struct GemmParams {
   // set by gemm_run / the kernel: XCD-aware workgroup -> tile remap, the K split of this workgroup
   int xcd_swz = 0, bid_z = 0;
 };
+
+// the head widths the whole-width kernels of gemm_wide.h are instantiated for
+bool gemm_wide_covers(int n_wide);
 
 // n_expsum (optional) receives the number of expsum partials written.
 int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st,

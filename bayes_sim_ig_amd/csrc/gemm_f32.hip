@@ -63,6 +63,77 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
   }
 }
 
+// The same reduction for a fused Adam step (EPI_ADAM: dW slabs -> one optimizer step on the weights),
+// four adjacent columns per thread: 16-byte loads of the slabs and of the optimizer state, all in
+// flight before the first dependent instruction.  Same arithmetic per element as epilogue_store's
+// EPI_ADAM branch (slab order, then the identical expressions): bit-identical to the scalar kernel.
+__global__ __launch_bounds__(256) void gemm_reduce_adam4_kernel(GemmParams p) {
+  const int n4 = p.n >> 2;
+  const int64_t total4 = (int64_t)p.m * n4;
+  const int64_t slab = p.partial_ld ? p.partial_slab : (int64_t)p.m * p.n;
+  const float ss = p.adam_dyn[0], ib = p.adam_dyn[1];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(e / n4), col = (int)(e % n4) * 4;
+    const int64_t pe = p.partial_ld ? (int64_t)row * p.partial_ld + col : (int64_t)row * p.n + col;
+    const int64_t ce = (int64_t)row * p.ldc + col;
+    F4 g{{0.f, 0.f, 0.f, 0.f}};
+    const F4 pm = ld4(p.adam_m + ce), pv = ld4(p.adam_v + ce), pp = ld4(p.c + ce);
+    int z = 0;
+    for (; z + 4 <= p.splits; z += 4) {
+      F4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = ld4(p.partial + (int64_t)(z + u) * slab + pe);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) g.v[c] += q[u].v[c];
+    }
+    for (; z < p.splits; ++z) {
+      const F4 q = ld4(p.partial + (int64_t)z * slab + pe);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g.v[c] += q.v[c];
+    }
+    if (p.grad_out) st4(p.grad_out + ce, g);
+    F4 m1, v1, p1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      m1.v[c] = pm.v[c] + (g.v[c] - pm.v[c]) * (1.0f - p.beta1);
+      v1.v[c] = pv.v[c] * p.beta2 + (1.0f - p.beta2) * g.v[c] * g.v[c];
+      p1.v[c] = pp.v[c] - ss * (m1.v[c] / (sqrtf(v1.v[c]) * ib + p.adam_eps));
+    }
+    st4(p.adam_m + ce, m1); st4(p.adam_v + ce, v1); st4(p.c + ce, p1);
+    if (col == 0 && p.bias_p) {
+      const float bg = p.bias_g[row];
+      const float bm = p.bias_m[row] + (bg - p.bias_m[row]) * (1.0f - p.beta1);
+      const float bv = p.bias_v[row] * p.beta2 + (1.0f - p.beta2) * bg * bg;
+      p.bias_m[row] = bm;
+      p.bias_v[row] = bv;
+      p.bias_p[row] = p.bias_p[row] - ss * (bm / (sqrtf(bv) * ib + p.adam_eps));
+    }
+  }
+}
+
+// (the reduce of a split product: the 16-byte kernel where it applies)
+static int launch_reduce(const GemmParams& p, hipStream_t st, int* n_expsum) {
+  const int64_t total = (int64_t)p.m * p.n;
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool adam4 = p.epilogue == EPI_ADAM && (p.n & 3) == 0 && (p.ldc & 3) == 0 && (p.partial_ld & 3) == 0 &&
+                     (p.partial_slab & 3) == 0 && al(p.partial) && al(p.c) && al(p.adam_m) && al(p.adam_v) &&
+                     (!p.grad_out || al(p.grad_out)) && getenv("BSIG_GEMM_NO_ADAM4") == nullptr;
+  if (adam4) {
+    const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total / 4, 256), 2048);
+    hipLaunchKernelGGL(gemm_reduce_adam4_kernel, dim3(blocks), dim3(256), 0, st, p);
+    BSIG_CHECK_LAUNCH("gemm_reduce_adam4");
+    return BSIG_OK;
+  }
+  const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total, 256), 2048);
+  hipLaunchKernelGGL(gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+  BSIG_CHECK_LAUNCH("gemm_reduce");
+  if (n_expsum && p.expsum) *n_expsum = blocks;
+  return BSIG_OK;
+}
+
 // Debug instantiation (BSIG_DEBUG_F64_ACC_MIN_K=<k>): a product whose contraction is at least <k>
 // long is formed by one thread per output element with the products and their sum in fp64, rounded
 // to fp32 once -- the value every fp32 summation order of the same operands approximates.  Same
@@ -280,7 +351,18 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
         wp.x = p.a; wp.ldx = p.lda; wp.ids = p.a_rows; wp.n_narrow = p.m;
         wp.dyn_stride = p.a_dyn_stride; wp.dyn_base = p.a_dyn_base;
         wp.out = reinterpret_cast<float*>(workspace); wp.ld_out = wide;
+        const bool combine = p.combine_tickets && p.epilogue == BSIG_EPI_BIAS && p.ldc >= wide &&
+                             (p.ldc & 3) == 0 && aligned(p.c, 16) && wp.slab < ((int64_t)1 << 31) &&
+                             env_int("BSIG_GEMM_NO_COMBINE", 0) == 0;
+        if (combine) {
+          wp.tickets = p.combine_tickets; wp.bias = p.bias; wp.final_out = p.c; wp.ld_final = p.ldc;
+          wp.expsum = p.expsum; wp.expsum_col0 = p.expsum_col0; wp.expsum_ncols = p.expsum_ncols;
+        }
         rc = gemm_wide_forward(wp, st);
+        if (rc == BSIG_OK && combine) {
+          if (n_expsum && p.expsum) *n_expsum = ceil_div(p.m, 64);
+          return BSIG_OK;
+        }
         if (rc == BSIG_OK) { p.partial_ld = wide; p.partial_slab = wp.slab; }
       }
     } else if (p.a_kmajor && p.b_kmajor && !p.a_rows && p.k >= 2048 && gemm_wide_covers(p.m) &&
@@ -297,12 +379,7 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     if (rc == BSIG_OK) {
       p.splits = wp.splits; p.k_chunk = wp.k_chunk;
       p.partial = reinterpret_cast<float*>(workspace);
-      const int64_t total = (int64_t)p.m * p.n;
-      const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total, 256), 2048);
-      hipLaunchKernelGGL(gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
-      BSIG_CHECK_LAUNCH("gemm_reduce");
-      if (n_expsum && p.expsum) *n_expsum = blocks;
-      return BSIG_OK;
+      return launch_reduce(p, st, n_expsum);
     }
     if (rc != BSIG_EUNSUPPORTED) return rc;
   }
@@ -356,11 +433,7 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
   if (rc != BSIG_OK) return rc;
   BSIG_CHECK_LAUNCH("gemm_mfma");
   if (p.splits > 1) {
-    const int64_t total = (int64_t)p.m * p.n;
-    const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total, 256), 2048);
-    hipLaunchKernelGGL(gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
-    BSIG_CHECK_LAUNCH("gemm_reduce");
-    if (n_expsum && p.expsum) *n_expsum = blocks;
+    BSIG_TRY(launch_reduce(p, st, n_expsum));
   } else if (n_expsum && p.expsum) {
     const int bm = kTileM[pl.tile], bn = kTileN[pl.tile];
     *n_expsum = ceil_div(p.m, bm) * ceil_div(p.n, bn);

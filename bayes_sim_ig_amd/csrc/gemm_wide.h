@@ -30,6 +30,7 @@
 // columns carry the products of clamped rows) or [z][Nh][F] (gradient).
 #pragma once
 #include "gemm_kernel.h"
+#include "persist_device.h"
 
 #include <type_traits>
 
@@ -45,6 +46,16 @@ struct WideParams {
   int n_narrow = 0;     // forward: B; gradient: F
   int k = 0, k_chunk = 0, splits = 1;
   float* out = nullptr; int64_t ld_out = 0; int64_t slab = 0;   // floats between two K slices' slabs
+  // forward only: combine the K slices INSIDE the launch.  Every workgroup writes its slab through,
+  // draws a ticket of its narrow tile; the last of the tile's `splits` workgroups sums the slabs in
+  // slice order (its own from its registers), adds the bias and stores final[b][0 .. NWT*16) -- no
+  // reduce kernel, and with expsum one partial sum of exp(final[b][c]) over c in [expsum_col0,
+  // expsum_col0 + expsum_ncols) per narrow tile (the jitter scale of the head, mdnn.py:115).
+  // tickets: one zeroed int32 per narrow tile; the last arriver leaves it zeroed.
+  int32_t* tickets = nullptr;
+  const float* bias = nullptr;      // [n_wide]
+  float* final_out = nullptr; int64_t ld_final = 0;
+  float* expsum = nullptr; int expsum_col0 = 0, expsum_ncols = 0;
 };
 
 constexpr int kWidePitch = 40;   // k-contiguous LDS rows (BK = 32 + 8): conflict-free 16x16x4 fragment reads
@@ -195,8 +206,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int j = 0; j < CNT; ++j)
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(nf[u], wf[u][j], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (CNT + 1), 0);   // DS reads
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * CNT, 0);         // MFMAs
         return;
       }
       const float4 nv = *reinterpret_cast<const float4*>(st + (nt * 16 + c16) * kWidePitch + kb * 16 + 4 * g);
@@ -235,6 +244,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       commit(nxt);
       fetch();
       compute(cur, 1);
+      // The order of the step, pinned (sched_group_barrier: MFMA 0x008, DS read 0x100, DS write 0x200,
+      // VMEM read 0x020).  Left to itself the scheduler put the six LDS stores of the next tile, each
+      // behind its own wait, right after the first MFMA (and, k-major, every ds_read_b32 next to its
+      // MFMA): the matrix pipe idled through them at the top of every step.
+      //   first 16 k : operands | MFMAs with one LDS store of the next tile after every 4th |
+      //                the rest of the MFMAs with the second 16 k's operand reads between them
+      //   second 16 k: MFMAs with one global load of the tile after next after every 4th | the rest
+      constexpr int NR = KMAJ ? 4 * (CNT + 1) : CNT + 1;   // (upper bound on the LDS reads of 16 k)
+      constexpr int NM = 4 * CNT, NW = 1 + kWRegs, NL = NW + (KMAJ ? 1 : 0);
+      constexpr int REST0 = NM - 4 * NW;
+      static_assert(REST0 > 0, "fewer MFMAs than LDS stores to spread");
+      __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < REST0; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (NR + REST0 - 1) / REST0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
       __syncthreads();
     };
     int kt = 0;
@@ -251,7 +289,65 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* out = p.out + (int64_t)by * p.slab;
     if constexpr (!KMAJ) {
       const int b = n0 + nt * 16 + c16;
-      if (b < p.n_narrow) {
+      if (p.tickets) {
+        // ---- in-launch combine of the K slices (see WideParams) ----
+        const int nsp = (int)gridDim.y;
+        const int boff = (int)((int64_t)min(b, p.n_narrow - 1) * p.ld_out) + wt0 * 16 + 4 * g;   // < 2^31 floats: the launcher checks
+        if (nsp > 1) {
+          const __amdgpu_buffer_rsrc_t rs = xwg_buffer(out);
+          if (b < p.n_narrow) {
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) xwg_store4(rs, boff + 16 * j, acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();           // (also: nobody reads an LDS image any more)
+        if (tid == 0) {
+          int old = nsp - 1;
+          if (nsp > 1) {
+            old = __hip_atomic_fetch_add(p.tickets + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == nsp - 1) __hip_atomic_store(p.tickets + bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          reinterpret_cast<int*>(wsm)[0] = old;
+        }
+        __syncthreads();
+        const bool last = reinterpret_cast<const int*>(wsm)[0] == nsp - 1;
+        float esum = 0.f;
+        if (last && b < p.n_narrow) {
+          floatx4 v[CNT];
+#pragma unroll
+          for (int j = 0; j < CNT; ++j) v[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+          for (int z = 0; z < nsp; ++z) {        // slice order, whoever arrives last
+            if (z == by) {
+#pragma unroll
+              for (int j = 0; j < CNT; ++j) v[j] += acc[j];
+            } else {
+              const __amdgpu_buffer_rsrc_t rz = xwg_buffer(p.out + (int64_t)z * p.slab);
+              f32x4 q[CNT];
+#pragma unroll
+              for (int j = 0; j < CNT; ++j) q[j] = xwg_load4(rz, boff + 16 * j);
+#pragma unroll
+              for (int j = 0; j < CNT; ++j) v[j] += q[j];
+            }
+          }
+          float* dst = p.final_out + (int64_t)b * p.ld_final + wt0 * 16 + 4 * g;
+#pragma unroll
+          for (int j = 0; j < CNT; ++j) {
+            const int col = (wt0 + j) * 16 + 4 * g;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float o = v[j][c] + (col + c < p.n_wide ? p.bias[col + c] : 0.f);
+              v[j][c] = o;
+              if (p.expsum && col + c >= p.expsum_col0 && col + c < p.expsum_col0 + p.expsum_ncols) esum += expf(o);
+            }
+            *reinterpret_cast<floatx4*>(dst + 16 * j) = v[j];
+          }
+        }
+        if (p.expsum && reinterpret_cast<const int*>(wsm)[0] == nsp - 1) {
+          const float s = block_sum(esum, wsm + 16);   // fixed order: bitwise reproducible
+          if (tid == 0) p.expsum[bx] = s;
+        }
+      } else if (b < p.n_narrow) {
 #pragma unroll
         for (int j = 0; j < CNT; ++j)
           *reinterpret_cast<floatx4*>(out + (int64_t)b * p.ld_out + (wt0 + j) * 16 + 4 * g) = acc[j];

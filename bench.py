@@ -734,7 +734,8 @@ def scaled_gemm_roofline(pkg, cfg, m, batch, nh, device):
     ids = torch.randint(0, pool, (batch,), device=device, dtype=torch.int32)
     w = torch.randn(n_out, L.round_up(k_in, 4), device=device)
     o = torch.empty(batch, n_out, device=device)
-    d_o = torch.randn(batch, n_out, device=device)
+    # (dO at the pitch the fit engine keeps it at: ceil16(Nh), the whole-width gradient kernel's operand layout)
+    d_o = torch.randn(batch, L.round_up(n_out, 16), device=device)[:, :n_out]
     dw = torch.empty(n_out, L.round_up(k_in, 4), device=device)
     ws = torch.empty(max(int(lib.bsig_gemm_workspace_bytes(batch, n_out, k_in)),
                          int(lib.bsig_gemm_workspace_bytes(n_out, k_in, batch))) // 4 + 1, device=device)
@@ -745,7 +746,7 @@ def scaled_gemm_roofline(pkg, cfg, m, batch, nh, device):
                                   L.ptr(ws), ws.numel() * 4, L.stream()))
 
     def dwf():
-        L.check(lib.bsig_gemm_f32(L.ptr(d_o), n_out, 1, None, L.ptr(x), x.stride(0), 1, L.ptr(ids),
+        L.check(lib.bsig_gemm_f32(L.ptr(d_o), d_o.stride(0), 1, None, L.ptr(x), x.stride(0), 1, L.ptr(ids),
                                   L.ptr(dw), dw.stride(0), n_out, k_in, batch, L.EPI_NONE, 0, None, None, 0,
                                   1.0, L.ptr(ws), ws.numel() * 4, L.stream()))
     res = {}
@@ -754,8 +755,9 @@ def scaled_gemm_roofline(pkg, cfg, m, batch, nh, device):
         us = _event_time(fn, 20, 3)
         res[tag] = {'shape': '%dx%dx%d' % ((batch, n_out, k_in) if tag == 'forward' else (n_out, k_in, batch)),
                     'avg_us': us, 'achieved': flops / us / 1e6, 'frac': flops / us / 1e6 / PEAK_F32_TFLOPS}
-    return {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel (fp32 32x32x2 MFMA; least-padding tile + split-K '
-                                       'picked by plan_gemm_large) incl. its split-K reduce',
+    return {'bound': 'mfma', 'kernel': 'gemm_wide_kernel (fp32 16x16x4 MFMA on whole-head-width tiles, split K) incl. its '
+                                       'split-K reduce (inside the fit the forward product combines its K slices in the launch '
+                                       'and the gradient\'s reduce carries the Adam step)',
             'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'algorithmic': '2*B*N*K = %.3e flop per launch' % flops,
             **res}
 
