@@ -237,7 +237,7 @@ static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* par
 static int weight_grad(const float* dy, int64_t nout, int64_t ld_dy, const float* xin, int64_t ldin,
                        const Inputs* src, int delta, int64_t nin, int64_t B, float* params,
                        float* grads, int64_t w_off, int64_t b_off, const AdamFuse* fuse,
-                       const Scratch& s, hipStream_t st) {
+                       const Scratch& s, hipStream_t st, const HeadBiasPartials* bias_partials = nullptr) {
   GemmParams g;
   g.a = dy; g.lda = ld_dy; g.a_kmajor = 1;
   set_src_b_kmajor(g, xin, ldin, src, delta);
@@ -248,6 +248,9 @@ static int weight_grad(const float* dy, int64_t nout, int64_t ld_dy, const float
     g.adam_dyn = fuse->dyn; g.beta1 = fuse->beta1; g.beta2 = fuse->beta2; g.adam_eps = fuse->eps;
     g.bias_p = params + b_off; g.bias_m = fuse->m + b_off; g.bias_v = fuse->v + b_off;
     g.bias_g = grads + b_off;
+    if (bias_partials && bias_partials->n > 1) {   // the finishing kernel's slab sums, added up by the reduce + Adam kernel
+      g.bias_g = bias_partials->sums; g.bias_g_n = bias_partials->n; g.bias_g_stride = bias_partials->stride;
+    }
   } else {
     g.epilogue = BSIG_EPI_NONE;
     g.c = grads + w_off;
@@ -260,7 +263,7 @@ static int weight_grad(const float* dy, int64_t nout, int64_t ld_dy, const float
 // counter seen by these kernels relative to the forward half.
 static int backward_pass(const bsig_mdn_cfg* c, const Layout& L, float* params,
                          const Inputs& in, int delta, int64_t B, const Scratch& s, float* grads,
-                         const AdamFuse* fuse, hipStream_t st) {
+                         const AdamFuse* fuse, hipStream_t st, const HeadBiasPartials* bias_partials = nullptr) {
   // input of the heads
   const float* feat; int64_t ldf; const Inputs* fsrc = nullptr;
   if (L.n_layers > 0) { feat = s.h[L.n_layers - 1]; ldf = c->hidden[L.n_layers - 1]; }
@@ -278,7 +281,7 @@ static int backward_pass(const bsig_mdn_cfg* c, const Layout& L, float* params,
   }
   // heads: dW = dO^T feat (bias gradient = column sums of dO, from the finish kernel)
   BSIG_TRY(weight_grad(s.d_o, L.nh, s.ld_o, feat, ldf, fsrc, delta, L.feat_dim, B, params, grads,
-                       L.head_w_off, L.head_b_off, fuse, s, st));
+                       L.head_w_off, L.head_b_off, fuse, s, st, bias_partials));
   for (int l = L.n_layers - 1; l >= 0; --l) {
     const int64_t hw = c->hidden[l];
     const float* xin; int64_t ldin; const Inputs* xsrc = nullptr;
@@ -307,14 +310,14 @@ static int head_nll(const bsig_mdn_cfg* c, const Layout& L, const Scratch& s, co
                     const float* noise, uint64_t seed, uint64_t stream_id,
                     const uint64_t* dyn_rng, float* loss, const int32_t* loss_slot, bool bwd,
                     float* head_bias_grad, int32_t* nonfinite, const HeadDyn* dyn,
-                    hipStream_t st) {
+                    hipStream_t st, HeadBiasPartials* bias_partials = nullptr) {
   const int64_t D = c->head.out_dim, K = c->head.n_comp;
   return mdn_head_nll_launch(&c->head, s.o, s.ld_o, s.o + K, s.ld_o, s.o + K + D * K, s.ld_o,
                              c->head.full_cov ? s.o + K + 2 * D * K : nullptr, s.ld_o, 0, y, ldy,
                              y_rows, B, norm_batch, noise, seed, stream_id, dyn_rng, loss,
                              loss_slot, bwd ? s.d_o : nullptr, s.ld_o,
                              bwd ? head_bias_grad : nullptr, nonfinite, s.head_ws,
-                             s.head_ws_bytes, st, dyn);
+                             s.head_ws_bytes, st, dyn, bias_partials);
 }
 
 // ---- fit engine -----------------------------------------------------------
@@ -556,11 +559,17 @@ static int enqueue_grad(bsig_fit_plan* p, hipStream_t st, bool fuse_adam) {
   BSIG_TRY(forward_pass(&p->cfg, p->L, b.params, in, p->batch, m.tr, m.tr.o, m.tr.ld_o, st,
                         &n_sig));
   hd.n_sig_ready = n_sig;
+  // a fused Adam step whose weight gradient runs as the whole-width kernel + reduce: the head bias
+  // gradients stay partial column sums (no colsum kernel); gemm_run refuses them on any other path
+  HeadBiasPartials bp;
+  const bool partial_bias = fuse_adam && p->L.n_layers == 0 && in.rows != nullptr &&
+      gemm_wide_gradient_applies(p->L.nh, p->L.feat_dim, p->batch, m.tr.ld_o, in.ldx, m.tr.d_o, in.x, true);
   BSIG_TRY(head_nll(&p->cfg, p->L, m.tr, b.y_train, b.ldy_train, b.ids_table, p->batch,
                     p->norm_batch, nullptr, 0, 0, rng, b.train_loss, b.state + ST_STEP, true,
-                    b.grads + p->L.head_b_off, b.state + ST_NONFINITE, &hd, st));
+                    b.grads + p->L.head_b_off, b.state + ST_NONFINITE, &hd, st,
+                    partial_bias ? &bp : nullptr));
   return backward_pass(&p->cfg, p->L, b.params, in, -1, p->batch, m.tr, b.grads,
-                       fuse_adam ? &fuse : nullptr, st);
+                       fuse_adam ? &fuse : nullptr, st, partial_bias ? &bp : nullptr);
 }
 
 static int enqueue_apply(bsig_fit_plan* p, hipStream_t st) {

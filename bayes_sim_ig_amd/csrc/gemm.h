@@ -39,6 +39,8 @@ struct GemmParams {
   // bias_p[row] with gradient bias_g[row] (column sums computed earlier)
   float* bias_p = nullptr; float* bias_m = nullptr; float* bias_v = nullptr;
   const float* bias_g = nullptr;
+  // ... or as bias_g_n partial sums per row, bias_g_stride floats apart (added up in index order)
+  int bias_g_n = 0; int64_t bias_g_stride = 0;
   // set by gemm_run: a k-contiguous operand whose rows are not 16-byte aligned is still fetched
   // in 16-byte quads (TileLoader::fetch)
   int a_unal = 0, b_unal = 0;
@@ -48,6 +50,11 @@ struct GemmParams {
 
 // the head widths the whole-width kernels of gemm_wide.h are instantiated for
 bool gemm_wide_covers(int n_wide);
+
+// will dW = dO^T X[ids] (both operands k-major, dO at a pitch of lda) run as the whole-width gradient
+// kernel + the 16-byte reduce + Adam kernel?  (the one path that takes partial bias sums, bias_g_n > 1)
+bool gemm_wide_gradient_applies(int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, const float* a,
+                                const float* b, bool gathered);
 
 // n_expsum (optional) receives the number of expsum partials written.
 int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st,

@@ -104,7 +104,18 @@ __global__ __launch_bounds__(256) void gemm_reduce_adam4_kernel(GemmParams p) {
     }
     st4(p.adam_m + ce, m1); st4(p.adam_v + ce, v1); st4(p.c + ce, p1);
     if (col == 0 && p.bias_p) {
-      const float bg = p.bias_g[row];
+      // (partial sums in index order, 16 loads in flight: one lane of a wavefront does this while the
+      // others wait -- a load per iteration made it 64 dependent round trips)
+      float bg = 0.f;
+      for (int q0 = 0; q0 < max(p.bias_g_n, 1); q0 += 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          t[u] = p.bias_g[(int64_t)min(q0 + u, max(p.bias_g_n, 1) - 1) * p.bias_g_stride + row];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (q0 + u < max(p.bias_g_n, 1)) bg += t[u];
+      }
       const float bm = p.bias_m[row] + (bg - p.bias_m[row]) * (1.0f - p.beta1);
       const float bv = p.bias_v[row] * p.beta2 + (1.0f - p.beta2) * bg * bg;
       p.bias_m[row] = bm;
@@ -121,6 +132,7 @@ static int launch_reduce(const GemmParams& p, hipStream_t st, int* n_expsum) {
   const bool adam4 = p.epilogue == EPI_ADAM && (p.n & 3) == 0 && (p.ldc & 3) == 0 && (p.partial_ld & 3) == 0 &&
                      (p.partial_slab & 3) == 0 && al(p.partial) && al(p.c) && al(p.adam_m) && al(p.adam_v) &&
                      (!p.grad_out || al(p.grad_out)) && getenv("BSIG_GEMM_NO_ADAM4") == nullptr;
+  BSIG_REQUIRE(!(p.bias_g_n > 1 && !adam4), "gemm: partial bias sums need the 16-byte reduce + Adam kernel");
   if (adam4) {
     const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total / 4, 256), 2048);
     hipLaunchKernelGGL(gemm_reduce_adam4_kernel, dim3(blocks), dim3(256), 0, st, p);
@@ -296,6 +308,12 @@ static bool unaligned_quads(const float* ptr, int64_t ld, int kmajor, int k) {
   return !kmajor && pick_vec(ptr, ld) == 1 && ld >= 4 && k >= 4 && getenv("BSIG_GEMM_NO_UNALIGNED") == nullptr;
 }
 
+bool gemm_wide_gradient_applies(int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, const float* a,
+                                const float* b, bool gathered) {
+  return env_int("BSIG_GEMM_WIDE", 1) && gathered && k >= 2048 && k % BK == 0 && gemm_wide_covers((int)m) &&
+         lda == ceil_div<int64_t>(m, 16) * 16 && n % 64 == 0 && pick_vec(a, lda) == 4 && pick_vec(b, ldb) == 4;
+}
+
 int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st,
              int* n_expsum) {
   BSIG_REQUIRE(p.a && p.b && p.c, "gemm: null pointer");
@@ -365,9 +383,8 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
         }
         if (rc == BSIG_OK) { p.partial_ld = wide; p.partial_slab = wp.slab; }
       }
-    } else if (p.a_kmajor && p.b_kmajor && !p.a_rows && p.k >= 2048 && gemm_wide_covers(p.m) &&
-               p.lda == ceil_div(p.m, 16) * 16 && p.n % 64 == 0 && pick_vec(p.a, p.lda) == 4 &&
-               pick_vec(p.b, p.ldb) == 4 && !p.a_dyn_stride && !p.a_dyn_base) {
+    } else if (p.a_kmajor && p.b_kmajor && !p.a_rows && !p.a_dyn_stride && !p.a_dyn_base &&
+               gemm_wide_gradient_applies(p.m, p.n, p.k, p.lda, p.ldb, p.a, p.b, p.b_rows != nullptr)) {
       if (split(p.n / 64, (int64_t)p.m * p.n)) {
         wp.wide = p.a; wp.ld_wide = p.lda; wp.n_wide = p.m;
         wp.x = p.b; wp.ldx = p.ldb; wp.ids = p.b_rows; wp.n_narrow = p.n;
@@ -383,6 +400,7 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     }
     if (rc != BSIG_EUNSUPPORTED) return rc;
   }
+  BSIG_REQUIRE(p.bias_g_n <= 1, "gemm: partial bias sums outside the whole-width gradient path");
   const GemmPlan pl = plan_gemm(p.m, p.n, p.k, workspace ? workspace_bytes : 0);
   p.splits = pl.splits; p.k_chunk = pl.k_chunk;
   p.partial = reinterpret_cast<float*>(workspace);

@@ -557,7 +557,8 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
                         uint64_t stream_id, const uint64_t* dyn_rng, float* loss,
                         const int32_t* loss_slot, float* d_out, int64_t ld_dout,
                         float* colsum_out, int32_t* nonfinite, void* workspace,
-                        size_t workspace_bytes, hipStream_t st, const HeadDyn* dyn) {
+                        size_t workspace_bytes, hipStream_t st, const HeadDyn* dyn,
+                        HeadBiasPartials* bias_partials) {
   HeadGeom g;
   BSIG_TRY(head_geom(dims, batch, &g));
   BSIG_REQUIRE(batch >= 1 && batch < (1 << 30), "mdn head: bad batch");
@@ -614,8 +615,11 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
                      ld_dout, cs, g.rows_per_slab, loss, loss_slot, nonfinite,
                      dyn ? dyn->hook : FinishHook());
   BSIG_CHECK_LAUNCH("mdn_finish");
-  if (colsum_out && g.slabs > 1)
-    BSIG_TRY(colsum_launch(slab_sums, g.Nh, g.slabs, g.Nh, colsum_out, nullptr, 0, st));
+  if (bias_partials) *bias_partials = HeadBiasPartials{};
+  if (colsum_out && g.slabs > 1) {
+    if (bias_partials) *bias_partials = HeadBiasPartials{slab_sums, g.slabs, g.Nh};   // the caller adds the slabs up
+    else BSIG_TRY(colsum_launch(slab_sums, g.Nh, g.slabs, g.Nh, colsum_out, nullptr, 0, st));
+  }
   return BSIG_OK;
 }
 
