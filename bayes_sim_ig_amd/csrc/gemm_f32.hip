@@ -351,10 +351,19 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     wp.dyn = p.dyn; wp.dyn_delta = p.dyn_delta; wp.k = p.k;
     int rc = BSIG_EUNSUPPORTED;
     auto split = [&](int64_t tiles, int64_t slab_floats) {
-      int64_t s = std::max<int64_t>((256 + tiles / 2) / tiles, 1);
-      s = std::min<int64_t>(s, std::max<int64_t>(p.k / (8 * BK), 1));
-      s = std::min<int64_t>(s, (int64_t)(workspace_bytes / (sizeof(float) * (size_t)slab_floats)));
-      if (s < 1) return false;
+      // one workgroup per CU at a time (123 KB of LDS): the launch takes ceil(tiles * s / 256) rounds
+      // of 1 / s of a tile's K loop each, plus a slab's worth of traffic per slice -- e.g. 313 row
+      // tiles (a 20000-row evaluation): unsplit 2 rounds of the whole K loop, in 4 slices 5 rounds of
+      // a quarter
+      const int64_t smax = std::min<int64_t>(std::min<int64_t>(8, std::max<int64_t>(p.k / (8 * BK), 1)),
+                                             (int64_t)(workspace_bytes / (sizeof(float) * (size_t)slab_floats)));
+      if (smax < 1) return false;
+      int64_t s = 1;
+      double best = 1e30;
+      for (int64_t c = 1; c <= smax; ++c) {
+        const double cost = (double)ceil_div<int64_t>(tiles * c, 256) / (double)c + 0.02 * (double)c;
+        if (cost < best - 1e-9) { best = cost; s = c; }
+      }
       const int64_t chunk = round_up<int64_t>(ceil_div<int64_t>(p.k, s), BK);
       wp.k_chunk = (int)chunk; wp.splits = (int)ceil_div<int64_t>(p.k, chunk);
       wp.slab = slab_floats;
@@ -495,10 +504,15 @@ __global__ __launch_bounds__(256) void rff_coeff_kernel(const float* __restrict_
 using namespace bsig;
 
 extern "C" size_t bsig_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
-  (void)k;
-  return (size_t)64 * (size_t)m * (size_t)n * sizeof(float) <= ((size_t)256 << 20)
-             ? (size_t)64 * (size_t)m * (size_t)n * sizeof(float)
-             : plan_gemm(m, n, k, (size_t)1 << 40).splits * (size_t)m * (size_t)n * sizeof(float);
+  size_t need = (size_t)64 * (size_t)m * (size_t)n * sizeof(float) <= ((size_t)256 << 20)
+                    ? (size_t)64 * (size_t)m * (size_t)n * sizeof(float)
+                    : plan_gemm(m, n, k, (size_t)1 << 40).splits * (size_t)m * (size_t)n * sizeof(float);
+  // the whole-width products (gemm_wide.h): up to 8 K slices of slabs at the padded head width
+  if (m >= 2048 && gemm_wide_covers((int)n))
+    need = std::max(need, (size_t)8 * (size_t)m * (size_t)round_up<int64_t>(n, 16) * sizeof(float));
+  if (k >= 2048 && gemm_wide_covers((int)m))
+    need = std::max(need, (size_t)8 * (size_t)m * (size_t)n * sizeof(float));
+  return need;
 }
 
 extern "C" int bsig_gemm_f32(const float* a, int64_t lda, int a_kmajor,

@@ -797,9 +797,9 @@ def _assert_envelope(hip, f32_logs, f64, factor=2.0, sigmas=3.0):
         h = np.abs(np.asarray(hip[key], dtype=np.float64) - r)
         d = np.array([np.abs(np.asarray(f[key], dtype=np.float64) - r) for f in f32_logs])   # [orders, points]
         env = d.max(axis=0)
-        lg = np.log10(np.maximum(d, 1e-300))
-        stat = 10.0 ** (lg.mean(axis=0) + sigmas * lg.std(axis=0, ddof=1))
-        stat = np.where(d.min(axis=0) > 0.0, stat, 0.0)      # (an order that is exact at a point: no log statistics)
+        ok = d.min(axis=0) > 0.0                              # (an order that is exact at a point: no log statistics)
+        lg = np.log10(np.where(ok[None, :], d, 1.0))
+        stat = np.where(ok, 10.0 ** (lg.mean(axis=0) + sigmas * lg.std(axis=0, ddof=1)), 0.0)
         bound = np.maximum(factor * env, stat) + 1e-4 * np.abs(r) + 1e-6
         print('  %-10s |hip-f64|/|f64|            %s\n  %-10s furthest of %d orders       %s\n  %-10s mean + %g sigma (log10)    %s' %
               (key, h / np.abs(r), '', len(f32_logs), env / np.abs(r), '', sigmas, stat / np.abs(r)))

@@ -192,6 +192,62 @@ def test_gemm_large_minibatch_shapes(B, shape):
         torch.testing.assert_close(out[:, cols].double(), ref, rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize('a_km,b_km', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_lean_gemm_is_bitwise_the_old_kernel(B, a_km, b_km):
+    """gemm_lean_kernel (csrc/gemm_lean.h: the K loop without vector-ALU work, two LDS images, one
+    barrier per step) keeps every output's fma chain: bit for bit gemm_mfma_kernel, on ragged
+    problems (edges in M, N and K -- the guarded last step), every tile shape, unsplit and split K,
+    gathered rows / gathered contraction rows.  (tools/gemm_lean_ab.py runs 240 such cases.)"""
+    import os
+    gen = torch.Generator().manual_seed(17 + 2 * a_km + b_km)
+    pool = 700
+    for (m, n, k) in ((300, 260, 530), (100, 512, 2310), (129, 97, 64)):
+        def pitched(rows, cols):
+            buf = torch.zeros(rows, (cols + 3) // 4 * 4)
+            buf[:, :cols] = torch.randn(rows, cols, generator=gen)
+            return buf.to(DEV)[:, :cols]
+        a = pitched(k, m) if a_km else pitched(pool, k)
+        b = pitched(pool, n) if b_km else pitched(n, k)
+        a_rows = None if a_km else torch.randint(0, pool, (m,), generator=gen).to(torch.int32).to(DEV)
+        b_rows = torch.randint(0, pool, (k,), generator=gen).to(torch.int32).to(DEV) if b_km else None
+        for tile in (0, 1, 2, 3, 4, 5):
+            for splits in (1, 3):
+                os.environ['BSIG_GEMM_TILE'], os.environ['BSIG_GEMM_SPLITS'] = str(tile), str(splits)
+                try:
+                    out = {}
+                    for lean in ('0', '1'):
+                        os.environ['BSIG_GEMM_LEAN'] = lean
+                        out[lean] = _gemm(B, a, b, m, n, k, a_km, b_km, a_rows=a_rows, b_rows=b_rows).clone()
+                finally:
+                    for key in ('BSIG_GEMM_TILE', 'BSIG_GEMM_SPLITS', 'BSIG_GEMM_LEAN'):
+                        os.environ.pop(key, None)
+                assert torch.equal(out['0'], out['1']), (m, n, k, tile, splits)
+
+
+def test_wide_gradient_gemm_at_the_padded_pitch(B):
+    """dW = dO^T F[ids] with dO at the pitch the fit engine keeps it at for large minibatches
+    (ceil16(Nh) = 272 floats): the whole-width gradient kernel (csrc/gemm_wide.h) against fp64 on
+    sampled columns and against the generic kernels everywhere (another summation order)."""
+    import os
+    gen = torch.Generator(device=DEV).manual_seed(12)
+    pool, bsz, nh, f = 20000, 8192, 260, 4096
+    feats = torch.randn(pool, f, device=DEV, generator=gen) * 0.02
+    ids = torch.randint(0, pool, (bsz,), device=DEV, generator=gen).to(torch.int32)
+    d_o = torch.full((bsz, 272), float('nan'), device=DEV)       # (the padding columns may hold anything)
+    d_o[:, :nh] = torch.randn(bsz, nh, device=DEV, generator=gen) * 0.01
+    out = _gemm(B, d_o[:, :nh], feats, nh, f, bsz, 1, 1, b_rows=ids).clone()
+    os.environ['BSIG_GEMM_WIDE'] = '0'
+    try:
+        ref32 = _gemm(B, d_o[:, :nh], feats, nh, f, bsz, 1, 1, b_rows=ids).clone()
+    finally:
+        os.environ.pop('BSIG_GEMM_WIDE')
+    cols = torch.arange(0, f, 61, device=DEV)
+    ref = d_o[:, :nh].double().T @ feats[ids.long()][:, cols].double()
+    torch.testing.assert_close(out[:, cols].double(), ref, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(out, ref32, rtol=1e-5, atol=2e-6)
+    assert not torch.equal(out, ref32)      # (it IS the other kernel: 16x16x4 tiles, 4 K slices)
+
+
 def test_gemm_gather_and_epilogues(B):
     L = B._lib
     gen = torch.Generator().manual_seed(5)
