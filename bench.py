@@ -822,7 +822,7 @@ def per_config_numbers(pkg, device, skip):
         out[name] = {'workload': '%s %s %s (I=%d), %d pairs' % (cfg['task'], cfg['model'], cfg['summarizer'],
                                                                bs.model.input_dim, n),
                      'pairs_per_s': n / dt, 'us_per_update': roof.get('us_per_update'),
-                     'roofline_frac': roof.get('frac'), 'kernel': roof['kernel'].split(':')[0],
+                     'mfma_frac': roof.get('frac'), 'kernel': roof['kernel'].split(':')[0],
                      'nll_rel_diff': nll['rel_diff'], 'nll_protocol': nll['protocol']}
         if wide:
             # both protocols side by side: 20 updates (inside the fp32 horizon of these ill-conditioned
@@ -833,8 +833,16 @@ def per_config_numbers(pkg, device, skip):
             out[name]['nll_rel_diff_100'] = nll100['rel_diff']
             out[name]['nll_note'] = ('ill-conditioned in fp32 beyond ~40 updates: two fp32 evaluation orders of '
                                      'the reference itself differ by 1e-3..1e-1 at update 100 (DESIGN.md 1)')
+        # (mfma_frac: algorithmic flops / time / 157.3 TFLOP/s.  A streamed plan is HBM-bound -- W1 and
+        # its Adam moments cross HBM once per update in each direction --: its roofline fraction is
+        # hbm_frac, the algorithmic W/m/v bytes per update over the update time against 8 TB/s)
         if roof.get('hbm_achieved_gbs_streamed_w1'):
             out[name]['hbm_gbs_streamed_w1'] = roof['hbm_achieved_gbs_streamed_w1']
+            out[name]['hbm_frac'] = roof['hbm_achieved_gbs_streamed_w1'] / PEAK_HBM_GBS
+            out[name]['bound'] = 'hbm'
+        else:
+            out[name]['bound'] = 'mfma'
+
         del bs, theta, states, actions
         torch.cuda.empty_cache()
     return out

@@ -64,6 +64,11 @@ rows = [('tiles: first / last start of the update', tiles, 0, np.min),
         ('owners: last d_out corrected + published', owners, 14, np.max),
         ('owners: last flag (dz2, dz1 out)', owners, 15, np.max),
         ('small: last weights published', small, 6, np.max)]
+def rel(v, t0, w=7):
+    """a stamp relative to t0; a stamp that was never taken (0) prints as n/a"""
+    return ('%%%d.2f' % w) % (v - t0) if v > 0 else ' ' * (w - 3) + 'n/a'
+
+
 acc = {r[0]: [] for r in rows}
 per = []
 for u in range(2, 7):
@@ -79,28 +84,28 @@ t0 = min(st[g, u, 0] for g in tiles)
 print('second chunk of update %d, wavefront 0 of four tile workgroups: start / dW MFMAs done / Adam, stores, W in LDS / '
       'behind the barrier / forward MFMAs done / behind the barrier' % u)
 for g in tiles[3::55]:
-    print('   wg %3d: ' % g + ' '.join('%7.2f' % (st[g, u, k] - t0) for k in range(8, 14)))
+    print('   wg %3d: ' % g + ' '.join(rel(st[g, u, k], t0) for k in range(8, 14)))
 t0w = st[254, 0, 0]
 if t0w > 0:
     print('tile workgroup 3, update 4, second chunk, per wavefront (us after wavefront 0 entered): entered / dW || Adam done / '
           'behind the barrier / forward done (stores, loads issued inside) / behind the barrier / gradient in LDS')
     for w in range(8):
-        print('   wave %d: ' % w + ' '.join('%6.2f' % (st[254, w, k] - t0w) for k in (0, 1, 2, 7, 8, 9)) +
+        print('   wave %d: ' % w + ' '.join(rel(st[254, w, k], t0w, 6) for k in (0, 1, 2, 7, 8, 9)) +
               '   forward: %d shader clocks in %.2f us = %.2f GHz' % ((st[254, w, 11] - st[254, w, 10]) * 100, st[254, w, 7] - st[254, w, 2], (st[254, w, 11] - st[254, w, 10]) * 100 / max(st[254, w, 7] - st[254, w, 2], 1e-9) / 1e3))
 if os.environ.get('DETAIL') == '1':
     u = 4
     t0 = min(st[g, u, 0] for g in tiles)
     print('update %d, tile workgroups: start / prefetched / released / dz1 / pass done / summed' % u)
     for g in tiles[::8]:
-        print('   wg %3d: ' % g + ' '.join('%7.2f' % (st[g, u, k] - t0) for k in range(6)))
+        print('   wg %3d: ' % g + ' '.join(rel(st[g, u, k], t0) for k in range(6)))
 if os.environ.get('WIDE_DETAIL') == '1':
     u = 4
     t0 = min(st[g, u, 0] for g in tiles)
     print('update %d, head-block workgroups (us after t0): h2 flags seen / h2 in LDS / head outputs flagged / d_out flags seen / '
           'd_out block in LDS / dz2 share flagged / weights published' % u)
     for g in small[4:]:
-        print('   wg %3d: %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f' % tuple([g] + [st[g, u, k] - t0 for k in (7, 8, 9, 4, 5, 10, 6)]) +
-              '   [mfma issued %.2f, exchanged %.2f, stores issued %.2f, acked %.2f]' % tuple(st[g, u, k] - t0 for k in (1, 2, 11, 3)))
+        print('   wg %3d: ' % g + ' '.join(rel(st[g, u, k], t0, 6) for k in (7, 8, 9, 4, 5, 10, 6)) +
+              '   [mfma issued %s, exchanged %s, stores issued %s, acked %s]' % tuple(rel(st[g, u, k], t0, 1).strip() for k in (1, 2, 11, 3)))
     print('owners: sum flags seen / h1 / h2 (flagged) / head outputs in LDS + exp sum published / rows finished / d_out published / flag_own')
     for g in owners[:6]:
-        print('   wg %3d: %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f' % tuple([g] + [st[g, u, k] - t0 for k in (6, 7, 8, 9, 13, 14, 15)]))
+        print('   wg %3d: ' % g + ' '.join(rel(st[g, u, k], t0, 6) for k in (6, 7, 8, 9, 13, 14, 15)))
