@@ -556,14 +556,10 @@ class MDNN(nn.Module):
             if slot[1] is not None:
                 slot[1].synchronize()
             slot[0][:n_ids].copy_(torch.from_numpy(ids_np.astype(np.int32)).reshape(-1))
-            if n_ids < (1 << 16) and batch_size % 4 == 0 and os.environ.get('BSIG_IDS_BY_DMA') != '1':
-                # a chunk's 40 KB table: a copy KERNEL reads the pinned buffer across PCIe (device-mapped
-                # host memory) -- a DMA copy between two kernels of the stream costs ~20 us of engine
-                # hand-offs per chunk (the "gap before the next fit_begin_kernel" of the chunk timeline)
-                _lib.check(lib.bsig_copy_rows(slot[0].data_ptr(), batch_size, None, ids_dev.data_ptr(),
-                                              batch_size, n_updates, batch_size, st))
-            else:
-                ids_dev[:n_ids].copy_(slot[0][:n_ids], non_blocking=True)
+            # (a copy KERNEL reading the pinned buffer across PCIe instead of this DMA copy was measured in
+            # round 5: 487.5 k against 489.0 k pairs/s -- the ~20 us "gap before the next fit_begin_kernel"
+            # of the chunk timeline is not the copy engine's hand-off)
+            ids_dev[:n_ids].copy_(slot[0][:n_ids], non_blocking=True)
             slot[1] = torch.cuda.Event()
             slot[1].record()
 
