@@ -612,6 +612,12 @@ static int enqueue_hoisted_rff(bsig_fit_plan* p, hipStream_t st) {
   // times); when that does not fit the plan's buffer, every gathered minibatch row
   const int64_t train_rows = p->feat_unique ? b.n_train : p->n_updates * p->batch;
   if (!p->feat_unique) in.rows = b.ids_table;
+  // the held-out rows lie right behind the training rows (the usual binding: one staged block of
+  // the chunk): ONE projection over all of them -- a 1000-pair chunk is 16 x 32 tiles of 64 x 64 =
+  // 512 workgroups, two per CU, where 800 + 200 rows were 416 + 128 in two launches
+  if (p->feat_unique && b.n_test > 0 && b.ldx_test == b.ldx_train &&
+      b.x_test == b.x_train + (size_t)b.n_train * b.ldx_train && getenv("BSIG_RFF_SPLIT_LAUNCH") == nullptr)
+    return rff_project(&p->cfg, in, train_rows + b.n_test, m.feats, m.big_ws, p->big_gemm_ws_bytes, st);
   BSIG_TRY(rff_project(&p->cfg, in, train_rows, m.feats, m.big_ws, p->big_gemm_ws_bytes, st));
   if (b.n_test > 0) {
     in.x = b.x_test; in.ldx = b.ldx_test; in.rows = nullptr;

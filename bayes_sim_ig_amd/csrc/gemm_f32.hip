@@ -263,9 +263,12 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
   if (m >= 256 && n >= 128 && t128 >= 192) {
     pl.tile = TILE_128; tiles = t128; target = 256;
   } else if (m >= 256 && n >= 128 && t12864 >= 160 && t12864 <= 512) {
-    // mid-sized (a chunk's RFF projection, 800 x 2048): 128x64 tiles give one round of
-    // ~224 workgroups on the 256 CUs where 64x64 tiles give 1.6 rounds of smaller ones
-    pl.tile = TILE_128x64; tiles = t12864; target = 256;
+    // mid-sized (a chunk's RFF projection: 1000 x 2048 x 2310 -- training and held-out rows in one
+    // launch).  With the lean loop (two LDS images: four 64 x 64 workgroups per CU) the unsplit 64 x 64
+    // tiling is the fastest of the sweep (profiles/r05_rff_chunk_sweep.txt: 1000 rows = 16 x 32 = 512
+    // workgroups, two per CU, 90 us against 97 for 128 x 64 tiles in two K halves; 800 rows 95 = 95).
+    // (round 2-4, gemm_mfma_kernel: 128x64 tiles in two k-halves, 101-104 us against 118-135.)
+    pl.tile = TILE_64; tiles = ceil_div<int64_t>(m, 64) * ceil_div<int64_t>(n, 64); target = 0;
   } else if (m <= 128 && n >= 64) {
     pl.tile = TILE_128x32; tiles = ceil_div<int64_t>(n, 32); target = 512;
   } else {
@@ -284,9 +287,6 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
     if (splits > max_by_k) splits = max_by_k;
     if (splits > 64) splits = 64;
   }
-  // (measured, tools/micro/rff_shape_sweep.py: 800..1000 x 2048 x 2310 runs 101-104 us as
-  // 128x64 tiles with two k-halves, 118-121 us as 64x64 tiles, 129-135 us unsplit)
-  if (pl.tile == TILE_128x64 && forced_tile < 0 && k >= 8 * BK) splits = 2;
   const int forced = env_int("BSIG_GEMM_SPLITS", 0);
   if (forced > 0) splits = forced;
   const int64_t max_by_ws = (int64_t)(ws_bytes / (sizeof(float) * (size_t)(m * n)));

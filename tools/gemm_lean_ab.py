@@ -177,6 +177,10 @@ def times():
          lambda: gemm(feats, w, 8192, 256, 4096, 0, 0, rows_a=ids)),
         ('RFF chunk 800x2048x2310 cos|sin', 2.0 * 800 * 2048 * 2310,
          lambda: gemm(x, co, 800, 2048, 2310, 0, 0, epi=L.EPI_COS_SIN, alpha=0.02)),
+        ('RFF chunk+heldout 1000x2048x2310 cos|sin', 2.0 * 1000 * 2048 * 2310,
+         lambda: gemm(x, co, 1000, 2048, 2310, 0, 0, epi=L.EPI_COS_SIN, alpha=0.02)),
+        ('RFF heldout 200x2048x2310 cos|sin', 2.0 * 200 * 2048 * 2310,
+         lambda: gemm(x, co, 200, 2048, 2310, 0, 0, epi=L.EPI_COS_SIN, alpha=0.02)),
         ('RFF 10000x2048x2310 cos|sin', 2.0 * 10000 * 2048 * 2310,
          lambda: gemm(x, co, 10000, 2048, 2310, 0, 0, epi=L.EPI_COS_SIN, alpha=0.02)),
         ('RFF 32000x2048x2310 cos|sin', 2.0 * 32000 * 2048 * 2310,
