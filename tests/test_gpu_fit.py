@@ -616,6 +616,20 @@ def test_scaled_batch_fit_matches_oracle(B):
     assert res['max_rel_diff_all_logs'] < 1e-4, res
 
 
+@pytest.mark.parametrize('batch', [2112, 2100])
+def test_scaled_batch_fit_ragged_minibatches(B, batch):
+    """The large-minibatch path at minibatch sizes that are no multiple of the whole-width kernels'
+    tiles: 2112 = 33 x 64 rows (both products on gemm_wide_kernel, K slices of 1056 rows) and 2100
+    (the forward product with a ragged last row tile, the gradient -- its contraction is no multiple
+    of 32 -- on the generic kernels at the padded dO pitch): every logged loss within 1e-4 of the oracle."""
+    import bench
+    cfg = dict(bench.CONFIGS['cfg5'])
+    theta, states, actions = bench.synth_pairs(cfg, 6000, 5, DEV)
+    torch.set_num_threads(8)
+    res = bench.scaled_nll_check(B, cfg, theta, states, actions, DEV, batch, n=6000, n_updates=6)
+    assert res['max_rel_diff_all_logs'] < 1e-4, res
+
+
 def _fp64_oracle(bench, cfg, in_dim, w0, freqs):
     o = bench.build_oracle(cfg, in_dim, 77, 0.0, freqs=freqs).double()
     o.load_state_dict({k: v.double() for k, v in w0.items()})
