@@ -67,18 +67,21 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
 // four adjacent columns per thread: 16-byte loads of the slabs and of the optimizer state, all in
 // flight before the first dependent instruction.  Same arithmetic per element as epilogue_store's
 // EPI_ADAM branch (slab order, then the identical expressions): bit-identical to the scalar kernel.
+template <bool ADAM>   // (false: BSIG_EPI_NONE, the plain sum -- a data-parallel rank's gradients)
 __global__ __launch_bounds__(256) void gemm_reduce_adam4_kernel(GemmParams p) {
   const int n4 = p.n >> 2;
   const int64_t total4 = (int64_t)p.m * n4;
   const int64_t slab = p.partial_ld ? p.partial_slab : (int64_t)p.m * p.n;
-  const float ss = p.adam_dyn[0], ib = p.adam_dyn[1];
+  float ss = 0.f, ib = 0.f;
+  if constexpr (ADAM) { ss = p.adam_dyn[0]; ib = p.adam_dyn[1]; }
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(e / n4), col = (int)(e % n4) * 4;
     const int64_t pe = p.partial_ld ? (int64_t)row * p.partial_ld + col : (int64_t)row * p.n + col;
     const int64_t ce = (int64_t)row * p.ldc + col;
     F4 g{{0.f, 0.f, 0.f, 0.f}};
-    const F4 pm = ld4(p.adam_m + ce), pv = ld4(p.adam_v + ce), pp = ld4(p.c + ce);
+    F4 pm{{0.f, 0.f, 0.f, 0.f}}, pv = pm, pp = pm;
+    if constexpr (ADAM) { pm = ld4(p.adam_m + ce); pv = ld4(p.adam_v + ce); pp = ld4(p.c + ce); }
     int z = 0;
     for (; z + 4 <= p.splits; z += 4) {
       F4 q[4];
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_adam4_kernel(GemmParams p) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) g.v[c] += q.v[c];
     }
+    if constexpr (!ADAM) { st4(p.c + ce, g); continue; }
     if (p.grad_out) st4(p.grad_out + ce, g);
     F4 m1, v1, p1;
 #pragma unroll
@@ -129,13 +133,14 @@ __global__ __launch_bounds__(256) void gemm_reduce_adam4_kernel(GemmParams p) {
 static int launch_reduce(const GemmParams& p, hipStream_t st, int* n_expsum) {
   const int64_t total = (int64_t)p.m * p.n;
   auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  const bool adam4 = p.epilogue == EPI_ADAM && (p.n & 3) == 0 && (p.ldc & 3) == 0 && (p.partial_ld & 3) == 0 &&
-                     (p.partial_slab & 3) == 0 && al(p.partial) && al(p.c) && al(p.adam_m) && al(p.adam_v) &&
-                     (!p.grad_out || al(p.grad_out)) && getenv("BSIG_GEMM_NO_ADAM4") == nullptr;
+  const bool quads = (p.n & 3) == 0 && (p.ldc & 3) == 0 && (p.partial_ld & 3) == 0 && (p.partial_slab & 3) == 0 &&
+                     al(p.partial) && al(p.c) && getenv("BSIG_GEMM_NO_ADAM4") == nullptr;
+  const bool adam4 = quads && p.epilogue == EPI_ADAM && al(p.adam_m) && al(p.adam_v) && (!p.grad_out || al(p.grad_out));
   BSIG_REQUIRE(!(p.bias_g_n > 1 && !adam4), "gemm: partial bias sums need the 16-byte reduce + Adam kernel");
-  if (adam4) {
+  if (adam4 || (quads && p.epilogue == BSIG_EPI_NONE && total >= (1 << 18))) {
     const int blocks = (int)std::min<int64_t>(ceil_div<int64_t>(total / 4, 256), 2048);
-    hipLaunchKernelGGL(gemm_reduce_adam4_kernel, dim3(blocks), dim3(256), 0, st, p);
+    if (adam4) hipLaunchKernelGGL(gemm_reduce_adam4_kernel<true>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_reduce_adam4_kernel<false>, dim3(blocks), dim3(256), 0, st, p);
     BSIG_CHECK_LAUNCH("gemm_reduce_adam4");
     return BSIG_OK;
   }
