@@ -7,11 +7,14 @@ namespace bsig {
 template <int NWT, bool KMAJ>
 static int launch_wide(const WideParams& p, hipStream_t st) {
   constexpr size_t lds = wide_lds_bytes<NWT>(KMAJ);
-  static bool attr_set = false;   // (per process; the attribute is per device function)
-  if (!attr_set) {
+  // (the attribute belongs to the function ON A DEVICE: once per device of this process)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  BSIG_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<NWT, KMAJ>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const dim3 grid(ceil_div(p.n_narrow, 64), p.splits);
   hipLaunchKernelGGL((gemm_wide_kernel<NWT, KMAJ>), grid, dim3(512), lds, st, p);
