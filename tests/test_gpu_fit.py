@@ -616,6 +616,37 @@ def test_scaled_batch_fit_matches_oracle(B):
     assert res['max_rel_diff_all_logs'] < 1e-4, res
 
 
+def test_scaled_batch_in_launch_combine_is_bitwise_the_reduce_kernel(B):
+    """The head forward product of a large minibatch combines its K slices INSIDE the launch
+    (csrc/gemm_wide.h: every workgroup writes its slab through, the last arriver of a row tile adds
+    the slabs in slice order and the bias).  Same sums in the same order as the separate reduce kernel
+    (BSIG_GEMM_NO_COMBINE=1): with EPS_NOISE = 0 (no exp partial sums, whose grouping differs) the two
+    fits must agree BIT FOR BIT -- every loss, every weight -- over 40 updates of minibatch 8192 and
+    their 20000-row evaluations: ~10^4 cross-workgroup hand-offs, any stale slab word would show."""
+    import bench
+    cfg = dict(bench.CONFIGS['cfg5'])
+    theta, states, actions = bench.synth_pairs(cfg, 40000, 9, DEV)
+    old = B.MDNN.EPS_NOISE
+    B.MDNN.EPS_NOISE = 0.0
+    try:
+        ids = np.random.RandomState(8).randint(0, 32000, (40, 8192))
+        runs = {}
+        for env in ('0', '1'):
+            os.environ['BSIG_GEMM_NO_COMBINE'] = env
+            try:
+                bs = bench.build_gpu_model(B, cfg, DEV, 78)
+                logs = bs.model.run_training(bs._summarize(states, actions), theta, 40, 8192, ids_table=ids)
+                torch.cuda.synchronize()
+                runs[env] = (logs, bs.model._flat.clone())
+            finally:
+                os.environ.pop('BSIG_GEMM_NO_COMBINE', None)
+        for key in ('train_loss', 'test_loss'):
+            np.testing.assert_array_equal(np.asarray(runs['0'][0][key]), np.asarray(runs['1'][0][key]))
+        assert torch.equal(runs['0'][1], runs['1'][1])
+    finally:
+        B.MDNN.EPS_NOISE = old
+
+
 @pytest.mark.parametrize('batch', [2112, 2100])
 def test_scaled_batch_fit_ragged_minibatches(B, batch):
     """The large-minibatch path at minibatch sizes that are no multiple of the whole-width kernels'
