@@ -123,6 +123,7 @@ _PROTOS = {
     'bsig_comm_world': (C.c_int, [vp]),
     'bsig_fit_dp_graph_status': (C.c_int, [vp, C.c_char_p, sz]),
     'bsig_comm_rank': (C.c_int, [vp]),
+    'bsig_comm_resident_calls': (i64, [vp]),
     'bsig_comm_allreduce': (C.c_int, [vp, vp, i64, vp]),
     'bsig_comm_broadcast': (C.c_int, [vp, vp, i64, C.c_int, vp]),
     'bsig_comm_destroy': (None, [vp]),

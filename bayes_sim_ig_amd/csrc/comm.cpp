@@ -31,10 +31,12 @@ const char* ncclGetErrorString(ncclResult_t);
 }
 #endif
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 
+#include "comm.h"
 #include "common.h"
 
 namespace {
@@ -105,7 +107,60 @@ struct bsig_comm {
   bsig_exchange_fn external = nullptr;   // a caller-supplied exchange (tests, other transports)
   void* external_ctx = nullptr;
   int world = 1, rank = 0, device = -1;
+  bsig::CommXr xr;                 // resident-exchange resources (comm_xr), created on first use
+  bool xr_made = false;
 };
+
+namespace bsig {
+
+int comm_xr(bsig_comm* c, CommXr* out) {
+  BSIG_REQUIRE(c && out, "comm_xr: null");
+  if (c->external) return BSIG_EUNSUPPORTED;
+  if (!c->xr_made) {
+    CommXr x;
+    // A stream of the HIGHEST priority: the runtime multiplexes streams of one priority over a few
+    // hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and an exchange stream that lands on the
+    // queue of the fit's stream sits BEHIND the resident kernel it is meant to answer -- every poll of
+    // the kernel then times out (measured: the fit fell back to the per-phase kernels, 58 us per update).
+    // Priorities have queues of their own.
+    int lo = 0, hi = 0;
+    BSIG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    BSIG_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, hi));
+    {
+      const char* pl = getenv("BSIG_DP_XR_PLAIN_READY");
+      if (pl && pl[0] == '1') BSIG_HIP(hipMalloc(reinterpret_cast<void**>(&x.ready), 256));
+      else BSIG_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&x.ready), 8, hipMallocSignalMemory));
+    }
+    BSIG_HIP(hipMalloc(reinterpret_cast<void**>(&x.done), 512));
+    BSIG_HIP(hipMemset(x.ready, 0, 8));
+    BSIG_HIP(hipMemset(x.done, 0, 512));
+    BSIG_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < CommXr::kRing; ++i) {
+      BSIG_HIP(hipEventCreateWithFlags(&x.ev_begin[i], hipEventDisableTiming));
+      BSIG_HIP(hipEventCreateWithFlags(&x.ev_end[i], hipEventDisableTiming));
+    }
+    c->xr = x;
+    c->xr_made = true;
+  }
+  *out = c->xr;
+  return BSIG_OK;
+}
+
+int comm_xr_advance(bsig_comm* c, unsigned n) {
+  BSIG_REQUIRE(c && c->xr_made, "comm_xr_advance: no resident-exchange state");
+  ++c->xr.calls;
+  c->xr.base += n;
+  if (c->xr.base > (1u << 30)) {      // (once per ~10^9 updates) start over, with nothing in flight
+    BSIG_HIP(hipDeviceSynchronize());
+    BSIG_HIP(hipMemset(c->xr.ready, 0, 8));
+    BSIG_HIP(hipMemset(c->xr.done, 0, 512));
+    BSIG_HIP(hipDeviceSynchronize());
+    c->xr.base = 0;
+  }
+  return BSIG_OK;
+}
+
+}  // namespace bsig
 
 static_assert(sizeof(ncclUniqueId) == BSIG_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
 
@@ -134,6 +189,13 @@ extern "C" int bsig_comm_init(const void* unique_id, int world, int rank, int de
   c->world = world; c->rank = rank; c->device = device;
   ncclUniqueId id;
   std::memcpy(&id, unique_id, sizeof(id));
+  // A rank that stays resident across the exchange (BSIG_DP_RESIDENT=1 with peers: opt-in, never run on
+  // more than one GPU so far) leaves RCCL the 8 CUs its 248 workgroups do not hold: every channel must
+  // be resident on every rank at once, or a ring waits for a workgroup that cannot be scheduled.
+  {
+    const char* r = getenv("BSIG_DP_RESIDENT");
+    if (world > 1 && r && r[0] == '1') setenv("NCCL_MAX_NCHANNELS", "8", 0);
+  }
   int prev = 0;
   (void)hipGetDevice(&prev);
   hipError_t e = hipSetDevice(device);
@@ -196,8 +258,16 @@ extern "C" int bsig_comm_broadcast(bsig_comm* c, float* buf, int64_t n, int root
   return BSIG_OK;
 }
 
+extern "C" int64_t bsig_comm_resident_calls(const bsig_comm* c) { return c && c->xr_made ? (int64_t)c->xr.calls : 0; }
+
 extern "C" void bsig_comm_destroy(bsig_comm* c) {
   if (!c) return;
+  if (c->xr_made) {
+    (void)hipStreamSynchronize(c->xr.stream);
+    for (int i = 0; i < bsig::CommXr::kRing; ++i) { (void)hipEventDestroy(c->xr.ev_begin[i]); (void)hipEventDestroy(c->xr.ev_end[i]); }
+    (void)hipFree(c->xr.ready); (void)hipFree(c->xr.done);
+    (void)hipStreamDestroy(c->xr.stream);
+  }
   if (c->nccl && g_rccl.ok) (void)g_rccl.comm_destroy(c->nccl);
   delete c;
 }

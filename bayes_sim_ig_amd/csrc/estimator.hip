@@ -26,12 +26,14 @@
 // via the column-0 threads, the layer's bias), so an update has no optimizer
 // kernel.  Data parallel: gradients go to the flat buffer, the caller
 // all-reduces it, then one flat Adam kernel runs (bsig_fit_grad / _apply).
+#include "comm.h"
 #include "gemm.h"
 #include "head.h"
 #include "persist.h"
 #include "persist_mdnn.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -443,7 +445,8 @@ static PersistShape persist_shape(const bsig_fit_plan* p) {
 // the pending Adam step of the previous one; n = 0 flushes that step.
 // eval_total > 0: the launch belongs to a call of eval_total updates whose held-out
 // evaluations run inside the launches.
-static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st, int eval_total = 0) {
+static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st, int eval_total = 0,
+                              const CommXr* xr = nullptr) {
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
   PersistBuffers pb;
@@ -457,6 +460,10 @@ static int enqueue_persistent(bsig_fit_plan* p, int n, hipStream_t st, int eval_
   if (p->split_adam) {
     pb.grads = b.grads; pb.adam_pending = p->adam_pending ? 1 : 0;
     p->adam_pending = false;
+  }
+  if (xr) {      // the whole call in one launch, resident across the exchange (persist.h)
+    pb.xr_ready = xr->ready; pb.xr_done = xr->done; pb.xr_base = xr->base;
+    pb.n_total = n;
   }
   if (eval_total > 0) {
     pb.do_eval = 1; pb.n_total = eval_total; pb.eval_every = std::max(eval_total / 5, 1);   // mdnn.py:235
@@ -1246,6 +1253,84 @@ extern "C" int bsig_fit_dp_graph_status(const bsig_fit_plan* p, char* msg, size_
   return p->g_dp_state;
 }
 
+// A data-parallel rank covered by the persistent kernel of the linear heads can stay RESIDENT across
+// the gradient exchange: ONE launch for the call (weights in LDS, moments in registers, held-out
+// evaluations inside, as a single rank), and a second stream that per update waits for the kernel's
+// "gradients are out" word, runs the all-reduce and writes the word the kernel polls
+// (fit_persistent.hip, XR).  No launch boundary and no W / m / v / g round trip through HBM per update.
+// Policy: opt-in, BSIG_DP_RESIDENT=1.  Measured on a 1-rank group (all this pool can run): 29.5 us per
+// update against 34.8 with a launch per update -- when the exchange stream is answered promptly, which
+// depends on what the process did with the GPU before (profiles/r05_NOTES.md, "Resident exchange");
+// when it is not, the bounded polls give up and the fit repeats on the per-phase kernels.  With peers,
+// RCCL's kernels would have to live on the 8 CUs the launch leaves free (comm.cpp caps its channels
+// for that case), which no one has run yet.
+static bool dp_resident_applies(const bsig_fit_plan* p, const bsig_comm* comm, int64_t n_updates) {
+  const char* e = getenv("BSIG_DP_RESIDENT");
+  const bool want = e && e[0] == '1';
+  const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
+  return want && bsig_comm_transport(comm) == 1 && p->persistent && n_updates >= 1 && n_updates == p->n_updates &&
+         !p->adam_pending && p->buf.x_kind == BSIG_X_ROWS && persist_variant(persist_shape(p)) == 2 &&
+         p->buf.n_test >= 1 && persist_eval_supported(persist_shape(p)) && !(no_ike && no_ike[0] == '1');
+}
+
+// One call = ONE launch on `st` and, per update, wait(ready) -> all-reduce -> write(done) on the
+// communicator's exchange stream.  What ties the two streams together, as measured on the pool
+// (profiles/r05_NOTES.md, "Resident exchange"):
+//  * the exchange stream waits for an event recorded on `st` just ahead of the launch before it starts
+//    polling the word: a wait-value packet left polling while `st` still runs the block's projection
+//    GEMMs (10 ms) answered so late afterwards that the first call of a fit timed out;
+//  * `st` does NOT wait for the exchange stream at the end of the call -- it does not have to (the
+//    last write of the call is what lets the kernel finish, so whatever follows the launch in `st`
+//    follows the exchange), and with that wait in place a second call enqueued behind a running one
+//    timed out every time;
+//  * the two words only grow (xr.base), nothing resets them between calls;
+//  * the host keeps the exchange stream at most one call ahead (below).
+static int run_dp_resident(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates, hipStream_t st) {
+  const auto t0_host = std::chrono::steady_clock::now();
+  CommXr xr;
+  BSIG_TRY(comm_xr(comm, &xr));
+  // At most `depth` calls in flight on the exchange stream (BSIG_DP_XR_DEPTH, 0: no limit): the host
+  // waits for the end of call c - depth before it enqueues the exchange of call c (the launch of call c
+  // is in `st` by then, the GPU does not idle).  1: with 3 calls or more of stream operations
+  // outstanding, calls timed out once ~65 000 operations had gone through the stream (always around
+  // the 210th call of a process; depth 1 and 2 ran 400+ calls clean, same speed).
+  static const int depth = [] { const char* e = getenv("BSIG_DP_XR_DEPTH"); return e ? std::min(std::max(atoi(e), 0), CommXr::kRing - 1) : 1; }();
+  const int slot = (int)(xr.calls % CommXr::kRing);
+  BSIG_HIP(hipEventRecord(xr.ev_begin[slot], st));
+  BSIG_HIP(hipStreamWaitEvent(xr.stream, xr.ev_begin[slot], 0));
+  BSIG_TRY(enqueue_persistent(p, (int)n_updates, st, (int)n_updates, &xr));
+  if (depth > 0 && xr.calls >= depth)
+    BSIG_HIP(hipEventSynchronize(xr.ev_end[(int)((xr.calls - depth) % CommXr::kRing)]));
+  // (diagnostics, 1-rank groups only: BSIG_DP_XR_NO_COLLECTIVE=1 leaves the -- identity -- all-reduce
+  // out, which isolates the hand-off from the collective's kernels on the 8 free CUs)
+  const char* nc = getenv("BSIG_DP_XR_NO_COLLECTIVE");
+  const bool skip = nc && nc[0] == '1' && bsig_comm_world(comm) == 1;
+  for (int64_t u = 1; u <= n_updates; ++u) {
+    BSIG_HIP(hipStreamWaitValue32(xr.stream, xr.ready, xr.base + (uint32_t)u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    if (!skip)
+      BSIG_TRY(bsig_comm_allreduce(comm, p->buf.grads, p->L.total, reinterpret_cast<bsig_stream_t>(xr.stream)));
+    BSIG_HIP(hipStreamWriteValue32(xr.stream, xr.done, xr.base + (uint32_t)u, 0));
+  }
+  BSIG_HIP(hipEventRecord(xr.ev_end[slot], xr.stream));
+  BSIG_TRY(comm_xr_advance(comm, (unsigned)n_updates));
+  if (getenv("BSIG_DP_XR_TRACE")) {
+    // (diagnostics) the time-out bit behind every resident call so far, read without a sync (-1: in flight)
+    static int32_t* hist = nullptr; static int n_hist = 0;
+    constexpr int kHist = 4096;
+    if (!hist) {
+      BSIG_HIP(hipHostMalloc(reinterpret_cast<void**>(&hist), kHist * 4, 0));
+      for (int i = 0; i < kHist; ++i) hist[i] = -1;
+    }
+    if (n_hist < kHist) BSIG_HIP(hipMemcpyAsync(&hist[n_hist++], p->buf.state + 2, 4, hipMemcpyDeviceToHost, st));
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "run_dp_resident: %lld updates enqueued in %.1f us of host time; time-out bits so far:", (long long)n_updates,
+            std::chrono::duration<double, std::micro>(t1 - t0_host).count());
+    for (int i = 0; i < n_hist; ++i) fprintf(stderr, " %d", (int)hist[i]);
+    fprintf(stderr, "\n");
+  }
+  return BSIG_OK;
+}
+
 extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates,
                                float* reduced_logs, bsig_stream_t stream) {
   bsig::Range roctx_range("bsig_fit_run_dp");
@@ -1260,10 +1345,15 @@ extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_upda
   if (p->use_graph) BSIG_TRY(ensure_graphs(p));
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
   int64_t n_evals = 0;
+  const bool resident = dp_resident_applies(p, comm, n_updates);
+  if (resident) {
+    BSIG_TRY(run_dp_resident(p, comm, n_updates, as_stream(stream)));
+    n_evals = count_evals(n_updates);
+  }
   const bool was_pending = p->adam_pending;
-  BSIG_TRY(ensure_dp_graph(p, comm));
+  if (!resident) BSIG_TRY(ensure_dp_graph(p, comm));
   p->adam_pending = was_pending;
-  for (int64_t it = 0; it < n_updates; ++it) {
+  for (int64_t it = 0; it < (resident ? 0 : n_updates); ++it) {
     if (p->g_dp_state == 1 && p->adam_pending) {
       // steady state: the captured launch (pending Adam step in, gradients out) + all-reduce
       BSIG_HIP(hipGraphLaunch(p->g_dp, as_stream(stream)));

@@ -73,6 +73,8 @@ struct UArgs {
   float* slabs; float* d_out; float* e_out; unsigned* flag_fwd; unsigned long long* gran;
   // data-parallel ranks (one update per launch; see PersistBuffers)
   float* grads; int adam_pending; int quad_ok;
+  // data-parallel rank RESIDENT across the exchange (XR instantiation; see PersistBuffers)
+  unsigned* xr_ready; const unsigned* xr_done; unsigned* xr_count; unsigned xr_base;   // (xr_count: a word of the sync region)
   // held-out evaluations inside the launch
   int do_eval, eval_every, n_total, n_test, eval_passes, NE, RE;
   int64_t eval_row0;
@@ -506,8 +508,16 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
   }
 
 // DP: data-parallel rank (gradients out, pending Adam step in).  NT: 16-row blocks per tile.
-template <bool DP, int NT>
+// XR (with DP = false): a data-parallel rank that stays RESIDENT across the gradient exchange -- the
+// single-rank kernel (W in LDS, moments in registers, a whole call per launch) whose dW goes to the flat
+// gradient buffer, written through; the tile workgroups count themselves, the last one raises the word
+// a second stream waits on (hipStreamWaitValue32 -> all-reduce -> hipStreamWriteValue32), every tile
+// workgroup polls the word that stream writes, takes its tile of the REDUCED gradients back around
+// the caches and takes the Adam step.  Same arithmetic per element as the other two instantiations:
+// a 1-rank group reproduces the single-rank run bit for bit.
+template <bool DP, int NT, bool XR = false>
 __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, const URole& role) {
+  static_assert(!(DP && XR), "XR is the resident kernel with the exchange inside, not the per-update launch");
   constexpr int NBW = 16 * NT;                 // head rows of the tile
   constexpr int MAXBLK = NT == 1 ? 3 : 2;      // 16-column blocks per wavefront in the dW / Adam phase
   float* Ft = smem;                            // [KS][FP]   minibatch features of this k-slice, transposed
@@ -861,6 +871,8 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
             const int n = n0 + 16 * nt + c16_l;
             if (DP) {
               if (n < Nh) p.grads[p.b_off + n] = g;
+            } else if constexpr (XR) {
+              if (n < Nh) xwg_store(p.grads + p.b_off + n, g);      // (Adam behind the exchange, below)
             } else {
               bw[nt] = adam_bias(g, bm[nt], bv[nt], bw[nt], a0, a1, ak);
               biasl[16 * nt + c16_l] = bw[nt];
@@ -869,6 +881,11 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
         }
       }
       const int n4 = (B + 3) >> 2;
+      // (XR) gradient tile <-> p.grads: byte offset of this lane's 16 bytes in block 0 of tile 0
+      [[maybe_unused]] const int xr_kb = min(p.KB, (p.Fdim - k0) >> 4), xr_nt = 64 * p.Fdim;
+      [[maybe_unused]] const int xr_lane = 4 * ((n0 + 4 * g4_l + (c16_l & 3)) * p.Fdim + k0 + 16 * w + (c16_l & ~3));
+      [[maybe_unused]] __amdgpu_buffer_rsrc_t xr_rsrc;
+      if constexpr (XR) xr_rsrc = xwg_buffer_n(p.grads + p.w_off, 4 * Nh * p.Fdim);
       const float* ap = XS + c16_l * FP + 4 * g4_l;
 #pragma unroll
       for (int jj = 0; jj < MAXBLK; ++jj) {
@@ -912,6 +929,20 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
                 const int n = n0 + 16 * nt + 4 * g4_l + v, kc = k0 + 16 * j + c16_l;
                 if (n < Nh && kc < p.Fdim) p.grads[p.w_off + (int64_t)n * p.Fdim + kc] = acc[nt][v];
               }
+          } else if constexpr (XR) {
+            // ... written through (the exchange stream's all-reduce reads it from memory), 16 bytes per
+            // lane: the accumulator of a lane is four ROWS of one column, a 4 x 4 transpose inside the
+            // lane quad makes that four columns of a row -- a cross-workgroup payload costs by its
+            // memory transactions (dword stores: 58 us per update with the exchange instead of 34).
+            // ONE lane offset for all blocks (block jj: an immediate, tile nt: the scalar offset; rows
+            // beyond Nh fall off the end of the buffer).
+            if (j < xr_kb) {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 q = quad_transpose4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3], c16_l & 3);
+                xwg_store4s(xr_rsrc, xr_lane + jj * 512, nt * xr_nt, q);
+              }
+            }
           } else {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -923,10 +954,74 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
           }
         }
       }
+      if constexpr (XR) {
+        // ---- the exchange: gradients out (acknowledged), count, signal, wait, reduced gradients in ----
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        BSIG_USTAMP(13);
+        if (tid_l == 0) {
+          const unsigned done_upd = (unsigned)step + 1u;      // updates of this call whose gradients are out
+          const unsigned old = __hip_atomic_fetch_add(p.xr_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned target = p.xr_base + done_upd;
+          if (old + 1u == done_upd * (unsigned)p.G)           // the last tile workgroup: ONE system-scope store
+            __hip_atomic_store(p.xr_ready, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          int spins = 0;
+          while ((int)(__hip_atomic_load(p.xr_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
+            if (++spins > (1 << 23)) { atomicOr(flagp, 2); break; }      // (bounded like every poll of the kernel)
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+        // (a run that gave up finishes this update on whatever the buffer holds and leaves at the top of
+        // the next one, the call fails with the sticky time-out error; a `break` HERE keeps every
+        // loop-carried register alive on one more path: 300 bytes of scratch per lane, 58 us per update)
+        (void)run_aborted(flagp, red, tid);
+        BSIG_USTAMP(14);
+        if (ks == 0 && w == 7 && g4_l == 0) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + 16 * nt + c16_l;
+            const float g = n < Nh ? xwg_load(p.grads + p.b_off + n) : 0.f;
+            bw[nt] = adam_bias(g, bm[nt], bv[nt], bw[nt], a0, a1, ak);
+            biasl[16 * nt + c16_l] = bw[nt];
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < MAXBLK; ++jj) {
+          const int j = w + 8 * jj;
+          if (j < p.KB) {
+            float gr[NT][4];
+            f32x4 gq[NT];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)      // (rows beyond Nh: zeros; every lane takes part in the transposes)
+              gq[nt] = j < xr_kb ? xwg_load4s(xr_rsrc, xr_lane + jj * 512, nt * xr_nt) : zero;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const f32x4 c = quad_transpose4(gq[nt][0], gq[nt][1], gq[nt][2], gq[nt][3], c16_l & 3);
+#pragma unroll
+              for (int v = 0; v < 4; ++v) gr[nt][v] = c[v];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                float* wp = Wl + (16 * nt + 4 * g4_l + v) * WP + 16 * j + c16_l;
+                *wp = adam_weight(gr[nt][v], Mr[jj][nt][v], Vr[jj][nt][v], *wp, a0, a1, ak);
+              }
+          }
+        }
+      }
       BSIG_USTAMP(8);
       lds_barrier();                 // (the next minibatch tile stays in flight)
       BSIG_USTAMP(12);
     }
+  }
+  if constexpr (XR) {
+    // a launch that gave up (a bounded poll timed out, here or in any workgroup) must not leave the
+    // exchange stream waiting for gradients that will never come: every wait of the call passes
+    if (slot == 0 && tid == 0 &&
+        (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2))
+      __hip_atomic_store(p.xr_ready, p.xr_base + (unsigned)p.n_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 
   // ---- evaluations still owed at the end of the launch ------------------------------------------
@@ -1030,13 +1125,13 @@ __device__ __forceinline__ void owner_only_workgroup(const UArgs& p, float* smem
   }
 }
 
-template <bool DP, int NT>
+template <bool DP, int NT, bool XR = false>
 __global__ __launch_bounds__(kUT) void linear_head_updates_kernel(UArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifndef BSIG_HOST_SAN_BUILD   // (see fit_persistent_mdnn.hip)
   const URole role = wg_role(blockIdx.x, p.T, p.G);
   if (role.tile < 0) owner_only_workgroup(p, smem, role, 16 * NT, DP);
-  else unified_workgroup<DP, NT>(p, smem, role);
+  else unified_workgroup<DP, NT, XR>(p, smem, role);
 #endif
 }
 
@@ -1207,7 +1302,8 @@ bool persist_eval_supported(const PersistShape& s) {
 static size_t u_data_bytes(const UGeom& g) {
   return round_up<size_t>((g.slab_floats + 2 * g.dout_floats + g.eval_floats) * sizeof(float), 256);
 }
-static size_t u_sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + 6 * kGranArr * 8; }
+// flags, granules and (last 256 bytes) the word the tile workgroups of a resident rank count themselves in
+static size_t u_sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + 6 * kGranArr * 8 + 256; }
 
 size_t persist_workspace_bytes(const PersistShape& s) {
   const int v = persist_variant(s);
@@ -1245,9 +1341,13 @@ static int u_launch(const UGeom& g, const UArgs& p, bool dp, int n, bool do_eval
                                  hipFuncAttributeMaxDynamicSharedMemorySize, kULds));
     BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_head_updates_kernel<true, NT>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, kULds));
+    BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_head_updates_kernel<false, NT, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kULds));
     attr_set = true;
   }
-  if (dp)
+  if (p.xr_ready)
+    hipLaunchKernelGGL((linear_head_updates_kernel<false, NT, true>), dim3(g.T), dim3(kUT), g.lds, st, p);
+  else if (dp)
     hipLaunchKernelGGL((linear_head_updates_kernel<true, NT>), dim3(g.T), dim3(kUT), g.lds, st, p);
   else
     hipLaunchKernelGGL((linear_head_updates_kernel<false, NT>), dim3(g.T), dim3(kUT), g.lds, st, p);
@@ -1267,7 +1367,12 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   BSIG_REQUIRE(b.ld_feats % 4 == 0 && aligned(b.feats, 16) && b.ld_feats >= s.feat_dim,
                "persistent updates: features must be 16-byte aligned rows");
   BSIG_REQUIRE(!(b.adam_pending && !b.grads), "persistent updates: pending Adam step without gradients");
-  BSIG_REQUIRE(!(b.grads && n > 1), "persistent updates: data-parallel launches take one update");
+  BSIG_REQUIRE(!(b.grads && n > 1 && !b.xr_ready), "persistent updates: data-parallel launches take one update");
+  BSIG_REQUIRE(!(b.xr_ready && !(b.grads && b.xr_done && !b.adam_pending && b.n_total == n)),
+               "persistent updates: a resident data-parallel launch takes the whole call");
+  BSIG_REQUIRE(!(b.xr_ready && !(b.w_off % 4 == 0 && s.feat_dim % 4 == 0 && aligned(b.grads, 16) &&
+                                 (int64_t)g.Nh * s.feat_dim < ((int64_t)1 << 29))),
+               "persistent updates: a resident data-parallel launch moves 16-byte gradient quads");
   if (n <= 0 && !b.adam_pending && !b.do_eval) return BSIG_OK;
   UArgs p{};
   p.B = s.batch; p.Bp = g.Bp; p.MT = g.MT;
@@ -1276,6 +1381,8 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.n_blocks = g.n_blocks; p.k_slices = g.k_slices; p.G = g.G; p.T = g.T; p.n_owner = g.n_owner; p.R = g.R;
   p.n_updates = std::max(n, 0); p.xs_floats = g.xs_floats;
   p.grads = b.grads; p.adam_pending = b.adam_pending;
+  p.xr_ready = b.xr_ready; p.xr_done = b.xr_done; p.xr_base = b.xr_base;
+  p.xr_count = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(b.workspace) + u_data_bytes(g) + u_sync_bytes() - 256);
   p.feats = b.feats; p.ld_feats = b.ld_feats; p.feat_ids = b.feat_ids; p.y = b.y; p.ldy = b.ldy; p.ids = b.ids;
   p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq; p.w_off = b.w_off; p.b_off = b.b_off;
   p.quad_ok = (p.w_off % 4 == 0 && p.Fdim % 4 == 0 &&
@@ -1310,6 +1417,7 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
     const char* t0 = getenv("BSIG_PROF_T0");
     p.prof_t0 = t0 ? atoi(t0) : 0;
   }
+  if (b.xr_ready && !p.n_total) p.n_total = n;      // (the release of a launch that gave up: every wait passes)
   return g.NT == 1 ? u_launch<1>(g, p, b.grads != nullptr, n, b.do_eval != 0, st)
                    : u_launch<2>(g, p, b.grads != nullptr, n, b.do_eval != 0, st);
 }

@@ -72,6 +72,20 @@ constexpr int kXwgPolicy = 16;          // gfx940+: sc1
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xwg_buffer(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
 }
+// ... a buffer of `bytes` bytes: loads beyond it return zeros, stores beyond it are dropped
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xwg_buffer_n(const float* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+// ... 16 bytes at byte offset voff (per lane) + soff (uniform)
+__device__ __forceinline__ void xwg_store4s(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 q) {
+  const u32x4 v = {__float_as_uint(q[0]), __float_as_uint(q[1]), __float_as_uint(q[2]), __float_as_uint(q[3])};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, kXwgPolicy);
+}
+__device__ __forceinline__ f32x4 xwg_load4s(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kXwgPolicy);
+  f32x4 f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+  return f;
+}
 __device__ __forceinline__ void xwg_store4(__amdgpu_buffer_rsrc_t r, int float_off, float a, float b,
                                            float c, float d) {
   const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
@@ -81,6 +95,23 @@ __device__ __forceinline__ f32x4 xwg_load4(__amdgpu_buffer_rsrc_t r, int float_o
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, kXwgPolicy);
   f32x4 f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
   return f;
+}
+
+// 4 x 4 transpose across the four lanes of a quad (lanes 4q .. 4q+3, a = lane & 3): lane a comes in with
+// column a of a 4 x 4 block, c[r] = M[r][a], and leaves with row a, M[a][0..3].  A 32x32 accumulator lane
+// holds four consecutive ROWS of one column; a cross-workgroup payload is stored 16 bytes per lane along a
+// row (it costs by the number of memory transactions): two butterfly steps turn the one into the other.
+__device__ __forceinline__ f32x4 quad_transpose4(float c0, float c1, float c2, float c3, int a) {
+  const bool odd = a & 1, hi = a & 2;
+  // step 1, partner a ^ 1: even lanes end with rows 0 and 2 of columns (a, a + 1), odd ones with rows 1 and 3
+  const float r0 = __shfl_xor(odd ? c0 : c1, 1, 64), r1 = __shfl_xor(odd ? c2 : c3, 1, 64);
+  const float pA0 = odd ? r0 : c0, pA1 = odd ? c1 : r0;      // row 0 / 1, the lane pair's two columns
+  const float pB0 = odd ? r1 : c2, pB1 = odd ? c3 : r1;      // row 2 / 3
+  // step 2, partner a ^ 2: lanes 0, 1 keep their row 0 / 1 pair and take the other pair's, lanes 2, 3 rows 2 / 3
+  const float q0 = __shfl_xor(hi ? pA0 : pB0, 2, 64), q1 = __shfl_xor(hi ? pA1 : pB1, 2, 64);
+  f32x4 out;
+  out[0] = hi ? q0 : pA0; out[1] = hi ? q1 : pA1; out[2] = hi ? pB0 : q0; out[3] = hi ? pB1 : q1;
+  return out;
 }
 
 }  // namespace bsig

@@ -130,23 +130,6 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// 4 x 4 transpose across the four lanes of a quad (lanes 4q .. 4q+3, a = lane & 3): lane a comes in with
-// column a of a 4 x 4 block, c[r] = M[r][a], and leaves with row a, M[a][0..3].  A 32x32 accumulator lane
-// holds four consecutive ROWS of one column; a cross-workgroup payload is stored 16 bytes per lane along a
-// row (it costs by the number of memory transactions): two butterfly steps turn the one into the other.
-__device__ __forceinline__ f32x4 quad_transpose4(float c0, float c1, float c2, float c3, int a) {
-  const bool odd = a & 1, hi = a & 2;
-  // step 1, partner a ^ 1: even lanes end with rows 0 and 2 of columns (a, a + 1), odd ones with rows 1 and 3
-  const float r0 = __shfl_xor(odd ? c0 : c1, 1, 64), r1 = __shfl_xor(odd ? c2 : c3, 1, 64);
-  const float pA0 = odd ? r0 : c0, pA1 = odd ? c1 : r0;      // row 0 / 1, the lane pair's two columns
-  const float pB0 = odd ? r1 : c2, pB1 = odd ? c3 : r1;      // row 2 / 3
-  // step 2, partner a ^ 2: lanes 0, 1 keep their row 0 / 1 pair and take the other pair's, lanes 2, 3 rows 2 / 3
-  const float q0 = __shfl_xor(hi ? pA0 : pB0, 2, 64), q1 = __shfl_xor(hi ? pA1 : pB1, 2, 64);
-  f32x4 out;
-  out[0] = hi ? q0 : pA0; out[1] = hi ? q1 : pA1; out[2] = hi ? pB0 : q0; out[3] = hi ? pB1 : q1;
-  return out;
-}
-
 // First-layer inputs from cross-correlation FACTOR rows (summarizers.py:106-119; layout in
 // bsig.h): x[i*A + j] = sf[i] * af[j] -- the one fp32 multiply the summarizer itself would
 // do --, x[S*A] = mean * 1, x[S*A + 1] = std * 1; columns beyond that come out as 1 * 1 and

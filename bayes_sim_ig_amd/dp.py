@@ -106,6 +106,11 @@ class DataParallel:
     _on_gpu = False
     _error = None
 
+    def resident_calls(self):
+        """(diagnostics) run_training calls this rank ran RESIDENT across the gradient exchange: one
+        launch per call, the all-reduces on a second stream (BSIG_DP_RESIDENT)."""
+        return int(_lib.load().bsig_comm_resident_calls(self.comm)) if self.comm is not None else 0
+
     def close(self):
         if self.comm is not None:
             _lib.load().bsig_comm_destroy(self.comm)

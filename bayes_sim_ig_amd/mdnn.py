@@ -270,6 +270,10 @@ class MDNN(nn.Module):
 
     def _disable_persistent(self):
         """From now on this model's plans use the per-phase kernels."""
+        import warnings
+        warnings.warn('bayes_sim_ig_amd: a persistent update launch timed out waiting for another workgroup '
+                      '(GPU shared with another process?); this model continues on the per-phase kernels, '
+                      'which are slower', RuntimeWarning, stacklevel=3)
         self._no_persistent = True
         self._drop_plan()
 

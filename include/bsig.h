@@ -398,6 +398,9 @@ int bsig_comm_init_external(int world, int rank, bsig_exchange_fn exchange, void
 int bsig_comm_transport(const bsig_comm* comm);
 int bsig_comm_world(const bsig_comm* comm);
 int bsig_comm_rank(const bsig_comm* comm);
+/* (diagnostics) bsig_fit_run_dp calls this communicator ran with the rank RESIDENT across the exchange
+ * (one launch per call, the all-reduces on a second stream: INTEGRATION.md, BSIG_DP_RESIDENT) */
+int64_t bsig_comm_resident_calls(const bsig_comm* comm);
 /* buf[n] (device, fp32) <- sum over ranks, in place, asynchronous on `stream`. */
 int bsig_comm_allreduce(bsig_comm* comm, float* buf, int64_t n, bsig_stream_t stream);
 /* buf[n] <- rank `root`'s buf (replica initialisation). */

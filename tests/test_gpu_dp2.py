@@ -108,3 +108,43 @@ def test_two_rank_fit_with_rank_local_jitter_scale(tmp_path):
         got, exp = np.asarray(res['logs'][key]), np.asarray(logs[key])
         print(key, 'max rel effect of rank-local jitter:', float(np.max(np.abs(got - exp) / np.abs(exp))))
         np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-6)
+
+
+def test_rank_resident_across_the_exchange_is_bitwise_the_per_update_launches(monkeypatch):
+    """BSIG_DP_RESIDENT: ONE launch per run_training call, the gradients handed to the exchange
+    stream's all-reduce and back per update (fit_persistent.hip, XR), against a launch + all-reduce
+    per update -- on a 1-rank RCCL group (all this pool can run): the same kernels' arithmetic in the
+    same order, so parameters and logs must be bit-identical; and the resident launches must really
+    have run (not timed out into the per-phase fallback, which would agree as well)."""
+    import warnings
+    import bench
+    import bayes_sim_ig_amd as pkg
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29581')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    try:
+        cfg = dict(bench.CONFIGS['cfg5'])
+        theta, states, actions = bench.synth_pairs(cfg, 5000, 21, 'cuda:0')
+        out = {}
+        for mode in ('0', '1'):
+            monkeypatch.setenv('BSIG_DP_RESIDENT', mode)
+            bs = bench.build_gpu_model(pkg, cfg, 'cuda:0', 31)
+            bs.model.enable_data_parallel()
+            np.random.seed(32)
+            before = bs.model._dp.resident_calls()
+            with warnings.catch_warnings():
+                warnings.simplefilter('error', RuntimeWarning)      # a time-out fallback is a failure here
+                logs = bs.fit(theta, states, actions)
+                logs += bs.fit(theta, states, actions)               # (a second fit right behind the first)
+            torch.cuda.synchronize()
+            assert not getattr(bs.model, '_no_persistent', False)
+            out[mode] = (logs, bs.model._flat.clone(), bs.model._dp.resident_calls() - before)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert out['0'][2] == 0 and out['1'][2] == 10, (out['0'][2], out['1'][2])
+    assert torch.equal(out['0'][1], out['1'][1])
+    for a, b in zip(out['0'][0], out['1'][0]):
+        assert a == b
