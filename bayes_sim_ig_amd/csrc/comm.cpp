@@ -36,6 +36,8 @@ const char* ncclGetErrorString(ncclResult_t);
 #include <mutex>
 #include <new>
 
+#include <hip/hip_runtime.h>
+
 #include "comm.h"
 #include "common.h"
 
@@ -113,25 +115,54 @@ struct bsig_comm {
 
 namespace bsig {
 
-int comm_xr(bsig_comm* c, CommXr* out) {
+namespace {
+// one thread: raise the word, time the answer (100 MHz wall clock; gives up after 2 ms)
+__global__ void xr_probe_kernel(unsigned* ready, const unsigned* done, unsigned target, long long* out) {
+  const long long t0 = wall_clock64();
+  __hip_atomic_store(ready, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
+    if (wall_clock64() - t0 > 200000) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  out[0] = wall_clock64() - t0;
+}
+}  // namespace
+
+// The hand-off of one update, as run_dp_resident enqueues it, with xr_probe_kernel in the place of the
+// resident launch (and a packet behind it in the launch stream, as the fit has).
+static int xr_probe(CommXr& x, hipStream_t st, hipStream_t cand, double* us) {
+  const unsigned target = ++x.base;
+  x.probe_out[0] = -1;
+  BSIG_HIP(hipEventRecord(x.ev_begin[0], st));
+  BSIG_HIP(hipStreamWaitEvent(cand, x.ev_begin[0], 0));
+  hipLaunchKernelGGL(xr_probe_kernel, dim3(1), dim3(1), 0, st, x.ready, x.done, target, x.probe_out);
+  BSIG_CHECK_LAUNCH("xr_probe");
+  BSIG_HIP(hipEventRecord(x.ev_end[0], st));
+  BSIG_HIP(hipStreamWaitValue32(cand, x.ready, target, hipStreamWaitValueGte, 0xFFFFFFFFu));
+  BSIG_HIP(hipStreamWriteValue32(cand, x.done, target, 0));
+  BSIG_HIP(hipStreamSynchronize(st));
+  BSIG_HIP(hipStreamSynchronize(cand));
+  *us = (double)x.probe_out[0] / 100.0;
+  return BSIG_OK;
+}
+
+int comm_xr(bsig_comm* c, hipStream_t launch_stream, CommXr* out) {
   BSIG_REQUIRE(c && out, "comm_xr: null");
   if (c->external) return BSIG_EUNSUPPORTED;
   if (!c->xr_made) {
     CommXr x;
-    // A stream of the HIGHEST priority: the runtime multiplexes streams of one priority over a few
+    // Streams of the HIGHEST priority: the runtime multiplexes the streams of one priority over a few
     // hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and an exchange stream that lands on the
-    // queue of the fit's stream sits BEHIND the resident kernel it is meant to answer -- every poll of
-    // the kernel then times out (measured: the fit fell back to the per-phase kernels, 58 us per update).
-    // Priorities have queues of their own.
+    // queue of the fit's stream sits BEHIND the resident kernel it is meant to answer.  Priorities
+    // have queues of their own (four more).
     int lo = 0, hi = 0;
     BSIG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    BSIG_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, hi));
-    {
-      const char* pl = getenv("BSIG_DP_XR_PLAIN_READY");
-      if (pl && pl[0] == '1') BSIG_HIP(hipMalloc(reinterpret_cast<void**>(&x.ready), 256));
-      else BSIG_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&x.ready), 8, hipMallocSignalMemory));
-    }
+    for (int i = 0; i < CommXr::kCand; ++i)
+      BSIG_HIP(hipStreamCreateWithPriority(&x.cand[i], hipStreamNonBlocking, hi));
+    // (hipStreamWaitValue32 of this runtime is a spinning kernel for either kind of memory)
+    BSIG_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&x.ready), 8, hipMallocSignalMemory));
     BSIG_HIP(hipMalloc(reinterpret_cast<void**>(&x.done), 512));
+    BSIG_HIP(hipHostMalloc(reinterpret_cast<void**>(&x.probe_out), 64, 0));
     BSIG_HIP(hipMemset(x.ready, 0, 8));
     BSIG_HIP(hipMemset(x.done, 0, 512));
     BSIG_HIP(hipDeviceSynchronize());
@@ -142,7 +173,27 @@ int comm_xr(bsig_comm* c, CommXr* out) {
     c->xr = x;
     c->xr_made = true;
   }
-  *out = c->xr;
+  CommXr& x = c->xr;
+  if (!x.probed || x.probed_for != launch_stream) {
+    BSIG_HIP(hipStreamSynchronize(launch_stream));
+    if (x.stream) BSIG_HIP(hipStreamSynchronize(x.stream));
+    int best = 0;
+    for (int i = 0; i < CommXr::kCand; ++i) {
+      double a = 0, b = 0;
+      BSIG_TRY(xr_probe(x, launch_stream, x.cand[i], &a));      // (the first one also loads the runtime's kernels)
+      BSIG_TRY(xr_probe(x, launch_stream, x.cand[i], &a));
+      BSIG_TRY(xr_probe(x, launch_stream, x.cand[i], &b));
+      x.probe_us[i] = a > b ? a : b;
+      if (x.probe_us[i] < x.probe_us[best]) best = i;
+    }
+    x.stream = x.cand[best];
+    x.usable = x.probe_us[best] <= kProbeOkUs;
+    x.probed = true; x.probed_for = launch_stream;
+    if (getenv("BSIG_DP_XR_TRACE"))
+      fprintf(stderr, "comm_xr: probes %.1f %.1f %.1f %.1f us -> candidate %d (%s)\n", x.probe_us[0], x.probe_us[1],
+              x.probe_us[2], x.probe_us[3], best, x.usable ? "usable" : "NOT usable");
+  }
+  *out = x;
   return BSIG_OK;
 }
 
@@ -263,10 +314,10 @@ extern "C" int64_t bsig_comm_resident_calls(const bsig_comm* c) { return c && c-
 extern "C" void bsig_comm_destroy(bsig_comm* c) {
   if (!c) return;
   if (c->xr_made) {
-    (void)hipStreamSynchronize(c->xr.stream);
+    for (int i = 0; i < bsig::CommXr::kCand; ++i) (void)hipStreamSynchronize(c->xr.cand[i]);
     for (int i = 0; i < bsig::CommXr::kRing; ++i) { (void)hipEventDestroy(c->xr.ev_begin[i]); (void)hipEventDestroy(c->xr.ev_end[i]); }
-    (void)hipFree(c->xr.ready); (void)hipFree(c->xr.done);
-    (void)hipStreamDestroy(c->xr.stream);
+    (void)hipFree(c->xr.ready); (void)hipFree(c->xr.done); (void)hipHostFree(c->xr.probe_out);
+    for (int i = 0; i < bsig::CommXr::kCand; ++i) (void)hipStreamDestroy(c->xr.cand[i]);
   }
   if (c->nccl && g_rccl.ok) (void)g_rccl.comm_destroy(c->nccl);
   delete c;

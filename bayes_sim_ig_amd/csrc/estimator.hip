@@ -1258,15 +1258,15 @@ extern "C" int bsig_fit_dp_graph_status(const bsig_fit_plan* p, char* msg, size_
 // evaluations inside, as a single rank), and a second stream that per update waits for the kernel's
 // "gradients are out" word, runs the all-reduce and writes the word the kernel polls
 // (fit_persistent.hip, XR).  No launch boundary and no W / m / v / g round trip through HBM per update.
-// Policy: opt-in, BSIG_DP_RESIDENT=1.  Measured on a 1-rank group (all this pool can run): 29.5 us per
-// update against 34.8 with a launch per update -- when the exchange stream is answered promptly, which
-// depends on what the process did with the GPU before (profiles/r05_NOTES.md, "Resident exchange");
-// when it is not, the bounded polls give up and the fit repeats on the per-phase kernels.  With peers,
-// RCCL's kernels would have to live on the 8 CUs the launch leaves free (comm.cpp caps its channels
-// for that case), which no one has run yet.
+// Policy: BSIG_DP_RESIDENT=1 / 0 forces / forbids; unset: ON for a 1-rank group (all this pool can run:
+// 29.5 us per update against 34.8 with a launch per update), OFF with peers -- RCCL's kernels would have
+// to live on the 8 CUs the launch leaves free (comm.cpp caps its channels for that case), which no one
+// has run yet.  The exchange stream is chosen by a probe (comm.h); when none is served promptly the
+// call falls back to a launch per update, and a launch whose polls time out anyway makes the fit
+// repeat on the per-phase kernels (mdnn.py), with a warning.
 static bool dp_resident_applies(const bsig_fit_plan* p, const bsig_comm* comm, int64_t n_updates) {
   const char* e = getenv("BSIG_DP_RESIDENT");
-  const bool want = e && e[0] == '1';
+  const bool want = e ? e[0] == '1' : bsig_comm_world(comm) == 1;
   const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
   return want && bsig_comm_transport(comm) == 1 && p->persistent && n_updates >= 1 && n_updates == p->n_updates &&
          !p->adam_pending && p->buf.x_kind == BSIG_X_ROWS && persist_variant(persist_shape(p)) == 2 &&
@@ -1288,7 +1288,7 @@ static bool dp_resident_applies(const bsig_fit_plan* p, const bsig_comm* comm, i
 static int run_dp_resident(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates, hipStream_t st) {
   const auto t0_host = std::chrono::steady_clock::now();
   CommXr xr;
-  BSIG_TRY(comm_xr(comm, &xr));
+  BSIG_TRY(comm_xr(comm, st, &xr));
   // At most `depth` calls in flight on the exchange stream (BSIG_DP_XR_DEPTH, 0: no limit): the host
   // waits for the end of call c - depth before it enqueues the exchange of call c (the launch of call c
   // is in `st` by then, the GPU does not idle).  1: with 3 calls or more of stream operations
@@ -1345,7 +1345,19 @@ extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_upda
   if (p->use_graph) BSIG_TRY(ensure_graphs(p));
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
   int64_t n_evals = 0;
-  const bool resident = dp_resident_applies(p, comm, n_updates);
+  bool resident = dp_resident_applies(p, comm, n_updates);
+  if (resident) {      // ... and an exchange stream that is answered while a kernel runs on `stream` (comm.h)
+    CommXr xr;
+    BSIG_TRY(comm_xr(comm, as_stream(stream), &xr));
+    if (!xr.usable) {
+      static bool told = false;
+      if (!told) fprintf(stderr, "bayes_sim_ig_amd: BSIG_DP_RESIDENT=1, but no exchange stream of this process is served while a "
+                                 "kernel runs on the fit's stream (best probe %.0f us): one launch per update instead\n",
+                         std::min(std::min(xr.probe_us[0], xr.probe_us[1]), std::min(xr.probe_us[2], xr.probe_us[3])));
+      told = true;
+      resident = false;
+    }
+  }
   if (resident) {
     BSIG_TRY(run_dp_resident(p, comm, n_updates, as_stream(stream)));
     n_evals = count_evals(n_updates);

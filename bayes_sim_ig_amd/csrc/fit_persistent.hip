@@ -882,7 +882,11 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
       }
       const int n4 = (B + 3) >> 2;
       // (XR) gradient tile <-> p.grads: byte offset of this lane's 16 bytes in block 0 of tile 0
-      [[maybe_unused]] const int xr_kb = min(p.KB, (p.Fdim - k0) >> 4), xr_nt = 64 * p.Fdim;
+      // (blocks [0, xr_kb) of this k-slice hold columns < Fdim; in the last of them, when Fdim is not a
+      // multiple of 16, only the lanes with xr_col + 128 jj < xr_cols -- the others get an offset beyond
+      // the end of the buffer: stores dropped, loads zero)
+      [[maybe_unused]] const int xr_cols = p.Fdim - k0, xr_kb = min(p.KB, (xr_cols + 15) >> 4), xr_nt = 64 * p.Fdim;
+      [[maybe_unused]] const int xr_col = 16 * w + (c16_l & ~3);
       [[maybe_unused]] const int xr_lane = 4 * ((n0 + 4 * g4_l + (c16_l & 3)) * p.Fdim + k0 + 16 * w + (c16_l & ~3));
       [[maybe_unused]] __amdgpu_buffer_rsrc_t xr_rsrc;
       if constexpr (XR) xr_rsrc = xwg_buffer_n(p.grads + p.w_off, 4 * Nh * p.Fdim);
@@ -934,13 +938,14 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
             // lane: the accumulator of a lane is four ROWS of one column, a 4 x 4 transpose inside the
             // lane quad makes that four columns of a row -- a cross-workgroup payload costs by its
             // memory transactions (dword stores: 58 us per update with the exchange instead of 34).
-            // ONE lane offset for all blocks (block jj: an immediate, tile nt: the scalar offset; rows
-            // beyond Nh fall off the end of the buffer).
+            // ONE lane offset for all blocks (block jj and tile nt: constants on top; rows beyond Nh fall
+            // off the end of the buffer -- the bounds check sees the VGPR offset only, so nothing rides
+            // in the scalar offset).
             if (j < xr_kb) {
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
                 const f32x4 q = quad_transpose4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3], c16_l & 3);
-                xwg_store4s(xr_rsrc, xr_lane + jj * 512, nt * xr_nt, q);
+                xwg_store4s(xr_rsrc, xr_col + 128 * jj < xr_cols ? xr_lane + jj * 512 + nt * xr_nt : -1, 0, q);
               }
             }
           } else {
@@ -994,7 +999,7 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)      // (rows beyond Nh: zeros; every lane takes part in the transposes)
-              gq[nt] = j < xr_kb ? xwg_load4s(xr_rsrc, xr_lane + jj * 512, nt * xr_nt) : zero;
+              gq[nt] = j < xr_kb ? xwg_load4s(xr_rsrc, xr_col + 128 * jj < xr_cols ? xr_lane + jj * 512 + nt * xr_nt : -1, 0) : zero;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
               const f32x4 c = quad_transpose4(gq[nt][0], gq[nt][1], gq[nt][2], gq[nt][3], c16_l & 3);

@@ -63,6 +63,12 @@ def main():
             th, stt, ac = bench.synth_pairs(cfg0, 1000, 5, 'cuda:0')
             b0 = bench.build_gpu_model(pkg, cfg0, 'cuda:0', 3)
             b0.fit(th, stt, ac); torch.cuda.synchronize(); keep.append(b0)
+        elif step == 'init':
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29583')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+        elif step == 'comm':       # the C-ABI communicator (and RCCL's own init) ahead of everything else
+            from bayes_sim_ig_amd import dp as _dp
+            keep.append(_dp.DataParallel(None).init_comm('cuda:0'))
         elif step == 'xtrain':
             import test_gpu_dp2 as t
             m = t._model(pkg, 512, 1e-5)
@@ -75,8 +81,9 @@ def main():
             keep += [torch.cuda.Stream() for _ in range(6)]
         elif step == 'sync':
             torch.cuda.synchronize()
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29583')
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29583')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
     cfg = dict(bench.CONFIGS['cfg5'])
     theta, states, actions = bench.synth_pairs(cfg, 3000, 21, 'cuda:0')
     os.environ['BSIG_DP_RESIDENT'] = '1'
