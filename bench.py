@@ -997,7 +997,10 @@ def main():
                 'gradient_exchange': ('rccl all-reduce' if os.environ.get('BENCH_BACKEND', 'nccl') == 'nccl'
                                       else os.environ['BENCH_BACKEND'] + ' all-reduce (functional check)')
                 if dist is not None else 'none',
-                'hip_graph': not args.no_graph},
+                'hip_graph': not args.no_graph,
+                # run_training calls of this rank that ran as ONE launch, resident across the gradient
+                # exchange (BSIG_DP_RESIDENT; the default on a 1-rank group), warm-up included
+                'rank_resident_calls': bsim.model._dp.resident_calls() if dist is not None else None},
             'sgd_visits_per_sec': value * 10.0,
             'heldout_nll_last_step_mean': final_test,
         }

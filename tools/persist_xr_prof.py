@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-os.environ['BSIG_DP_RESIDENT'] = '1'
+os.environ['BSIG_DP_RESIDENT'] = '1'      # (the default on a 1-rank group)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench                     # noqa: E402
 import bayes_sim_ig_amd as B     # noqa: E402
@@ -29,15 +29,13 @@ bs.model.enable_data_parallel()
 bs.fit(theta, states, actions)       # (the fit's own chunk protocol: pre-projected features)
 buf = torch.zeros(2 * 256 * 8 * 16, dtype=torch.int64, device=dev)
 lib.bsig_debug_persist_profile(buf.data_ptr())
-print('profiled fit', file=sys.stderr, flush=True)
 logs = bs.fit(theta, states, actions)
 torch.cuda.synchronize()
-print('chunks:', len(logs), [float(l['train_loss'][-1]) for l in logs], file=sys.stderr, flush=True)
 lib.bsig_debug_persist_profile(None)
 st = buf.cpu().numpy().reshape(2, 256, 8, 16).astype(np.float64)[0] / 100.0
-print('nonzero stamps in the buffer:', int((buf != 0).sum()), file=sys.stderr)
-print('stamped slots per index:', [(k, int((st[:, 1, k] > 0).sum())) for k in range(16)])
 tiles = [g for g in range(256) if st[g, 1, 13] > 0]
+if not tiles:
+    sys.exit('no stamps of a resident launch: the call ran one launch per update (BSIG_DP_XR_TRACE=1 shows the probes)')
 owners = [g for g in range(256) if st[g, 1, 4] > 0 and g not in tiles]
 print('%d tile workgroups (resident across the exchange), %d row owners; updates %s + 1..7'
       % (len(tiles), len(owners), os.environ.get('BSIG_PROF_T0', '0')))
