@@ -489,7 +489,8 @@ static PersistMdnnShape persist_mdnn_shape(const bsig_fit_plan* p) {
 
 // n consecutive updates of the two-layer MDNN in its persistent kernel (with_eval: a whole
 // bsig_fit_run call, its held-out evaluations inside the launch)
-static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, int eval_total = 0) {
+static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, int eval_total = 0,
+                                   const CommXr* xr = nullptr) {
   PlanMem m; plan_mem(p, &m);
   const bsig_fit_buffers& b = p->buf;
   PersistMdnnBuffers pb;
@@ -505,6 +506,9 @@ static int enqueue_persistent_mdnn(bsig_fit_plan* p, int n, hipStream_t st, int 
   if (p->split_adam) {
     pb.grads = b.grads; pb.adam_pending = p->adam_pending ? 1 : 0;
     p->adam_pending = false;
+  }
+  if (xr) {      // the whole call in one launch, resident across the exchange (persist_mdnn.h)
+    pb.xr_ready = xr->ready; pb.xr_done = xr->done; pb.xr_base = xr->base;
   }
   if (eval_total > 0) {
     pb.do_eval = 1; pb.n_total = eval_total; pb.eval_every = std::max(eval_total / 5, 1);   // mdnn.py:235
@@ -1268,23 +1272,15 @@ static bool dp_resident_applies(const bsig_fit_plan* p, const bsig_comm* comm, i
   const char* e = getenv("BSIG_DP_RESIDENT");
   const bool want = e ? e[0] == '1' : bsig_comm_world(comm) == 1;
   const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
-  return want && bsig_comm_transport(comm) == 1 && p->persistent && n_updates >= 1 && n_updates == p->n_updates &&
-         !p->adam_pending && p->buf.x_kind == BSIG_X_ROWS && persist_variant(persist_shape(p)) == 2 &&
-         p->buf.n_test >= 1 && persist_eval_supported(persist_shape(p)) && !(no_ike && no_ike[0] == '1');
+  if (!(want && bsig_comm_transport(comm) == 1 && n_updates >= 1 && n_updates == p->n_updates && !p->adam_pending &&
+        p->buf.n_test >= 1 && !(no_ike && no_ike[0] == '1')))
+    return false;
+  if (p->persistent)
+    return p->buf.x_kind == BSIG_X_ROWS && persist_variant(persist_shape(p)) == 2 && persist_eval_supported(persist_shape(p));
+  // the two-layer MDNN with its first layer resident on the chip (not the streamed kernel)
+  return p->persistent_mdnn && !p->mdnn_streams && persist_mdnn_eval_supported(persist_mdnn_shape(p));
 }
 
-// One call = ONE launch on `st` and, per update, wait(ready) -> all-reduce -> write(done) on the
-// communicator's exchange stream.  What ties the two streams together, as measured on the pool
-// (profiles/r05_NOTES.md, "Resident exchange"):
-//  * the exchange stream waits for an event recorded on `st` just ahead of the launch before it starts
-//    polling the word: a wait-value packet left polling while `st` still runs the block's projection
-//    GEMMs (10 ms) answered so late afterwards that the first call of a fit timed out;
-//  * `st` does NOT wait for the exchange stream at the end of the call -- it does not have to (the
-//    last write of the call is what lets the kernel finish, so whatever follows the launch in `st`
-//    follows the exchange), and with that wait in place a second call enqueued behind a running one
-//    timed out every time;
-//  * the two words only grow (xr.base), nothing resets them between calls;
-//  * the host keeps the exchange stream at most one call ahead (below).
 static int run_dp_resident(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates, hipStream_t st) {
   const auto t0_host = std::chrono::steady_clock::now();
   CommXr xr;
@@ -1298,7 +1294,8 @@ static int run_dp_resident(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates,
   const int slot = (int)(xr.calls % CommXr::kRing);
   BSIG_HIP(hipEventRecord(xr.ev_begin[slot], st));
   BSIG_HIP(hipStreamWaitEvent(xr.stream, xr.ev_begin[slot], 0));
-  BSIG_TRY(enqueue_persistent(p, (int)n_updates, st, (int)n_updates, &xr));
+  if (p->persistent) BSIG_TRY(enqueue_persistent(p, (int)n_updates, st, (int)n_updates, &xr));
+  else BSIG_TRY(enqueue_persistent_mdnn(p, (int)n_updates, st, (int)n_updates, &xr));
   if (depth > 0 && xr.calls >= depth)
     BSIG_HIP(hipEventSynchronize(xr.ev_end[(int)((xr.calls - depth) % CommXr::kRing)]));
   // (diagnostics, 1-rank groups only: BSIG_DP_XR_NO_COLLECTIVE=1 leaves the -- identity -- all-reduce

@@ -213,7 +213,8 @@ static size_t mdnn_data_bytes(const MdnnGeom& g) {
   return round_up<size_t>((g.slab_floats + 4 * g.act_floats + g.dout_floats + 2 * kPackFloats +
                            g.eval_floats + mdnn_wide_floats(g) + (g.stream ? g.act_floats : 0)) * sizeof(float), 256);
 }
-static size_t mdnn_sync_bytes() { return 14 * kFlagArr * sizeof(unsigned) + 6 * kGranArr * 8; }
+// flags, granules and (last 256 bytes) the word the workgroups of a resident rank count themselves in
+static size_t mdnn_sync_bytes() { return 14 * kFlagArr * sizeof(unsigned) + 6 * kGranArr * 8 + 256; }
 
 size_t persist_mdnn_workspace_bytes(const PersistMdnnShape& s) {
   MdnnGeom g;
@@ -254,7 +255,9 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   BSIG_REQUIRE(b.w2_off % 2 == 0 && b.wh_off % 2 == 0 && aligned(b.params, 16),
                "persistent MDNN updates: weight blocks must be 8-byte aligned");
   BSIG_REQUIRE(!(b.adam_pending && !b.grads), "persistent MDNN updates: pending Adam step without gradients");
-  BSIG_REQUIRE(!(b.grads && n > 1), "persistent MDNN updates: data-parallel launches take one update");
+  BSIG_REQUIRE(!(b.grads && n > 1 && !b.xr_ready), "persistent MDNN updates: data-parallel launches take one update");
+  BSIG_REQUIRE(!(b.xr_ready && !(b.grads && b.xr_done && !b.adam_pending && !g.stream && b.do_eval && b.n_total == n && n >= 1)),
+               "persistent MDNN updates: a resident data-parallel launch takes the whole call, evaluations inside");
   if (n <= 0 && !b.adam_pending && !b.do_eval) return BSIG_OK;
   int s_nip = 0, s_pf = 0;
   size_t s_lds = 0;
@@ -292,6 +295,7 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.k_slices = g.k_slices; p.G1 = g.G1; p.n_owner = g.n_owner; p.n_small = g.n_small;
   p.n_updates = std::max(n, 0); p.x_floats = g.x_floats;
   p.grads = b.grads; p.adam_pending = b.adam_pending;
+  p.xr_ready = b.xr_ready; p.xr_done = b.xr_done; p.xr_base = b.xr_base;
   p.x = b.x; p.ldx = b.ldx; p.ids = b.ids; p.y = b.y; p.ldy = b.ldy;
   p.x_fac = fac ? 1 : 0; p.xS = b.x_s; p.xA = b.x_a;
   p.params = b.params; p.m1 = b.exp_avg; p.m2 = b.exp_avg_sq;
@@ -342,6 +346,7 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
   p.flag_h2e = p.flag_evr + kFlagArr;
   p.flag_oe = p.flag_h2e + kFlagArr;
   p.gran = reinterpret_cast<unsigned long long*>(sync + 14 * kFlagArr * sizeof(unsigned));
+  p.xr_count = reinterpret_cast<unsigned*>(sync + mdnn_sync_bytes() - 256);
   p.gran_eval = p.gran + 3 * kGranArr;
   if (b.do_eval) {
     BSIG_REQUIRE(g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
@@ -374,7 +379,7 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
     else if (g.mr == 2) BSIG_MDNN_LAUNCH(DP_, FAC_, false, false, 2);        \
     else BSIG_MDNN_LAUNCH(DP_, FAC_, false, false, kMR);                     \
   } while (0)
-  const bool dp = b.grads != nullptr, full = s.full_cov != 0;
+  const bool dp = b.grads != nullptr && !b.xr_ready, full = s.full_cov != 0;      // (resident: the single-rank instantiations)
   if (g.stream) return mdnn_stream_launch(p, dp, g.wide != 0, full, (int)grid.x, std::max(g.lds, s_lds), st);
   if (dp && fac) BSIG_MDNN_LAUNCH_WF(true, true);
   else if (dp) BSIG_MDNN_LAUNCH_WF(true, false);

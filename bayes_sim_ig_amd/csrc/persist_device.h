@@ -97,6 +97,26 @@ __device__ __forceinline__ f32x4 xwg_load4(__amdgpu_buffer_rsrc_t r, int float_o
   return f;
 }
 
+// A data-parallel rank RESIDENT across the gradient exchange (persist.h: PersistBuffers::xr_*), the
+// hand-off of one update by one workgroup whose gradients are out and acknowledged (s_waitcnt(0) +
+// barrier before the call): thread 0 counts the workgroup in, the last of the n_wg raises *ready to
+// base + done_upd with ONE system-scope store, and waits (bounded) until the exchange stream has
+// written the same number behind its all-reduce.  The caller follows with a workgroup barrier.
+__device__ __forceinline__ void xr_hand_off(unsigned* count, unsigned* ready, const unsigned* done, unsigned base,
+                                            unsigned done_upd, unsigned n_wg, int32_t* flagp) {
+  const unsigned target = base + done_upd;
+  const unsigned old = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old + 1u == done_upd * n_wg)
+    __hip_atomic_store(ready, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  int spins = 0;
+  while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
+    if (++spins > (1 << 23)) { atomicOr(flagp, 2); break; }
+    // (a run that gave up elsewhere: the workgroup that would release the exchange stream may be this one)
+    if ((spins & 1023) == 0 && (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2)) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 // 4 x 4 transpose across the four lanes of a quad (lanes 4q .. 4q+3, a = lane & 3): lane a comes in with
 // column a of a 4 x 4 block, c[r] = M[r][a], and leaves with row a, M[a][0..3].  A 32x32 accumulator lane
 // holds four consecutive ROWS of one column; a cross-workgroup payload is stored 16 bytes per lane along a

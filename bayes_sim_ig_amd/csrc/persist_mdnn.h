@@ -28,6 +28,9 @@ struct PersistMdnnBuffers {
   // launch first takes the Adam step of the previous update from the (reduced) `grads`.
   // n = 0 with adam_pending: that step only.
   float* grads = nullptr; int adam_pending = 0;
+  // ... or RESIDENT across the exchange, as persist.h: PersistBuffers::xr_* (plans whose first layer is
+  // resident on the chip and whose evaluations run inside the launch; ONE launch for the whole call)
+  unsigned* xr_ready = nullptr; const unsigned* xr_done = nullptr; unsigned xr_base = 0;
   // held-out evaluations inside the launch (persist_mdnn_eval_supported): after update `it`
   // of the call with it % eval_every == 0 and after the last of its n_total updates
   // (mdnn.py:235-242); evaluation k writes test_loss[state[1]] and advances state[1]

@@ -71,6 +71,11 @@ struct MdnnArgs {
   // and the Adam step of the PREVIOUS update (on the reduced gradients) is taken by the
   // weights' owners while they load them (adam_pending)
   float* grads; int adam_pending;
+  // ... or RESIDENT across the exchange (DP = false instantiations, xr_ready != null; persist.h): the
+  // G1 tile and the n_small small-weight workgroups write their gradients through to `grads`, count
+  // themselves in xr_count (a word of the sync region), the last one raises *xr_ready, all poll
+  // *xr_done and take their Adam step from the reduced `grads`
+  unsigned* xr_ready; const unsigned* xr_done; unsigned* xr_count; unsigned xr_base;
   int pair_ok;                       // rows of W1 are 8-byte aligned pairs (w1_off, I even)
   // held-out evaluations inside the launch (mdnn.py:235-242; do_eval), as in
   // fit_persistent.hip: the tile workgroups form the held-out rows' first-layer products
@@ -292,6 +297,7 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
   const int kcol = 32 * w + l31;
   const bool col_ok = k0 + kcol < p.I;
   const bool pend = DP && p.adam_pending != 0;
+  const bool xr = !DP && p.xr_ready != nullptr;      // resident across the gradient exchange (MdnnArgs)
   // first launch of a run_training call: a fresh optimizer (mdnn.py:203) -- the moments start
   // at zero in the registers, nobody has to clear (or read) them in memory
   const bool fresh = !DP && step0 == 0;
@@ -550,6 +556,13 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
           for (int i = 0; i < 16; ++i)
             p.grads[p.w1_off + (int64_t)(n0 + acc_row(i, h_l)) * p.I + k0 + kcol_l] = acc[i];
         }
+      } else if (xr) {
+        // resident across the exchange: written through (the exchange stream's all-reduce reads memory)
+        if (k0 + kcol_l < p.I) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            xwg_store(p.grads + p.w1_off + (int64_t)(n0 + acc_row(i, h_l)) * p.I + k0 + kcol_l, acc[i]);
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -560,13 +573,48 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     }
     // this wavefront's 32 columns of the NEXT minibatch tile (requested in the wait window above)
     if (t + 1 < p.n_updates) { BSIG_MPF_LIST(BSIG_MPF_STORE) }
-    bias_pending = ks == 0 && !DP;
+    bias_pending = ks == 0 && !DP && !xr;
     __syncthreads();
     if (DP && ks == 0 && tid_l < kMNB) {
       float g = 0.f;
 #pragma unroll
       for (int q = 0; q < kMT / 32; ++q) g += bpart[q * 32 + tid_l];
       p.grads[p.b1_off + n0 + tid_l] = g;
+    }
+    if (!DP && xr) {
+      if (ks == 0 && tid_l < kMNB) {
+        float g = 0.f;
+#pragma unroll
+        for (int q = 0; q < kMT / 32; ++q) g += bpart[q * 32 + tid_l];
+        xwg_store(p.grads + p.b1_off + n0 + tid_l, g);
+      }
+      // ---- the exchange: gradients out (acknowledged), count, signal, wait, reduced gradients in ----
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      BSIG_MSTAMP(13);
+      if (tid_l == 0)
+        xr_hand_off(p.xr_count, p.xr_ready, p.xr_done, p.xr_base, (unsigned)t + 1u, (unsigned)(p.G1 + p.n_small), flagp);
+      __syncthreads();
+      BSIG_MSTAMP(14);
+      if (k0 + kcol_l < p.I) {
+        float gq[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          gq[i] = xwg_load(p.grads + p.w1_off + (int64_t)(n0 + acc_row(i, h_l)) * p.I + k0 + kcol_l);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float* wp = Wl + acc_row(i, h_l) * kMPitch + kcol_l;
+          *wp = adam_weight(gq[i], Mr[i], Vr[i], *wp, a0, a1, ak);
+        }
+      }
+      if (ks == 0 && tid_l < kMNB) {
+        const float g = xwg_load(p.grads + p.b1_off + n0 + tid_l);
+        float bm = biasl[32 + tid_l], bv = biasl[64 + tid_l];
+        biasl[tid_l] = adam_bias(g, bm, bv, biasl[tid_l], a0, a1, ak);
+        biasl[32 + tid_l] = bm;
+        biasl[64 + tid_l] = bv;
+      }
+      __syncthreads();
     }
     BSIG_MSTAMP(12);
   }
@@ -594,6 +642,10 @@ __device__ __forceinline__ void mdnn_tile_workgroup(const MdnnArgs& p, float* sm
     p.m1[p.b1_off + n0 + tid] = biasl[32 + tid];
     p.m2[p.b1_off + n0 + tid] = biasl[64 + tid];
   }
+  // a resident launch that gave up must not leave the exchange stream waiting for gradients that will
+  // never come: every wait of the call passes
+  if (xr && wg == 0 && tid == 0 && (__hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2))
+    __hip_atomic_store(p.xr_ready, p.xr_base + (unsigned)p.n_updates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (wg == 0 && tid == 0 && p.n_updates > 0) {
     int32_t* st = p.state;
     reinterpret_cast<double*>(st + 12)[0] = b1t;
@@ -717,6 +769,7 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
   const AdamK ak{1.0f - (float)p.beta1, (float)p.beta2, 1.0f - (float)p.beta2, p.adam_eps};
 
   const bool pend = DP && p.adam_pending != 0;
+  const bool xr = !DP && p.xr_ready != nullptr;      // resident across the gradient exchange (MdnnArgs)
   const bool fresh = !DP && step0 == 0;      // fresh optimizer: the moments start at zero
   const float pa0 = pend ? reinterpret_cast<const float*>(p.state)[4] : 0.f;
   const float pa1 = pend ? reinterpret_cast<const float*>(p.state)[5] : 0.f;
@@ -970,6 +1023,8 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
         const int n = n0 + acc_row(i, h_l);
         if (DP) {
           if (n < nrows) p.grads[w_off + (int64_t)n * kMH + kcol_l] = acc[i];
+        } else if (xr) {
+          if (n < nrows) xwg_store(p.grads + w_off + (int64_t)n * kMH + kcol_l, acc[i]);
         } else {
           Wr[i] = adam_weight(acc[i], Mr[i], Vr[i], Wr[i], a0, a1, ak);
           if (n < nrows) xwg_store(p.params + w_off + (int64_t)n * kMH + kcol_l, Wr[i]);
@@ -981,8 +1036,38 @@ __device__ __forceinline__ void mdnn_small_workgroup(const MdnnArgs& p, float* s
       for (int b = 0; b < B; ++b) g += X[lane * DOP + b];
       if (DP) {
         p.grads[b_off + n0 + lane] = g;
+      } else if (xr) {
+        xwg_store(p.grads + b_off + n0 + lane, g);
       } else {
         bw = adam_bias(g, bm, bv, bw, a0, a1, ak);
+        xwg_store(p.params + b_off + n0 + lane, bw);
+      }
+    }
+    if (!DP && xr) {
+      // ---- the exchange (see the tile workgroups), then the Adam step on the reduced gradients ----
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid == 0)
+        xr_hand_off(p.xr_count, p.xr_ready, p.xr_done, p.xr_base, (unsigned)t + 1u, (unsigned)(p.G1 + p.n_small), flagp);
+      __syncthreads();
+      if (w < 4) {
+        int h_l = h, kcol_l = kcol;
+        asm volatile("" : "+v"(h_l), "+v"(kcol_l));
+        float gq[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + acc_row(i, h_l);
+          gq[i] = n < nrows ? xwg_load(p.grads + w_off + (int64_t)n * kMH + kcol_l) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + acc_row(i, h_l);
+          Wr[i] = adam_weight(gq[i], Mr[i], Vr[i], Wr[i], a0, a1, ak);
+          if (n < nrows) xwg_store(p.params + w_off + (int64_t)n * kMH + kcol_l, Wr[i]);
+          if (is_w2) publish_w2(i, h_l, kcol_l, step + 1);
+        }
+      } else if (bias_lane) {
+        bw = adam_bias(xwg_load(p.grads + b_off + n0 + lane), bm, bv, bw, a0, a1, ak);
         xwg_store(p.params + b_off + n0 + lane, bw);
       }
     }

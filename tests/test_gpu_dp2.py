@@ -110,9 +110,10 @@ def test_two_rank_fit_with_rank_local_jitter_scale(tmp_path):
         np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-6)
 
 
-def test_rank_resident_across_the_exchange_is_bitwise_the_per_update_launches(monkeypatch):
+@pytest.mark.parametrize('config', ['cfg5', 'cfg3', 'cfg2'])
+def test_rank_resident_across_the_exchange_is_bitwise_the_per_update_launches(monkeypatch, config):
     """BSIG_DP_RESIDENT: ONE launch per run_training call, the gradients handed to the exchange
-    stream's all-reduce and back per update (fit_persistent.hip, XR), against a launch + all-reduce
+    stream's all-reduce and back per update (fit_persistent.hip XR, fit_persistent_mdnn.hip), against a launch + all-reduce
     per update -- on a 1-rank RCCL group (all this pool can run): the same kernels' arithmetic in the
     same order, so parameters and logs must be bit-identical; and the resident launches must really
     have run (not timed out into the per-phase fallback, which would agree as well)."""
@@ -125,7 +126,7 @@ def test_rank_resident_across_the_exchange_is_bitwise_the_per_update_launches(mo
     if created:
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
     try:
-        cfg = dict(bench.CONFIGS['cfg5'])
+        cfg = dict(bench.CONFIGS[config])      # (cfg3: the MDNN kernel, fit_persistent_mdnn.hip, on factor rows)
         theta, states, actions = bench.synth_pairs(cfg, 5000, 21, 'cuda:0')
         out = {}
         for mode in ('0', '1'):
