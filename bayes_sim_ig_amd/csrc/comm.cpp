@@ -187,7 +187,9 @@ int comm_xr(bsig_comm* c, hipStream_t launch_stream, CommXr* out) {
       if (x.probe_us[i] < x.probe_us[best]) best = i;
     }
     x.stream = x.cand[best];
-    x.usable = x.probe_us[best] <= kProbeOkUs;
+    // (tests: BSIG_DP_XR_PROBE_OK_US=0 makes every candidate unusable -- the launch-per-update fallback)
+    const char* ok_us = getenv("BSIG_DP_XR_PROBE_OK_US");
+    x.usable = x.probe_us[best] <= (ok_us ? atof(ok_us) : kProbeOkUs);
     x.probed = true; x.probed_for = launch_stream;
     if (getenv("BSIG_DP_XR_TRACE"))
       fprintf(stderr, "comm_xr: probes %.1f %.1f %.1f %.1f us -> candidate %d (%s)\n", x.probe_us[0], x.probe_us[1],

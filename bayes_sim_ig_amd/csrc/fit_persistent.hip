@@ -964,18 +964,8 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         BSIG_USTAMP(13);
-        if (tid_l == 0) {
-          const unsigned done_upd = (unsigned)step + 1u;      // updates of this call whose gradients are out
-          const unsigned old = __hip_atomic_fetch_add(p.xr_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned target = p.xr_base + done_upd;
-          if (old + 1u == done_upd * (unsigned)p.G)           // the last tile workgroup: ONE system-scope store
-            __hip_atomic_store(p.xr_ready, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          int spins = 0;
-          while ((int)(__hip_atomic_load(p.xr_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target) < 0) {
-            if (++spins > (1 << 23)) { atomicOr(flagp, 2); break; }      // (bounded like every poll of the kernel)
-            __builtin_amdgcn_s_sleep(8);
-          }
-        }
+        if (tid_l == 0)      // (updates of THIS call whose gradients are out: the launch is the whole call)
+          xr_hand_off(p.xr_count, p.xr_ready, p.xr_done, p.xr_base, (unsigned)t + 1u, (unsigned)p.G, flagp);
         // (a run that gave up finishes this update on whatever the buffer holds and leaves at the top of
         // the next one, the call fails with the sticky time-out error; a `break` HERE keeps every
         // loop-carried register alive on one more path: 300 bytes of scratch per lane, 58 us per update)

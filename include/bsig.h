@@ -415,7 +415,11 @@ void bsig_comm_destroy(bsig_comm* comm);
  * bsig_fit_flush at the end -- all enqueued from here, no host work in between.
  * `reduced_logs` (device, n_updates + n_evals + 3 floats, may be NULL) receives,
  * summed over the ranks: train_loss[n_updates] | test_loss[e] * n_test |
- * n_test | #ranks with the non-finite flag | #ranks with a poll time-out. */
+ * n_test | #ranks with the non-finite flag | #ranks with a poll time-out.
+ * A rank whose plan runs in a chip-resident persistent kernel with its evaluations inside the
+ * launch can make ONE launch for the whole call instead and stay resident across the exchange:
+ * the all-reduces then run on a stream of the communicator's own (RCCL transport; BSIG_DP_RESIDENT,
+ * default: 1-rank groups only -- INTEGRATION.md; same results bit for bit). */
 int bsig_fit_run_dp(bsig_fit_plan* plan, bsig_comm* comm, int64_t n_updates,
                     float* reduced_logs, bsig_stream_t stream);
 /* With BSIG_DP_GRAPH=1, bsig_fit_run_dp captures a steady-state update of a rank whose updates run

@@ -149,3 +149,39 @@ def test_rank_resident_across_the_exchange_is_bitwise_the_per_update_launches(mo
     assert torch.equal(out['0'][1], out['1'][1])
     for a, b in zip(out['0'][0], out['1'][0]):
         assert a == b
+
+
+def test_resident_rank_without_a_usable_exchange_stream_runs_one_launch_per_update(monkeypatch):
+    """No candidate stream answers the probe in time (forced: BSIG_DP_XR_PROBE_OK_US=0): the call must run
+    one launch + all-reduce per update -- no resident call, no time-out, the same bits."""
+    import warnings
+    import bench
+    import bayes_sim_ig_amd as pkg
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29582')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    try:
+        cfg = dict(bench.CONFIGS['cfg5'])
+        theta, states, actions = bench.synth_pairs(cfg, 2000, 22, 'cuda:0')
+        out = {}
+        for mode, ok_us in (('0', None), ('1', '0')):
+            monkeypatch.setenv('BSIG_DP_RESIDENT', mode)
+            if ok_us is None:
+                monkeypatch.delenv('BSIG_DP_XR_PROBE_OK_US', raising=False)
+            else:
+                monkeypatch.setenv('BSIG_DP_XR_PROBE_OK_US', ok_us)
+            bs = bench.build_gpu_model(pkg, cfg, 'cuda:0', 33)
+            bs.model.enable_data_parallel()
+            np.random.seed(34)
+            with warnings.catch_warnings():
+                warnings.simplefilter('error', RuntimeWarning)
+                logs = bs.fit(theta, states, actions)
+            torch.cuda.synchronize()
+            out[mode] = (logs, bs.model._flat.clone(), bs.model._dp.resident_calls())
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert out['1'][2] == 0
+    assert torch.equal(out['0'][1], out['1'][1]) and out['0'][0] == out['1'][0]
