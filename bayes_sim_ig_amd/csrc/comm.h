@@ -1,6 +1,7 @@
 // Internal: what a data-parallel rank that stays RESIDENT across the gradient exchange needs from its
-// communicator (comm.cpp owns it): a second stream for the exchange and the three words of the
-// hand-off (persist.h: PersistBuffers::xr_*).
+// communicator (comm.cpp owns it): a second stream for the exchange, chosen by a probe, and the two
+// words of the hand-off (persist.h: PersistBuffers::xr_*; the word the workgroups count themselves in
+// belongs to the plan's workspace).
 #pragma once
 #include "common.h"
 

@@ -1257,13 +1257,14 @@ extern "C" int bsig_fit_dp_graph_status(const bsig_fit_plan* p, char* msg, size_
   return p->g_dp_state;
 }
 
-// A data-parallel rank covered by the persistent kernel of the linear heads can stay RESIDENT across
-// the gradient exchange: ONE launch for the call (weights in LDS, moments in registers, held-out
-// evaluations inside, as a single rank), and a second stream that per update waits for the kernel's
-// "gradients are out" word, runs the all-reduce and writes the word the kernel polls
-// (fit_persistent.hip, XR).  No launch boundary and no W / m / v / g round trip through HBM per update.
+// A data-parallel rank covered by a chip-resident persistent kernel (the linear heads, or the two-layer
+// MDNN whose first layer fits the chip) can stay RESIDENT across the gradient exchange: ONE launch for
+// the call (weights in LDS, moments in registers, held-out evaluations inside, as a single rank), and
+// a second stream that per update waits for the kernel's "gradients are out" word, runs the
+// all-reduce and writes the word the kernel polls (fit_persistent.hip: XR; persist_mdnn_device.h:
+// xr).  No launch boundary and no W / m / v / g round trip through HBM per update.
 // Policy: BSIG_DP_RESIDENT=1 / 0 forces / forbids; unset: ON for a 1-rank group (all this pool can run:
-// 29.5 us per update against 34.8 with a launch per update), OFF with peers -- RCCL's kernels would have
+// cfg5 29.5 us per update against 34.8 with a launch per update, cfg3 39 against 47), OFF with peers -- RCCL's kernels would have
 // to live on the 8 CUs the launch leaves free (comm.cpp caps its channels for that case), which no one
 // has run yet.  The exchange stream is chosen by a probe (comm.h); when none is served promptly the
 // call falls back to a launch per update, and a launch whose polls time out anyway makes the fit

@@ -27,12 +27,12 @@ struct PersistBuffers {
   // `adam_pending` the launch first takes the Adam step of the previous update
   // from the (reduced) `grads`.  n = 0 with adam_pending: that step only.
   float* grads = nullptr; int adam_pending = 0;
-  // ... or RESIDENT across the exchange (fit_persistent.hip only): ONE launch for the whole call; after
-  // update u (1-based) the kernel writes its gradients through to `grads`, raises *xr_ready to xr_base + u
-  // (signal memory a stream can wait on) and polls *xr_done until the caller's exchange stream has written
-  // the same number behind its all-reduce.  The two words only ever grow (xr_base: the updates of earlier
-  // calls): nothing resets them between calls -- a hipMemsetAsync of the signal word did not stay behind
-  // the kernel of the previous call in the stream (two calls in flight: every poll timed out).
+  // ... or RESIDENT across the exchange (fit_persistent.hip; persist_mdnn.h has the same three fields): ONE
+  // launch for the whole call; after update u (1-based) the kernel writes its gradients through to `grads`,
+  // raises *xr_ready to xr_base + u (a word a stream can wait on) and polls *xr_done until the caller's
+  // exchange stream has written the same number behind its all-reduce.  The two words only ever grow
+  // (xr_base: the updates of earlier calls): nothing has to reset them between calls, so no stream
+  // operation of one call has to be ordered against the exchange of another.
   unsigned* xr_ready = nullptr; const unsigned* xr_done = nullptr; unsigned xr_base = 0;
   // held-out evaluations inside the launch (persist_eval_supported): after update `it` of the
   // call with it % eval_every == 0 and after the last of its n_total updates (mdnn.py:235-242);

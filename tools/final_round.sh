@@ -10,7 +10,6 @@ OUT=$R/gpurun_out
 CSRC=$(python3 "$R/tools/csrc_hash.py")
 mkdir -p "$OUT"
 cd "$R"
-python3 bench.py > "$OUT/${TAG}_bench_line.json" 2> "$OUT/${TAG}_bench_stderr.log"
 python3 tools/yaml_configs_bench.py > "$OUT/${TAG}_yaml_configs.txt" 2>&1
 for c in anymal_yaml shadow_more; do
   n=${c%_yaml}
@@ -30,14 +29,22 @@ DPQ="--steps 3 --warmup 1 --no-per-config --no-largest-size --no-cpu-baseline --
   grep "time-out bits" "$OUT/${TAG}_dp_resident_stderr.log" | tail -1 | sed "s/.*time-out bits so far://" | tr ' ' '\n' | grep -v "^$" | sort | uniq -c | sed "s/^/  time-out bit of the resident calls (count value): /"
   echo "BSIG_DP_RESIDENT=0 BENCH_FORCE_DP=1 python bench.py $DPQ  (one launch + all-reduce per update)"
   BSIG_DP_RESIDENT=0 BENCH_FORCE_DP=1 python3 bench.py $DPQ 2>/dev/null
-  echo "BENCH_FORCE_DP=1 python bench.py --config cfg3 --pairs 20000 $DPQ  (MDNN kernel: one launch per update)"
+  echo "BENCH_FORCE_DP=1 python bench.py --config cfg3 --pairs 20000 $DPQ  (MDNN kernel, resident across the exchange)"
   BENCH_FORCE_DP=1 python3 bench.py --config cfg3 --pairs 20000 $DPQ 2>/dev/null
+  echo "BSIG_DP_RESIDENT=0 BENCH_FORCE_DP=1 python bench.py --config cfg3 --pairs 20000 $DPQ  (MDNN kernel: one launch + all-reduce per update)"
+  BSIG_DP_RESIDENT=0 BENCH_FORCE_DP=1 python3 bench.py --config cfg3 --pairs 20000 $DPQ 2>/dev/null
 } > "$OUT/${TAG}_dp_1rank.txt"
 rm -f "$OUT/${TAG}_dp_resident_stderr.log"
 BSIG_PROF_T0=50 python3 tools/persist_xr_prof.py 2>/dev/null | grep -v "^stamped\|^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > "$OUT/${TAG}_cfg5_dp_resident_timeline.txt"
+python3 tools/persist_xr_prof.py cfg3 2>/dev/null | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > "$OUT/${TAG}_cfg3_dp_resident_timeline.txt"
 python3 tools/persist_prof.py cfg2 2>&1 | grep -v "amdgpu.ids" > "$OUT/${TAG}_cfg2_update_timeline.txt"
 for f in bench_line.json yaml_configs.txt anymal_update_timeline.txt shadow_more_update_timeline.txt cfg3_update_timeline.txt \
-         cfg5_update_timeline.txt cfg5_update_timeline_warm.txt cfg2_update_timeline.txt dp_1rank.txt cfg5_dp_resident_timeline.txt summarizer_bench.txt fill_bench.txt gemm_heldout_sweep.txt; do
+         cfg5_update_timeline.txt cfg5_update_timeline_warm.txt cfg2_update_timeline.txt dp_1rank.txt cfg5_dp_resident_timeline.txt cfg3_dp_resident_timeline.txt summarizer_bench.txt fill_bench.txt gemm_heldout_sweep.txt; do
   [ -f "$OUT/${TAG}_$f" ] && [ "${f##*.}" = txt ] && sed -i "1i # head: $HEADSHA\n# csrc: $CSRC" "$OUT/${TAG}_$f"
 done
 bash tools/round_profiles.sh "$TAG" "$HEADSHA"
+# the bench line LAST, with this pass's counters of the dominant kernel in profiles/ (bench.pmc_traffic
+# takes them from there and refuses counters of other kernel sources)
+cp "$OUT/${TAG}_cfg5_pmc_FETCH_SIZE.txt" "$OUT/${TAG}_cfg5_pmc_WRITE_SIZE.txt" "$R/profiles/"
+cd "$R"
+python3 bench.py > "$OUT/${TAG}_bench_line.json" 2> "$OUT/${TAG}_bench_stderr.log"

@@ -22,7 +22,9 @@ lib.bsig_debug_persist_profile.restype = None
 lib.bsig_debug_persist_profile.argtypes = [C.c_void_p]
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29534')
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(dev))
-cfg = dict(bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else 'cfg5'])
+if len(sys.argv) < 2:
+    sys.argv.append('cfg5')
+cfg = dict(bench.CONFIGS[sys.argv[1]])
 theta, states, actions = bench.synth_pairs(cfg, 2000, 3, dev)
 bs = bench.build_gpu_model(B, cfg, dev, 77)
 bs.model.enable_data_parallel()
@@ -33,24 +35,36 @@ logs = bs.fit(theta, states, actions)
 torch.cuda.synchronize()
 lib.bsig_debug_persist_profile(None)
 st = buf.cpu().numpy().reshape(2, 256, 8, 16).astype(np.float64)[0] / 100.0
-tiles = [g for g in range(256) if st[g, 1, 13] > 0]
+tiles = [g for g in range(256) if st[g, 1, 13] > 0 and st[g, 1, 12] > 0 and
+         (cfg['model'] != 'MDNN' or (st[g, 1, 11] > 0 and st[g, 1, 15] == 0))]      # (MDNN: the owners stamp 13 / 14 too)
 if not tiles:
     sys.exit('no stamps of a resident launch: the call ran one launch per update (BSIG_DP_XR_TRACE=1 shows the probes)')
-owners = [g for g in range(256) if st[g, 1, 4] > 0 and g not in tiles]
-print('%d tile workgroups (resident across the exchange), %d row owners; updates %s + 1..7'
-      % (len(tiles), len(owners), os.environ.get('BSIG_PROF_T0', '0')))
+mdnn = cfg['model'] == 'MDNN'
+T0 = os.environ.get('BSIG_PROF_T0', '0')
+if mdnn:
+    # (fit_persistent_mdnn.hip: stamps of the tile workgroups; the small-weight workgroups hand off too)
+    print('%s: %d tile workgroups (resident across the exchange); updates %s + 1..7' % (sys.argv[1], len(tiles), T0))
+    table = (('forward MFMAs', 0, 2), ('slab store + flag', 2, 3), ('wait for the owners', 3, 10),
+             ('dz1^T load', 10, 11), ('dW1 MFMAs + gradients out, acked', 11, 13), ('exchange wait', 13, 14),
+             ('reduced gradients in + Adam', 14, 12))
+    rel = 10
+else:
+    owners = [g for g in range(256) if st[g, 1, 4] > 0 and g not in tiles]
+    print('%d tile workgroups (resident across the exchange), %d row owners; updates %s + 1..7' % (len(tiles), len(owners), T0))
+    table = (('fwd mfma (wave 0)', 0, 1), ('slab store+flag', 1, 3), ('next tile requested', 3, 2),
+             ('wait for owners', 2, 10), ('dO^T load', 10, 11), ('dW mfma + gradients out, acked', 11, 13),
+             ('exchange wait', 13, 14), ('reduced gradients in + Adam', 14, 8), ('end barrier', 8, 12))
+    rel = 10
 for g in tiles[:1] + tiles[-1:]:
     print('tile wg %3d: update = %.1f us' % (g, np.mean(st[g, 2:8, 0] - st[g, 1:7, 0])))
-    for n, a, b in (('fwd mfma (wave 0)', 0, 1), ('slab store+flag', 1, 3), ('next tile requested', 3, 2),
-                    ('wait for owners', 2, 10), ('dO^T load', 10, 11), ('dW mfma + gradients out, acked', 11, 13),
-                    ('exchange wait', 13, 14), ('reduced gradients in + Adam', 14, 8), ('end barrier', 8, 12)):
-        print('    %-32s %6.2f us' % (n, (st[g, 1:8, b] - st[g, 1:8, a]).mean()))
+    for n, a, b in table:
+        print('    %-34s %6.2f us' % (n, (st[g, 1:8, b] - st[g, 1:8, a]).mean()))
 u = slice(2, 7)
 t0 = np.min(st[tiles][:, u, 0], axis=0)
 print('chip-level, mean over updates 2..6 (us after the first tile workgroup starts the update):')
-for label, k, fn in (('last tile wg released by the owners', 10, np.max),
+for label, k, fn in (('last tile wg released by the owners', rel, np.max),
                      ('first tile wg has its gradients out', 13, np.min),
-                     ('last tile wg has its gradients out (-> ready signal)', 13, np.max),
+                     ('last tile wg has its gradients out', 13, np.max),
                      ('first tile wg sees the exchange done', 14, np.min),
                      ('last tile wg sees the exchange done', 14, np.max),
                      ('last tile wg finished the update', 12, np.max)):
