@@ -389,6 +389,7 @@ struct bsig_fit_plan {
   bool persistent_mdnn_cap;    // ... the plan's shape is covered (persistent_mdnn: this binding is)
   bool mdnn_streams;           // ... with a streamed first layer (cross-correlation factor rows only)
   int dp_evals_done;           // data-parallel + in-launch evaluations: bsig_fit_eval calls so far
+  bool resident_ran;           // a resident data-parallel call ran since bsig_fit_begin (its workgroup count word is used up)
   bool adam_pending;           // ... data-parallel: the Adam step on the reduced gradients is
                                // taken by the next launch (or flushed before an evaluation)
   size_t persist_bytes;
@@ -951,6 +952,7 @@ extern "C" int bsig_fit_begin(bsig_fit_plan* p, uint64_t seed, int64_t norm_batc
   if (norm_batch != p->norm_batch) { drop_graphs(p); p->norm_batch = norm_batch; }
   hipStream_t st = as_stream(stream);
   p->adam_pending = false;
+  p->resident_ran = false;
   p->dp_evals_done = 0;
   BeginZero bz{};
   int nz = 0;
@@ -1343,7 +1345,9 @@ extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_upda
   if (p->use_graph) BSIG_TRY(ensure_graphs(p));
   const int64_t every = std::max<int64_t>(n_updates / 5, 1);   // mdnn.py:235
   int64_t n_evals = 0;
-  bool resident = dp_resident_applies(p, comm, n_updates);
+  // (the word the workgroups of a resident launch count themselves in is zeroed by bsig_fit_begin: one
+  // resident call per begin, a further call continues with a launch per update)
+  bool resident = !p->resident_ran && dp_resident_applies(p, comm, n_updates);
   if (resident) {      // ... and an exchange stream that is answered while a kernel runs on `stream` (comm.h)
     CommXr xr;
     BSIG_TRY(comm_xr(comm, as_stream(stream), &xr));
@@ -1358,6 +1362,7 @@ extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_upda
   }
   if (resident) {
     BSIG_TRY(run_dp_resident(p, comm, n_updates, as_stream(stream)));
+    p->resident_ran = true;
     n_evals = count_evals(n_updates);
   }
   const bool was_pending = p->adam_pending;
