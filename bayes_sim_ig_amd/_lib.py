@@ -124,6 +124,8 @@ _PROTOS = {
     'bsig_fit_dp_graph_status': (C.c_int, [vp, C.c_char_p, sz]),
     'bsig_comm_rank': (C.c_int, [vp]),
     'bsig_comm_resident_calls': (i64, [vp]),
+    'bsig_comm_set_resident': (None, [vp, C.c_int]),
+    'bsig_comm_resident_mode': (C.c_int, [vp]),
     'bsig_comm_allreduce': (C.c_int, [vp, vp, i64, vp]),
     'bsig_comm_broadcast': (C.c_int, [vp, vp, i64, C.c_int, vp]),
     'bsig_comm_destroy': (None, [vp]),

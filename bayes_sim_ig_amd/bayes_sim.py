@@ -135,13 +135,17 @@ class BayesSim(object):
             # same TOGETHER: the time-out bit travels in the logs every call sums over the ranks
             # (bsig_fit_run_dp), the rank that timed out keeps enqueueing its all-reduces, so every
             # rank reads the same flag at the same chunk, restores and repeats
+            # A rank that stayed resident across the exchange first goes back to one launch per update
+            # (MDNN._give_up_a_level), the per-phase kernels come second.
             from .mdnn import PersistentTimeout
             snap = self.model._snapshot()
-            try:
-                return self._fit_once(params, traj_states, traj_actions)
-            except PersistentTimeout:
-                self.model._restore(snap)
-                self.model._disable_persistent()
+            for _ in range(2):
+                calls0 = self.model._resident_calls()
+                try:
+                    return self._fit_once(params, traj_states, traj_actions)
+                except PersistentTimeout:
+                    self.model._restore(snap)
+                    self.model._give_up_a_level(calls0)
         return self._fit_once(params, traj_states, traj_actions)
 
     def _fit_once(self, params, traj_states, traj_actions):

@@ -111,6 +111,7 @@ struct bsig_comm {
   int world = 1, rank = 0, device = -1;
   bsig::CommXr xr;                 // resident-exchange resources (comm_xr), created on first use
   bool xr_made = false;
+  int resident_mode = -1;          // bsig_comm_set_resident: -1 policy (BSIG_DP_RESIDENT / default), 0 never, 1 always
 };
 
 namespace bsig {
@@ -311,6 +312,8 @@ extern "C" int bsig_comm_broadcast(bsig_comm* c, float* buf, int64_t n, int root
   return BSIG_OK;
 }
 
+extern "C" void bsig_comm_set_resident(bsig_comm* c, int mode) { if (c) c->resident_mode = mode < 0 ? -1 : (mode ? 1 : 0); }
+extern "C" int bsig_comm_resident_mode(const bsig_comm* c) { return c ? c->resident_mode : -1; }
 extern "C" int64_t bsig_comm_resident_calls(const bsig_comm* c) { return c && c->xr_made ? (int64_t)c->xr.calls : 0; }
 
 extern "C" void bsig_comm_destroy(bsig_comm* c) {

@@ -1273,7 +1273,8 @@ extern "C" int bsig_fit_dp_graph_status(const bsig_fit_plan* p, char* msg, size_
 // repeat on the per-phase kernels (mdnn.py), with a warning.
 static bool dp_resident_applies(const bsig_fit_plan* p, const bsig_comm* comm, int64_t n_updates) {
   const char* e = getenv("BSIG_DP_RESIDENT");
-  const bool want = e ? e[0] == '1' : bsig_comm_world(comm) == 1;
+  const int mode = bsig_comm_resident_mode(comm);      // (bsig_comm_set_resident overrides the policy)
+  const bool want = mode >= 0 ? mode == 1 : (e ? e[0] == '1' : bsig_comm_world(comm) == 1);
   const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
   if (!(want && bsig_comm_transport(comm) == 1 && n_updates >= 1 && n_updates == p->n_updates && !p->adam_pending &&
         p->buf.n_test >= 1 && !(no_ike && no_ike[0] == '1')))
@@ -1305,7 +1306,11 @@ static int run_dp_resident(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates,
   // out, which isolates the hand-off from the collective's kernels on the 8 free CUs)
   const char* nc = getenv("BSIG_DP_XR_NO_COLLECTIVE");
   const bool skip = nc && nc[0] == '1' && bsig_comm_world(comm) == 1;
-  for (int64_t u = 1; u <= n_updates; ++u) {
+  // (tests: BSIG_DP_XR_DROP_CALL=k leaves the k-th resident call of the communicator, 0-based, without
+  // its exchange -- the launch's bounded polls give up, as when the exchange stream is not served)
+  const char* drop = getenv("BSIG_DP_XR_DROP_CALL");
+  const bool dropped = drop && atoll(drop) == xr.calls;
+  for (int64_t u = 1; u <= (dropped ? 0 : n_updates); ++u) {
     BSIG_HIP(hipStreamWaitValue32(xr.stream, xr.ready, xr.base + (uint32_t)u, hipStreamWaitValueGte, 0xFFFFFFFFu));
     if (!skip)
       BSIG_TRY(bsig_comm_allreduce(comm, p->buf.grads, p->L.total, reinterpret_cast<bsig_stream_t>(xr.stream)));

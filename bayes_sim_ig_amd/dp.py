@@ -111,6 +111,12 @@ class DataParallel:
         launch per call, the all-reduces on a second stream (BSIG_DP_RESIDENT)."""
         return int(_lib.load().bsig_comm_resident_calls(self.comm)) if self.comm is not None else 0
 
+    def set_resident(self, mode):
+        """Over the BSIG_DP_RESIDENT policy, for this communicator: False never, True always where
+        covered, None back to the policy."""
+        if self.comm is not None:
+            _lib.load().bsig_comm_set_resident(self.comm, -1 if mode is None else int(bool(mode)))
+
     def close(self):
         if self.comm is not None:
             _lib.load().bsig_comm_destroy(self.comm)

@@ -268,6 +268,23 @@ class MDNN(nn.Module):
         self._flat.copy_(snap[0]); self._exp_avg.copy_(snap[1]); self._exp_avg_sq.copy_(snap[2])
         np.random.set_state(snap[3]); torch.set_rng_state(snap[4])
 
+    def _resident_calls(self):
+        return self._dp.resident_calls() if self._dp is not None else 0
+
+    def _give_up_a_level(self, resident_calls_before):
+        """After a persistent launch timed out.  A data-parallel rank that stayed resident across the
+        gradient exchange in the calls since ``resident_calls_before`` first goes back to one launch per
+        update (the exchange stream was not served in time: the launch itself had the chip); a time-out
+        after that, or without the resident exchange: the per-phase kernels."""
+        if self._dp is not None and self._dp.resident_calls() > resident_calls_before:
+            import warnings
+            warnings.warn('bayes_sim_ig_amd: a data-parallel launch that stays resident across the gradient '
+                          'exchange timed out waiting for the exchange; this model continues with one launch '
+                          'per update', RuntimeWarning, stacklevel=3)
+            self._dp.set_resident(False)
+            return
+        self._disable_persistent()
+
     def _disable_persistent(self):
         """From now on this model's plans use the per-phase kernels."""
         import warnings
@@ -451,18 +468,18 @@ class MDNN(nn.Module):
             return self._run_training_once(x_data, y_data, n_updates, batch_size, test_frac,
                                            ids_table, _defer, _feats)
         snap = self._snapshot() if self._may_time_out() else None
-        try:
-            return self._run_training_once(x_data, y_data, n_updates, batch_size, test_frac,
-                                           ids_table, False, _feats)
-        except PersistentTimeout:
-            # (a data-parallel rank: the flag is the SUM over the ranks of the call's logs -- every
-            # rank of the group arrives here in the same call and repeats it with its peers)
-            if snap is None:
-                raise
-            self._restore(snap)
-            self._disable_persistent()
-            return self._run_training_once(x_data, y_data, n_updates, batch_size, test_frac,
-                                           ids_table, False, _feats)
+        for attempt in range(3):
+            calls0 = self._resident_calls()
+            try:
+                return self._run_training_once(x_data, y_data, n_updates, batch_size, test_frac,
+                                               ids_table, False, _feats)
+            except PersistentTimeout:
+                # (a data-parallel rank: the flag is the SUM over the ranks of the call's logs -- every
+                # rank of the group arrives here in the same call and repeats it with its peers)
+                if snap is None or attempt == 2:
+                    raise
+                self._restore(snap)
+                self._give_up_a_level(calls0)
 
     def _may_time_out(self):
         """Could the next call run a persistent kernel?  (Unknown before the first plan exists.)"""

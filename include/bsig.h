@@ -401,6 +401,11 @@ int bsig_comm_rank(const bsig_comm* comm);
 /* (diagnostics) bsig_fit_run_dp calls this communicator ran with the rank RESIDENT across the exchange
  * (one launch per call, the all-reduces on a second stream: INTEGRATION.md, BSIG_DP_RESIDENT) */
 int64_t bsig_comm_resident_calls(const bsig_comm* comm);
+/* Per communicator, over the BSIG_DP_RESIDENT policy: 0 never resident (what the Python mirror sets
+ * after a resident launch timed out: one launch per update from then on), 1 always where covered,
+ * -1 back to the policy. */
+void bsig_comm_set_resident(bsig_comm* comm, int mode);
+int bsig_comm_resident_mode(const bsig_comm* comm);
 /* buf[n] (device, fp32) <- sum over ranks, in place, asynchronous on `stream`. */
 int bsig_comm_allreduce(bsig_comm* comm, float* buf, int64_t n, bsig_stream_t stream);
 /* buf[n] <- rank `root`'s buf (replica initialisation). */

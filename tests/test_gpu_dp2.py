@@ -185,3 +185,39 @@ def test_resident_rank_without_a_usable_exchange_stream_runs_one_launch_per_upda
             dist.destroy_process_group()
     assert out['1'][2] == 0
     assert torch.equal(out['0'][1], out['1'][1]) and out['0'][0] == out['1'][0]
+
+
+def test_resident_launch_that_times_out_falls_back_to_one_launch_per_update(monkeypatch):
+    """The exchange of one resident call never answers (forced: BSIG_DP_XR_DROP_CALL): the launch's bounded
+    polls give up, the fit restores its snapshot, this model's rank stops staying resident (NOT: stops
+    using the persistent kernel) and the repeated fit is bit for bit the launch-per-update fit."""
+    import bench
+    import bayes_sim_ig_amd as pkg
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29584')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    try:
+        cfg = dict(bench.CONFIGS['cfg5'])
+        theta, states, actions = bench.synth_pairs(cfg, 3000, 23, 'cuda:0')
+        monkeypatch.setenv('BSIG_DP_RESIDENT', '0')
+        ref = bench.build_gpu_model(pkg, cfg, 'cuda:0', 35)
+        ref.model.enable_data_parallel()
+        np.random.seed(36)
+        ref_logs = ref.fit(theta, states, actions)
+        monkeypatch.setenv('BSIG_DP_RESIDENT', '1')
+        lib = pkg._lib.load()
+        bs = bench.build_gpu_model(pkg, cfg, 'cuda:0', 35)
+        bs.model.enable_data_parallel()
+        np.random.seed(36)
+        with pytest.warns(RuntimeWarning, match='resident across the gradient exchange timed out'):
+            monkeypatch.setenv('BSIG_DP_XR_DROP_CALL', '1')      # the communicator's second call: chunk 1 of 3
+            logs = bs.fit(theta, states, actions)
+        torch.cuda.synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert not getattr(bs.model, '_no_persistent', False)
+    assert lib.bsig_comm_resident_mode(bs.model._dp.comm) == 0
+    assert logs == ref_logs and torch.equal(bs.model._flat, ref.model._flat)
