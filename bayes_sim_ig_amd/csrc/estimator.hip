@@ -1218,6 +1218,26 @@ __global__ void pack_dp_logs_kernel(const float* train_loss, const float* test_l
 // 8(e)).  Nothing in the launch's arguments changes from update to update (everything per-step is
 // resolved on the device).  BSIG_DP_GRAPH=0 keeps the direct calls; a failed capture is recorded
 // (bsig_fit_dp_graph_status) and the direct calls are used.
+// The gradient exchange of a data-parallel update.  (tests) BSIG_DEBUG_GRAD_EXCHANGE_SCALE=s multiplies
+// the exchanged gradients by s, as s identical peers would: the all-reduce of a 1-rank group is the
+// identity, which cannot tell a rank that takes its Adam step from the REDUCED buffer from one that
+// keeps its own gradients -- with s != 1 every path must consume what the exchange left in memory.
+__global__ void debug_scale_kernel(float* buf, int64_t n, float s) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    buf[i] *= s;
+}
+static int allreduce_grads(bsig_fit_plan* p, bsig_comm* comm, bsig_stream_t stream) {
+  BSIG_TRY(bsig_comm_allreduce(comm, p->buf.grads, p->L.total, stream));
+  if (const char* e = getenv("BSIG_DEBUG_GRAD_EXCHANGE_SCALE")) {
+    const float s = (float)atof(e);
+    if (s != 1.0f) {
+      hipLaunchKernelGGL(debug_scale_kernel, dim3(256), dim3(256), 0, as_stream(stream), p->buf.grads, p->L.total, s);
+      BSIG_CHECK_LAUNCH("debug_scale");
+    }
+  }
+  return BSIG_OK;
+}
+
 static int ensure_dp_graph(bsig_fit_plan* p, bsig_comm* comm) {
   if (p->g_dp_state == 1 && p->g_dp_comm == comm) return BSIG_OK;
   if (p->g_dp_state < 0 && p->g_dp_comm == comm) return BSIG_OK;
@@ -1237,7 +1257,7 @@ static int ensure_dp_graph(bsig_fit_plan* p, bsig_comm* comm) {
   if (e == hipSuccess) {
     p->adam_pending = true;
     rc = enqueue_persistent(p, 1, p->cap_stream, dp_eval_total(p));
-    if (rc == BSIG_OK) rc = bsig_comm_allreduce(comm, p->buf.grads, p->L.total, reinterpret_cast<bsig_stream_t>(p->cap_stream));
+    if (rc == BSIG_OK) rc = allreduce_grads(p, comm, reinterpret_cast<bsig_stream_t>(p->cap_stream));
     e = hipStreamEndCapture(p->cap_stream, &graph);
   }
   if (e == hipSuccess && rc == BSIG_OK) e = hipGraphInstantiate(&p->g_dp, graph, nullptr, nullptr, 0);
@@ -1313,7 +1333,7 @@ static int run_dp_resident(bsig_fit_plan* p, bsig_comm* comm, int64_t n_updates,
   for (int64_t u = 1; u <= (dropped ? 0 : n_updates); ++u) {
     BSIG_HIP(hipStreamWaitValue32(xr.stream, xr.ready, xr.base + (uint32_t)u, hipStreamWaitValueGte, 0xFFFFFFFFu));
     if (!skip)
-      BSIG_TRY(bsig_comm_allreduce(comm, p->buf.grads, p->L.total, reinterpret_cast<bsig_stream_t>(xr.stream)));
+      BSIG_TRY(allreduce_grads(p, comm, reinterpret_cast<bsig_stream_t>(xr.stream)));
     BSIG_HIP(hipStreamWriteValue32(xr.stream, xr.done, xr.base + (uint32_t)u, 0));
   }
   BSIG_HIP(hipEventRecord(xr.ev_end[slot], xr.stream));
@@ -1380,7 +1400,7 @@ extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_upda
       p->adam_pending = true;
     } else {
       BSIG_TRY(bsig_fit_grad(p, stream));
-      BSIG_TRY(bsig_comm_allreduce(comm, p->buf.grads, p->L.total, stream));
+      BSIG_TRY(allreduce_grads(p, comm, stream));
       BSIG_TRY(bsig_fit_apply(p, stream));
     }
     if (it % every == 0 || it + 1 == n_updates) { BSIG_TRY(bsig_fit_eval(p, stream)); ++n_evals; }

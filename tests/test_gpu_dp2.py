@@ -221,3 +221,42 @@ def test_resident_launch_that_times_out_falls_back_to_one_launch_per_update(monk
     assert not getattr(bs.model, '_no_persistent', False)
     assert lib.bsig_comm_resident_mode(bs.model._dp.comm) == 0
     assert logs == ref_logs and torch.equal(bs.model._flat, ref.model._flat)
+
+
+@pytest.mark.parametrize('config', ['cfg5', 'cfg3'])
+def test_resident_rank_takes_its_adam_step_from_the_exchanged_gradients(monkeypatch, config):
+    """A 1-rank group's all-reduce is the identity: a resident rank that kept its OWN gradients instead of
+    reloading the buffer the exchange stream reduced would pass every other test.  With the exchanged
+    gradients tripled (BSIG_DEBUG_GRAD_EXCHANGE_SCALE=3: three identical peers) the resident rank and the
+    launch-per-update rank must still agree bit for bit -- and both must differ from the unscaled fit."""
+    import bench
+    import bayes_sim_ig_amd as pkg
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29585')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    try:
+        cfg = dict(bench.CONFIGS[config])
+        theta, states, actions = bench.synth_pairs(cfg, 2000, 25, 'cuda:0')
+        out = {}
+        for mode, scale in (('0', '3'), ('1', '3'), ('1', None)):
+            monkeypatch.setenv('BSIG_DP_RESIDENT', mode)
+            if scale is None:
+                monkeypatch.delenv('BSIG_DEBUG_GRAD_EXCHANGE_SCALE', raising=False)
+            else:
+                monkeypatch.setenv('BSIG_DEBUG_GRAD_EXCHANGE_SCALE', scale)
+            bs = bench.build_gpu_model(pkg, cfg, 'cuda:0', 41)
+            bs.model.enable_data_parallel()
+            np.random.seed(42)
+            logs = bs.fit(theta, states, actions)
+            torch.cuda.synchronize()
+            assert not getattr(bs.model, '_no_persistent', False)
+            out[(mode, scale)] = (logs, bs.model._flat.clone(), bs.model._dp.resident_calls())
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert out[('0', '3')][2] == 0 and out[('1', '3')][2] == 2 and out[('1', None)][2] == 2
+    assert torch.equal(out[('0', '3')][1], out[('1', '3')][1])
+    assert out[('0', '3')][0] == out[('1', '3')][0]
+    assert not torch.equal(out[('1', '3')][1], out[('1', None)][1])
