@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""Which earlier activity in a process breaks the resident exchange?  argv: steps before the resident fit:
-'train' (a single-process MDRFF-512 run_training), 'spawn' (two child processes on the GPU), 'stream'
-(a few extra streams), 'sync'."""
+"""Which earlier activity of a process breaks the resident exchange (profiles/r05_NOTES.md, "Resident
+exchange", item 7)?  argv: steps before the resident fit on a 1-rank RCCL group --
+'train[_nograph][_nopersist][_del]' (a single-process MDRFF-512 run_training), 'fit_nodp', 'model_only',
+'libkernel', 'pinned' / 'pageable' (a host-to-device copy), 'nbstream' (a kernel on a side stream),
+'stream', 'spawn' (two child processes on the GPU), 'sync', 'init' (init_process_group here, not at the
+end), 'comm' (the C-ABI communicator here).  Prints whether the fit timed out and the resident calls.
+With the exchange stream chosen by a probe (comm.cpp: comm_xr) every combination runs clean."""
 import os
 import sys
 import warnings
@@ -69,12 +73,6 @@ def main():
         elif step == 'comm':       # the C-ABI communicator (and RCCL's own init) ahead of everything else
             from bayes_sim_ig_amd import dp as _dp
             keep.append(_dp.DataParallel(None).init_comm('cuda:0'))
-        elif step == 'xtrain':
-            import test_gpu_dp2 as t
-            m = t._model(pkg, 512, 1e-5)
-            x, y, ids = t._data(0)
-            m.run_training(x.cuda(), y.cuda(), t.NU, t.B, test_frac=0.2, ids_table=ids)
-            keep.append(m)
         elif step == 'spawn':
             mp.spawn(child, nprocs=2, join=True)
         elif step == 'stream':
