@@ -490,15 +490,24 @@ __device__ __forceinline__ void diag_row_body(const HeadArgs& a, const RowGeom& 
   out.lse = lse; out.uds = uds; out.bad = bad;
 }
 
-template <typename Eps>
+// NQCAP: what the caller knows about the sweeps (rg.nq <= NQCAP): a kernel built for NQCAP = 2 carries
+// only the two-sweep body and its registers (the wave kernel: 109 -> VGPRs of the <2> body alone).
+template <int NQCAP = kElemsPerLane, typename Eps>
 __device__ __forceinline__ void diag_row_impl(const HeadArgs& a, const RowGeom& rg, int row, bool active,
                                               int lane, float* tile, const float* yv, float* rk,
                                               float* lpk, float* dlg, Eps& eps_src, RowOut& out,
                                               const float* eu_pre) {
   (void)lpk;
-  if (rg.nq <= 2) diag_row_body<2>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
-  else if (rg.nq <= 4) diag_row_body<4>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
-  else diag_row_body<kElemsPerLane>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+  if constexpr (NQCAP <= 2) {
+    diag_row_body<2>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+  } else if constexpr (NQCAP <= 4) {
+    if (rg.nq <= 2) diag_row_body<2>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+    else diag_row_body<4>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+  } else {
+    if (rg.nq <= 2) diag_row_body<2>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+    else if (rg.nq <= 4) diag_row_body<4>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+    else diag_row_body<kElemsPerLane>(a, rg, row, active, lane, tile, yv, rk, dlg, eps_src, out, eu_pre);
+  }
 }
 
 // `eps_fn()` form: the jitter scale from a plain callable; the lane geometry computed here
@@ -510,6 +519,15 @@ __device__ __forceinline__ void diag_row(const HeadArgs& a, int row, bool active
   EpsNow<EpsFn&> e{eps_fn};
   const RowGeom rg = row_geom(a.D, a.K, lane);
   diag_row_impl(a, rg, row, active, lane, tile, yv, rk, lpk, dlg, e, out, eu_pre);
+}
+// ... for a kernel built for at most NQCAP sweeps
+template <int NQCAP, typename EpsFn>
+__device__ __forceinline__ void diag_row_capped(const HeadArgs& a, int row, bool active, int lane,
+                                                float* tile, const float* yv, float* rk, float* lpk,
+                                                float* dlg, EpsFn&& eps_fn, RowOut& out) {
+  EpsNow<EpsFn&> e{eps_fn};
+  const RowGeom rg = row_geom(a.D, a.K, lane);
+  diag_row_impl<NQCAP>(a, rg, row, active, lane, tile, yv, rk, lpk, dlg, e, out, nullptr);
 }
 #endif
 

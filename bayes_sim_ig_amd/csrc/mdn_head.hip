@@ -257,7 +257,7 @@ __global__ void mdn_nll_kernel(HeadArgs a) {
   if (bad && a.nonfinite) atomicOr(a.nonfinite, 1);
 }
 
-template <int WPB>
+template <int WPB, int NQCAP = kElemsPerLane>
 __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int D = a.D, K = a.K, Nh = a.Nh;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(WPB * 64) void mdn_nll_diag_wave_kernel(HeadArgs a)
   __builtin_amdgcn_wave_barrier();
 
   RowOut ro;
-  diag_row(a, row, active, lane, tile, yv, rk, lpk, dlg, [&] { return eps; }, ro);
+  diag_row_capped<NQCAP>(a, row, active, lane, tile, yv, rk, lpk, dlg, [&] { return eps; }, ro);
   const bool bwd = a.d_out != nullptr;
   if (bwd && active) {
     float* o = a.d_out + (int64_t)row * a.ld_dout;
@@ -596,9 +596,16 @@ int mdn_head_nll_launch(const bsig_head_dims* dims, const float* seg_w, int64_t 
   a.sig_partials = sig_partials; a.n_sig = n_sig;
   a.d_out = d_out; a.ld_dout = ld_dout;
   a.block_lse = block_lse; a.block_uds = block_uds; a.nonfinite = nonfinite;
-  if (g.wave_per_row)
-    hipLaunchKernelGGL(mdn_nll_diag_wave_kernel<kWavesPerBlock>, dim3(g.blocks),
-                       dim3(g.threads), g.lds, st, a);
+  if (g.wave_per_row) {
+    // (rows of at most two sweeps -- D <= 2 * (64 / K): every BASELINE shape -- run the kernel that
+    // carries only the two-sweep row body: fewer registers, twice the rows per CU in flight)
+    const int nq = ceil_div(g.D, 64 / g.K);
+    if (nq <= 2)
+      hipLaunchKernelGGL((mdn_nll_diag_wave_kernel<kWavesPerBlock, 2>), dim3(g.blocks), dim3(g.threads), g.lds, st, a);
+    else
+      hipLaunchKernelGGL((mdn_nll_diag_wave_kernel<kWavesPerBlock, kElemsPerLane>), dim3(g.blocks), dim3(g.threads),
+                         g.lds, st, a);
+  }
   else if (g.Ls > 0)
     hipLaunchKernelGGL(mdn_nll_kernel<true>, dim3(g.blocks), dim3(g.threads), g.lds, st, a);
   else
