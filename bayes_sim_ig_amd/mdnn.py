@@ -562,7 +562,10 @@ class MDNN(nn.Module):
             and uploaded through a pinned staging ring (a pageable source would make the copy wait
             for the stream to drain)."""
             if ids_table is None:
-                ids_np = np.random.randint(0, n_train, (n_updates, batch_size))
+                # (dtype=int32: the SAME draws from the same stream as the reference's int64 default --
+                # tests/test_ids_draw.py -- in half the host time and without the astype pass: at 122 x
+                # 8192 ids the draw is what the GPU waits for when the host is busy)
+                ids_np = np.random.randint(0, n_train, (n_updates, batch_size), dtype=np.int32)
             else:
                 ids_np = np.asarray(ids_table)
                 assert ids_np.shape == (n_updates, batch_size)
@@ -576,7 +579,7 @@ class MDNN(nn.Module):
             ring['next'] += 1
             if slot[1] is not None:
                 slot[1].synchronize()
-            slot[0][:n_ids].copy_(torch.from_numpy(ids_np.astype(np.int32)).reshape(-1))
+            slot[0][:n_ids].copy_(torch.from_numpy(np.ascontiguousarray(ids_np, dtype=np.int32)).reshape(-1))
             # (a copy KERNEL reading the pinned buffer across PCIe instead of this DMA copy was measured in
             # round 5: 487.5 k against 489.0 k pairs/s -- the ~20 us "gap before the next fit_begin_kernel"
             # of the chunk timeline is not the copy engine's hand-off)
