@@ -44,7 +44,6 @@ for f in bench_line.json yaml_configs.txt anymal_update_timeline.txt shadow_more
   [ -f "$OUT/${TAG}_$f" ] && [ "${f##*.}" = txt ] && sed -i "1i # head: $HEADSHA\n# csrc: $CSRC" "$OUT/${TAG}_$f"
 done
 bash tools/round_profiles.sh "$TAG" "$HEADSHA"
-# The bench line is NOT taken here: right behind the counter passes the chip runs slow (a scaled-batch
-# fit at 0.49 of the peak instead of 0.65, measured), and bench.pmc_traffic wants this pass's counters
-# in profiles/ first.  Copy the files into profiles/, then, in a call of its own:
+# The bench line is NOT taken here: bench.pmc_traffic wants this pass's counters in profiles/ first (and
+# a line taken right behind the counter passes once read a scaled-batch fit at 0.49 of the peak).  Copy the files into profiles/, then, in a call of its own:
 #   python bench.py > gpurun_out/<tag>_bench_line.json
