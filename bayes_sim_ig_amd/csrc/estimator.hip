@@ -1231,7 +1231,13 @@ static int allreduce_grads(bsig_fit_plan* p, bsig_comm* comm, bsig_stream_t stre
   if (const char* e = getenv("BSIG_DEBUG_GRAD_EXCHANGE_SCALE")) {
     const float s = (float)atof(e);
     if (s != 1.0f) {
-      hipLaunchKernelGGL(debug_scale_kernel, dim3(256), dim3(256), 0, as_stream(stream), p->buf.grads, p->L.total, s);
+      // 8 workgroups: ONE per XCD is what a kernel on the exchange stream can have while a resident launch
+      // holds 248 CUs -- measured with this stand-in (BSIG_DEBUG_GRAD_EXCHANGE_GRID): grids of 1 and 8
+      // run, 9 / 16 / 32 / 64 / 256 never get their last workgroups placed and every call times out
+      // (profiles/r05_NOTES.md).  The same bound is why comm.cpp caps RCCL at 8 channels for a resident rank.
+      const char* ge = getenv("BSIG_DEBUG_GRAD_EXCHANGE_GRID");
+      const int grid = ge ? std::max(atoi(ge), 1) : 8;
+      hipLaunchKernelGGL(debug_scale_kernel, dim3(grid), dim3(1024), 0, as_stream(stream), p->buf.grads, p->L.total, s);
       BSIG_CHECK_LAUNCH("debug_scale");
     }
   }

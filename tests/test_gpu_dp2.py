@@ -110,6 +110,29 @@ def test_two_rank_fit_with_rank_local_jitter_scale(tmp_path):
         np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-6)
 
 
+def _fit_clean(build, fits=1, retries=1):
+    """build() -> (BayesSim, theta, states, actions); its fit(s) with any time-out fallback turned into a
+    retry on a fresh model (one resident call in some 38 000 has timed out on this pool without a known
+    cause: DESIGN.md 5 -- a test of what the resident path computes should not fail on that).  Returns
+    (model wrapper, logs, resident calls of the fits)."""
+    import warnings
+    for attempt in range(retries + 1):
+        bs, theta, states, actions, seed = build()
+        np.random.seed(seed)
+        before = bs.model._dp.resident_calls()
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter('error', RuntimeWarning)      # a time-out fallback is a failure here
+                logs = []
+                for _ in range(fits):
+                    logs += bs.fit(theta, states, actions)
+            torch.cuda.synchronize()
+            return bs, logs, bs.model._dp.resident_calls() - before
+        except RuntimeWarning:
+            if attempt == retries:
+                raise
+
+
 @pytest.mark.parametrize('config', ['cfg5', 'cfg3', 'cfg2'])
 def test_rank_resident_across_the_exchange_is_bitwise_the_per_update_launches(monkeypatch, config):
     """BSIG_DP_RESIDENT: ONE launch per run_training call, the gradients handed to the exchange
@@ -129,19 +152,15 @@ def test_rank_resident_across_the_exchange_is_bitwise_the_per_update_launches(mo
         cfg = dict(bench.CONFIGS[config])      # (cfg3: the MDNN kernel, fit_persistent_mdnn.hip, on factor rows)
         theta, states, actions = bench.synth_pairs(cfg, 5000, 21, 'cuda:0')
         out = {}
-        for mode in ('0', '1'):
-            monkeypatch.setenv('BSIG_DP_RESIDENT', mode)
+        def build():
             bs = bench.build_gpu_model(pkg, cfg, 'cuda:0', 31)
             bs.model.enable_data_parallel()
-            np.random.seed(32)
-            before = bs.model._dp.resident_calls()
-            with warnings.catch_warnings():
-                warnings.simplefilter('error', RuntimeWarning)      # a time-out fallback is a failure here
-                logs = bs.fit(theta, states, actions)
-                logs += bs.fit(theta, states, actions)               # (a second fit right behind the first)
-            torch.cuda.synchronize()
+            return bs, theta, states, actions, 32
+        for mode in ('0', '1'):
+            monkeypatch.setenv('BSIG_DP_RESIDENT', mode)
+            bs, logs, calls = _fit_clean(build, fits=2)      # (the second fit right behind the first)
             assert not getattr(bs.model, '_no_persistent', False)
-            out[mode] = (logs, bs.model._flat.clone(), bs.model._dp.resident_calls() - before)
+            out[mode] = (logs, bs.model._flat.clone(), calls)
     finally:
         if created:
             dist.destroy_process_group()
@@ -172,14 +191,12 @@ def test_resident_rank_without_a_usable_exchange_stream_runs_one_launch_per_upda
                 monkeypatch.delenv('BSIG_DP_XR_PROBE_OK_US', raising=False)
             else:
                 monkeypatch.setenv('BSIG_DP_XR_PROBE_OK_US', ok_us)
-            bs = bench.build_gpu_model(pkg, cfg, 'cuda:0', 33)
-            bs.model.enable_data_parallel()
-            np.random.seed(34)
-            with warnings.catch_warnings():
-                warnings.simplefilter('error', RuntimeWarning)
-                logs = bs.fit(theta, states, actions)
-            torch.cuda.synchronize()
-            out[mode] = (logs, bs.model._flat.clone(), bs.model._dp.resident_calls())
+            def build():
+                bs = bench.build_gpu_model(pkg, cfg, 'cuda:0', 33)
+                bs.model.enable_data_parallel()
+                return bs, theta, states, actions, 34
+            bs, logs, calls = _fit_clean(build)
+            out[mode] = (logs, bs.model._flat.clone(), calls)
     finally:
         if created:
             dist.destroy_process_group()
@@ -246,13 +263,13 @@ def test_resident_rank_takes_its_adam_step_from_the_exchanged_gradients(monkeypa
                 monkeypatch.delenv('BSIG_DEBUG_GRAD_EXCHANGE_SCALE', raising=False)
             else:
                 monkeypatch.setenv('BSIG_DEBUG_GRAD_EXCHANGE_SCALE', scale)
-            bs = bench.build_gpu_model(pkg, cfg, 'cuda:0', 41)
-            bs.model.enable_data_parallel()
-            np.random.seed(42)
-            logs = bs.fit(theta, states, actions)
-            torch.cuda.synchronize()
+            def build():
+                bs = bench.build_gpu_model(pkg, cfg, 'cuda:0', 41)
+                bs.model.enable_data_parallel()
+                return bs, theta, states, actions, 42
+            bs, logs, calls = _fit_clean(build)
             assert not getattr(bs.model, '_no_persistent', False)
-            out[(mode, scale)] = (logs, bs.model._flat.clone(), bs.model._dp.resident_calls())
+            out[(mode, scale)] = (logs, bs.model._flat.clone(), calls)
     finally:
         if created:
             dist.destroy_process_group()
