@@ -257,6 +257,51 @@ def gen_chunk_mdrff():
                4, 4, [], False, 23)
 
 
+# ------------------------------------- f4: cos-only features, Matern draws
+def gen_rff_variants():
+    """rff.py:98-102,122-126 (cos-only feature map + its offsets) and
+    rff.py:151-184 (Matern12/32/52 Student-t frequency draws) from the
+    reference's own RFF class, input_dim > 100 so that no ghalton is reached.
+    Call order pinned: draw_freqs (normal, then chisquare) BEFORE the offsets'
+    np.random.rand."""
+    from bayes_sim_ig.models.rff import RFF
+    g = torch.Generator().manual_seed(301)
+    x = torch.randn(12, 302, generator=g) * 0.5
+    out = {'x': x.numpy()}
+    np.random.seed(31)
+    r = RFF(64, 302, 4.0, cos_only=True, quasi_random=False, kernel='RBF')
+    out['cos_rbf.seed'] = np.int64(31)
+    out['cos_rbf.freqs'] = r.freqs.numpy()
+    out['cos_rbf.offset'] = r.offset.numpy()
+    out['cos_rbf.a'] = np.float64(r.a)
+    out['cos_rbf.features'] = r.to_features(x).numpy()
+    out['cos_rbf.rng_after'] = np.int64(np.random.randint(0, 1 << 30))
+    for i, kern in enumerate(('Matern12', 'Matern32', 'Matern52', 'Laplace')):
+        seed = 40 + i
+        for cos_only in (False, True):
+            tag = '%s.%s' % (kern, 'cos' if cos_only else 'cossin')
+            np.random.seed(seed)
+            r = RFF(48, 150, [0.5 + 0.01 * j for j in range(150)],
+                    cos_only=cos_only, quasi_random=False, kernel=kern)
+            out[tag + '.seed'] = np.int64(seed)
+            out[tag + '.freqs'] = r.freqs.numpy()
+            out[tag + '.a'] = np.float64(r.a)
+            if cos_only:
+                out[tag + '.offset'] = r.offset.numpy()
+            xs = x[:, :150] * 0.05      # heavy-tailed freqs: keep |inner| moderate
+            out[tag + '.features'] = r.to_features(xs).numpy()
+            out[tag + '.rng_after'] = np.int64(np.random.randint(0, 1 << 30))
+    out['x150'] = (x[:, :150] * 0.05).numpy()
+    save('rff_variants.npz', **out)
+
+
+def gen_chunk_mdrff_matern():
+    """bayes_sim.py:72-81: 'MDRFF_Matern32_2.0' -> kernel Matern32, sigma 2.0,
+    n_feat 200; teacher-forced chunk like chunk_mdrff_corrdiff."""
+    chunk_case('mdrff_matern32', 'MDRFF_Matern32_2.0', 'summary_corrdiff', 200,
+               21, 4, 1, 4, 4, [], False, 24)
+
+
 # ------------------------------------------------------------------- pdf
 def gen_pdf():
     rs = np.random.RandomState(5)
@@ -342,9 +387,11 @@ def gen_pendulum():
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    gen_summaries()
-    gen_one_step()
-    gen_chunks()
-    gen_chunk_mdrff()
-    gen_pdf()
-    gen_pendulum()
+    # no argument: every fixture; otherwise only the named generators
+    # (round 6 added gen_rff_variants / gen_chunk_mdrff_matern without
+    # rewriting the older files: `make_golden.py gen_rff_variants gen_chunk_mdrff_matern`)
+    todo = sys.argv[1:] or ['gen_summaries', 'gen_one_step', 'gen_chunks',
+                            'gen_chunk_mdrff', 'gen_rff_variants',
+                            'gen_chunk_mdrff_matern', 'gen_pdf', 'gen_pendulum']
+    for name in todo:
+        globals()[name]()

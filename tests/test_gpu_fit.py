@@ -39,6 +39,9 @@ CHUNKS = {
                                hidden=(16, 16), full=True),
     'mdrff_corrdiff': dict(cls='MDRFF', summarizer='summary_corrdiff', d=4, k=4,
                            hidden=[], full=False),
+    # f4: the reference's BayesSim built with modelClass 'MDRFF_Matern32_2.0' (bayes_sim.py:72-81)
+    'mdrff_matern32': dict(cls='MDRFF', summarizer='summary_corrdiff', d=4, k=4,
+                           hidden=[], full=False, kernel='Matern32', sigma=2.0),
 }
 
 
@@ -50,7 +53,9 @@ def _chunk_model(B, tag, g, input_dim):
                   full_covariance=kw['full'], lr=float(g['lr']),
                   activation=torch.nn.Tanh, device=DEV)
     if kw['cls'] == 'MDRFF':
-        m = B.MDRFF(n_feat=200, sigma=4.0, freqs=g['rff.freqs'], **common)
+        m = B.MDRFF(n_feat=200, sigma=kw.get('sigma', 4.0), kernel=kw.get('kernel', 'RBF'),
+                    freqs=g['rff.freqs'], **common)
+        np.testing.assert_array_equal(m.rff.sigma.cpu().numpy(), g['rff.sigma'])
     else:
         m = B.MDNN(hidden_layers=kw['hidden'], **common)
     m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items()

@@ -324,6 +324,61 @@ def test_rff_features_match_reference(B):
         B.RFF(64, 302, 4.0, kernel='Nope', quasi_random=False)
 
 
+RFF_VARIANTS = ['cos_rbf'] + ['%s.%s' % (k, m) for k in ('Matern12', 'Matern32', 'Matern52',
+                                                           'Laplace')
+                              for m in ('cossin', 'cos')]
+
+
+@pytest.mark.parametrize('tag', RFF_VARIANTS)
+def test_rff_variants_match_reference(B, tag):
+    """f4: bsig_rff_project(cos_only=1) (rff.py:122-126, offsets :98-102) and the cos/sin map on
+    Matern / Laplace frequencies (rff.py:151-184) against features the reference's own RFF objects
+    produced (tests/golden/rff_variants.npz); the draw itself is bit-equal."""
+    g = golden('rff_variants.npz')
+    if tag == 'cos_rbf':
+        args, xk = dict(n_feat=64, d=302, sigma=4.0, cos_only=True, kernel='RBF'), 'x'
+    else:
+        kern, mode = tag.split('.')
+        args, xk = dict(n_feat=48, d=150, sigma=[0.5 + 0.01 * j for j in range(150)],
+                        cos_only=(mode == 'cos'), kernel=kern), 'x150'
+    np.random.seed(int(g[tag + '.seed']))
+    rff = B.RFF(quasi_random=False, device=DEV, **args)
+    assert int(np.random.randint(0, 1 << 30)) == int(g[tag + '.rng_after'])
+    np.testing.assert_array_equal(rff.freqs.cpu().numpy(), g[tag + '.freqs'])
+    if args['cos_only']:
+        np.testing.assert_array_equal(rff.offset.cpu().numpy(), g[tag + '.offset'])
+    out = rff.to_features(torch.from_numpy(g[xk]).to(DEV)).cpu().numpy()
+    assert out.shape == g[tag + '.features'].shape
+    # the fp32 error of the inner product (~1e-7 |inner| per term order) passes straight through
+    # cos / sin: 3e-6 where |inner| <= 8 (every RBF / Matern32 / Matern52 entry), scaled with
+    # |inner| for the Cauchy-tailed Matern12 / Laplace frequencies (|inner| up to 1.8e3)
+    sig = rff.sigma.cpu().numpy().astype(np.float64)
+    inner = g[xk].astype(np.float64) @ (g[tag + '.freqs'].astype(np.float64) / sig).T
+    if not args['cos_only']:
+        inner = np.concatenate([inner, inner], axis=1)
+    tol = 3e-6 * np.maximum(1.0, np.abs(inner) / 8.0)
+    err = np.abs(out - g[tag + '.features'])
+    assert (err <= tol).all(), (tag, float((err / tol).max()))
+    # and against the fp64 value of the same map, same bound
+    if args['cos_only']:
+        f64 = float(g[tag + '.a']) * np.cos(inner + g[tag + '.offset'].astype(np.float64))
+    else:
+        half = inner[:, :inner.shape[1] // 2]
+        f64 = float(g[tag + '.a']) * np.concatenate([np.cos(half), np.sin(half)], axis=1)
+    assert (np.abs(out - f64) <= tol).all()
+
+
+def test_rff_cos_only_large_shape_vs_fp64(B):
+    """cos-only epilogue on a GEMM-sized problem (several tiles, ragged edges)."""
+    np.random.seed(5)
+    rff = B.RFF(1000, 302, 4.0, cos_only=True, quasi_random=False, device=DEV)
+    x = torch.randn(777, 302, generator=torch.Generator().manual_seed(6))
+    out = rff.to_features(x.to(DEV)).cpu().numpy()
+    inner = x.numpy().astype(np.float64) @ (rff.freqs.cpu().numpy().astype(np.float64) / 4.0).T
+    f64 = float(rff.a) * np.cos(inner + rff.offset.cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(out, f64, rtol=0, atol=3e-6)
+
+
 # ------------------------------------------------------------------- MDN head
 def _head_dims(B, d, k, full, eps):
     hd = B._lib.HeadDims()

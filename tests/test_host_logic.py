@@ -92,6 +92,33 @@ def test_mdrff_frequency_draw_consumes_numpy_rng_like_reference():
         B.RFF(64, 302, 4.0, kernel='Bogus', quasi_random=False)
 
 
+@pytest.mark.parametrize('tag', ['cos_rbf'] + ['%s.%s' % (k, m)
+                                               for k in ('Matern12', 'Matern32', 'Matern52',
+                                                         'Laplace')
+                                               for m in ('cossin', 'cos')])
+def test_rff_variant_draws_are_the_references(tag):
+    """f4 (host half): the product RFF consumes the numpy RNG like the reference's RFF for the
+    cos-only map (freqs, then 2*pi*rand offsets, rff.py:98-102) and for the Matern / Laplace
+    Student-t draws (normal, then chisquare, rff.py:151-184): frequencies, offsets and the RNG
+    state afterwards equal the reference-generated golden bit for bit."""
+    g = golden('rff_variants.npz')
+    if tag == 'cos_rbf':
+        args = dict(n_feat=64, d=302, sigma=4.0, cos_only=True, kernel='RBF')
+    else:
+        kern, mode = tag.split('.')
+        args = dict(n_feat=48, d=150, sigma=[0.5 + 0.01 * j for j in range(150)],
+                    cos_only=(mode == 'cos'), kernel=kern)
+    np.random.seed(int(g[tag + '.seed']))
+    r = B.RFF(quasi_random=False, device='cpu', **args)
+    assert int(np.random.randint(0, 1 << 30)) == int(g[tag + '.rng_after'])
+    np.testing.assert_array_equal(r.freqs.numpy(), g[tag + '.freqs'])
+    assert float(r.a) == float(g[tag + '.a'])
+    if args['cos_only']:
+        np.testing.assert_array_equal(r.offset.numpy(), g[tag + '.offset'])
+    else:
+        assert r.offset is None
+
+
 @pytest.mark.skipif(not NO_GPU, reason='checks the no-GPU failure mode')
 def test_product_path_fails_loudly_without_gpu():
     m = B.MDNN(input_dim=4, output_dim=2, output_lows=np.zeros(2), output_highs=np.ones(2),
@@ -120,6 +147,25 @@ def test_bayessim_constructs_by_name_like_reference():
         B.BayesSim(model_cfg=dict(cfg, summarizerFxn='nope'), obs_dim=4, act_dim=1,
                    params_dim=13, params_lows=np.zeros(13), params_highs=np.ones(13),
                    prior=None)
+
+
+def test_bayessim_matern_model_by_name_draws_the_references_model():
+    """f4: BayesSim(modelClass='MDRFF_Matern32_2.0') under the seeds make_golden.chunk_case used
+    builds the reference's model: same torch-RNG head init, same numpy-RNG Student-t frequencies
+    (bayes_sim.py:72-81, rff.py:167-170), sigma 2.0."""
+    g = golden('chunk_mdrff_matern32.npz')
+    cfg = {'modelClass': 'MDRFF_Matern32_2.0', 'summarizerFxn': 'summary_corrdiff',
+           'trainTrajLen': 21, 'components': 4, 'hiddenLayers': [], 'lr': 1e-3,
+           'fullCovariance': False}
+    B.MDNN.VERBOSE = False
+    torch.manual_seed(24)
+    np.random.seed(24)
+    bs = B.BayesSim(model_cfg=cfg, obs_dim=4, act_dim=1, params_dim=4,
+                    params_lows=np.zeros(4), params_highs=np.ones(4), prior=None)
+    np.testing.assert_array_equal(bs.model.rff.freqs.numpy(), g['rff.freqs'])
+    np.testing.assert_array_equal(bs.model.rff.sigma.numpy(), g['rff.sigma'])
+    for k, v in bs.model.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), g['w0.' + k])
 
 
 def test_compat_aliases():

@@ -125,6 +125,9 @@ def test_closed_form_head_matches_reference(tag):
                                 k=3, hidden=(16, 16), full=True)),
     ('mdrff_corrdiff', dict(cls='MDRFF', summarizer='summary_corrdiff', d=4,
                             k=4, hidden=[], full=False)),
+    # bayes_sim.py:72-81: 'MDRFF_Matern32_2.0' -> Student-t frequencies, sigma 2.0
+    ('mdrff_matern32', dict(cls='MDRFF', summarizer='summary_corrdiff', d=4,
+                            k=4, hidden=[], full=False, kernel='Matern32', sigma=2.0)),
 ])
 def test_teacher_forced_chunk_matches_reference(tag, kw):
     g = golden('chunk_%s.npz' % tag)
@@ -138,7 +141,9 @@ def test_teacher_forced_chunk_matches_reference(tag, kw):
                   full_covariance=kw['full'], lr=float(g['lr']),
                   activation=torch.nn.Tanh, eps_noise=0.0)
     if kw['cls'] == 'MDRFF':
-        m = oest.OracleMDRFF(n_feat=200, sigma=4.0, freqs=g['rff.freqs'], **common)
+        m = oest.OracleMDRFF(n_feat=200, sigma=kw.get('sigma', 4.0),
+                             kernel=kw.get('kernel', 'RBF'), freqs=g['rff.freqs'], **common)
+        np.testing.assert_array_equal(m.rff.sigma.numpy(), g['rff.sigma'])
     else:
         m = oest.OracleMDNN(hidden_layers=kw['hidden'], **common)
     m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items()
@@ -157,6 +162,40 @@ def test_teacher_forced_chunk_matches_reference(tag, kw):
     np.testing.assert_allclose(covs, g['mog.Ss'], rtol=1e-3, atol=1e-8)
     nll = -oden.mog_logpdf(a, ms, ls, g['theta'][n_train:n_train + 1])
     np.testing.assert_allclose(nll, g['mog.nll_true'], rtol=1e-4)
+
+
+RFF_VARIANTS = ['cos_rbf'] + ['%s.%s' % (k, m) for k in ('Matern12', 'Matern32', 'Matern52',
+                                                           'Laplace')
+                              for m in ('cossin', 'cos')]
+
+
+def rff_variant_args(tag):
+    """Constructor arguments make_golden.gen_rff_variants used for a case."""
+    if tag == 'cos_rbf':
+        return dict(n_feat=64, d=302, sigma=4.0, cos_only=True, kernel='RBF'), 'x'
+    kern, mode = tag.split('.')
+    return dict(n_feat=48, d=150, sigma=[0.5 + 0.01 * j for j in range(150)],
+                cos_only=(mode == 'cos'), kernel=kern), 'x150'
+
+
+@pytest.mark.parametrize('tag', RFF_VARIANTS)
+def test_rff_variants_match_reference(tag):
+    """f4: cos-only feature map + offsets (rff.py:98-102,122-126) and the
+    Matern / Laplace Student-t draws (rff.py:151-184), against the reference's
+    own RFF objects: frequencies and offsets bit-equal (same numpy-RNG call
+    order: normal, chisquare, then rand), global RNG left in the same state."""
+    g = golden('rff_variants.npz')
+    args, xk = rff_variant_args(tag)
+    np.random.seed(int(g[tag + '.seed']))
+    r = oest.OracleRFF(**args)
+    assert int(np.random.randint(0, 1 << 30)) == int(g[tag + '.rng_after'])
+    np.testing.assert_array_equal(r.freqs.numpy(), g[tag + '.freqs'])
+    assert float(r.a) == float(g[tag + '.a'])
+    if args['cos_only']:
+        np.testing.assert_array_equal(r.offset.numpy(), g[tag + '.offset'])
+    feats = r.to_features(torch.from_numpy(g[xk])).numpy()
+    assert feats.shape == g[tag + '.features'].shape == (12, args['n_feat'])
+    np.testing.assert_allclose(feats, g[tag + '.features'], rtol=0, atol=1e-6)
 
 
 def test_numpy_ids_stream_is_batchable():
