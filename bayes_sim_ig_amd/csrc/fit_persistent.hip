@@ -136,34 +136,23 @@ __device__ __forceinline__ int u_evals_before(int s, int every) { return s == 0 
 // A row owner's sum over the k-slices: out[r * out_pitch + col] = sum_z slabs[z * zs + rowoff(r) + col]
 // for r < nrows, col < n_cols (float offsets; `slabs` workgroup-uniform), slices added in order, up
 // to 16 loads in flight per lane -- buffer loads: one address register per lane, the slice offset
-// is scalar.  `fn(col, v)` sees every sum.  TAG: the slab words validate themselves (persist_device.h,
-// "self-validating payload words"): a batch of loads is re-issued until every word carries `par`.
-template <bool TAG, typename RowOff, typename F>
+// is scalar.  `fn(col, v)` sees every sum.
+template <typename RowOff, typename F>
 __device__ __forceinline__ void u_rows_sum(const float* slabs, RowOff&& rowoff, int k_slices, int zs, int nrows,
-                                           int n_cols, float* out, int out_pitch, int tid, unsigned par,
-                                           int32_t* flagp, F&& fn) {
+                                           int n_cols, float* out, int out_pitch, int tid, F&& fn) {
   const __amdgpu_buffer_rsrc_t sr = xwg_buffer(slabs);
   for (int idx = tid; idx < nrows * n_cols; idx += kUT) {
     const int r = idx / n_cols, col = idx - r * n_cols;
     const int voff = (rowoff(r) + col) * 4;
     float v = 0.f;
     for (int z = 0; z < k_slices; z += 16) {
-      unsigned q[16];
-      for (unsigned spin = 0;; ++spin) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          q[u] = __builtin_amdgcn_raw_buffer_load_b32(sr, voff, min(z + u, k_slices - 1) * zs * 4, kXwgPolicy);
-        if (!TAG) break;
-        unsigned bad = 0u;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) bad |= q[u] ^ par;
-        if ((bad & 1u) == 0u) break;
-        if (tagged_give_up(spin, flagp)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
+      float q[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u)
-        if (z + u < k_slices) v += TAG ? untagged(q[u]) : __uint_as_float(q[u]);
+        q[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, voff, min(z + u, k_slices - 1) * zs * 4, kXwgPolicy));
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (z + u < k_slices) v += q[u];
     }
     out[r * out_pitch + col] = v;
     fn(col, v);
@@ -174,10 +163,10 @@ __device__ __forceinline__ void u_rows_sum(const float* slabs, RowOff&& rowoff, 
 // slice group sg) adds the slices sg, sg + SG, ... of 4 adjacent columns (16-byte loads, <= 8 in
 // flight), the SG partial sums meet in LDS (`part`, 4 * kUT floats) and are added in group order.
 // A fixed partition: bitwise reproducible.  nrows * ld / 4 <= kUT quads (else: u_rows_sum).
-template <bool TAG, typename RowOff, typename F>
+template <typename RowOff, typename F>
 __device__ __forceinline__ void u_rows_sum4(const float* slabs, RowOff&& rowoff, int k_slices, int zs, int nrows,
                                             int n_cols, int ld, float* out, int out_pitch, float* part, int tid,
-                                            unsigned par, int32_t* flagp, F&& fn) {
+                                            F&& fn) {
   const __amdgpu_buffer_rsrc_t sr = xwg_buffer(slabs);
   const int ncq = (n_cols + 3) >> 2, Q = nrows * ncq;      // (only the quads that hold head outputs: 260 of 288 columns)
   const int SG = max(1, min(min(k_slices, kUT / Q), 8));
@@ -187,24 +176,12 @@ __device__ __forceinline__ void u_rows_sum4(const float* slabs, RowOff&& rowoff,
     const int voff = rowoff(r) + c4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int z0 = sg; z0 < k_slices; z0 += 8 * SG) {
-      u32x4 q[8];
-      for (unsigned spin = 0;; ++spin) {
+      f32x4 q[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) q[u] = xwg_load4_bits(sr, voff + min(z0 + u * SG, k_slices - 1) * zs);
-        if (!TAG) break;
-        bool ok = true;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ok = ok && tagged_ok4(q[u], par);
-        if (ok) break;
-        if (tagged_give_up(spin, flagp)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
+      for (int u = 0; u < 8; ++u) q[u] = xwg_load4(sr, voff + min(z0 + u * SG, k_slices - 1) * zs);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (z0 + u * SG < k_slices) {
-          if (TAG) v += untagged4(q[u]);
-          else { const f32x4 f = {__uint_as_float(q[u].x), __uint_as_float(q[u].y), __uint_as_float(q[u].z), __uint_as_float(q[u].w)}; v += f; }
-        }
+        if (z0 + u * SG < k_slices) v += q[u];
     }
     *reinterpret_cast<f32x4*>(part + 4 * (sg * Q + qc)) = v;
   }
@@ -296,12 +273,12 @@ __device__ __forceinline__ void u_owner_eval(const UArgs& p, float* XS, float* r
   const int nr = eo < p.n_test ? min(p.RE, (p.n_test - eo + p.NE - 1) / p.NE) : 0;   // this owner's rows
   const float* ebase = p.eval_slabs + (int64_t)(eidx % 3) * p.eval_passes * p.k_slices * B * NhP;
   float eacc = 0.f;
-  u_rows_sum<false>(ebase,
+  u_rows_sum(ebase,
              [&](int r) {
                const int erow = eo + p.NE * r, pass = erow / B, rb = erow - pass * B;
                return (pass * p.k_slices * B + rb) * NhP;
              },
-             p.k_slices, B * NhP, nr, Nh, XS, per_wave, tid, 0u, flagp,
+             p.k_slices, B * NhP, nr, Nh, XS, per_wave, tid,
              [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
   eacc = wave_sum_dpp(eacc);
   if (lane == 0) red[w] = eacc;
@@ -428,22 +405,21 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
     float eu_pre[kElemsPerLane];
     a.stream_id = rng_ctr0 + (uint64_t)t + (uint64_t)(p.do_eval ? u_evals_before(step, p.eval_every) - ev0 : 0);
     if (owner_wave) diag_row_noise(a, rg.groups, rg.k, rg.d0, row, active, lane, eu_pre);
-    // The forward product's slabs carry the update's parity in every word (persist_device.h): no flags.
-    // Quiet wait for ONE word of this owner's first row in the LAST k-slice (a workgroup that comes here
-    // ~10 us early must not sweep 22 slabs per round), then the sum's own loads check what they got.
-    const unsigned par = epoch & 1u;
-    if (w == 0) tagged_wait_one(p.slabs + ((int64_t)(p.k_slices - 1) * B + r0) * NhP, par, flagp);
+    if (w == 0) {
+      flag_wait_one(p.flag_fwd, p.G - 1, epoch, flagp);
+      flags_wait(p.flag_fwd, p.G, epoch, lane, flagp);
+    }
     __syncthreads();
     BSIG_USTAMP(4);
     float eacc = 0.f;
     if (!has_tile && p.R * NhP <= 4 * kUT)      // (the F^T region of a workgroup without a tile is free)
-      u_rows_sum4<true>(p.slabs, [&](int r) { return (r0 + r) * NhP; }, p.k_slices, B * NhP, min(p.R, B - r0), Nh,
-                        NhP, XS, per_wave, Ft, tid_l, par, flagp,
-                        [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
+      u_rows_sum4(p.slabs, [&](int r) { return (r0 + r) * NhP; }, p.k_slices, B * NhP, min(p.R, B - r0), Nh,
+                  NhP, XS, per_wave, Ft, tid_l,
+                  [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
     else
-      u_rows_sum<true>(p.slabs, [&](int r) { return (r0 + r) * NhP; }, p.k_slices, B * NhP,
-                       min(p.R, B - r0), Nh, XS, per_wave, tid_l, par, flagp,
-                       [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
+      u_rows_sum(p.slabs, [&](int r) { return (r0 + r) * NhP; }, p.k_slices, B * NhP,
+                 min(p.R, B - r0), Nh, XS, per_wave, tid_l,
+                 [&](int col, float v) { if (col >= K + DK && col < K + 2 * DK) eacc += expf(v); });
     eacc = wave_sum_dpp(eacc);
     if (lane == 0) red[w] = eacc;
     __syncthreads();
@@ -470,28 +446,22 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
       BSIG_USTAMP(7);
       if (active) {
         // d_out row without the jitter-scale term, and exp(pre) of the row for the tile
-        // workgroups to add it (lane's elements are columns lane + q*TPR): self-validating words,
-        // 16 bytes per lane (the quads [0, ceil4(Nh)) of the row; the tail of the last one: zeros) --
-        // nothing waits for the stores, the tile workgroups check the words they load
+        // workgroups to add it (lane's elements are columns lane + q*TPR)
         for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
         __builtin_amdgcn_wave_barrier();
-        const __amdgpu_buffer_rsrc_t dr = xwg_buffer(p.d_out + (int64_t)row * NhP);
-        for (int j4 = 4 * lane; j4 < Nh; j4 += 256) {
-          const float v0 = tile[j4], v1 = j4 + 1 < Nh ? tile[j4 + 1] : 0.f, v2 = j4 + 2 < Nh ? tile[j4 + 2] : 0.f,
-                      v3 = j4 + 3 < Nh ? tile[j4 + 3] : 0.f;
-          xwg_store4_tagged(dr, j4, v0, v1, v2, v3, par);
-        }
+        float* dst = p.d_out + (int64_t)row * NhP;
+        for (int j = lane; j < Nh; j += 64) xwg_store(dst + j, tile[j]);
         if (p.eps_noise != 0.f) {
           const int TPR = (64 / K) * K;
-          unsigned* est = reinterpret_cast<unsigned*>(p.e_out + (int64_t)row * NhP + K + DK);
+          float* est = p.e_out + (int64_t)row * NhP + K + DK;
 #pragma unroll
           for (int q = 0; q < kElemsPerLane; ++q)
-            if (lane < TPR && lane + q * TPR < DK)
-              __hip_atomic_store(est + lane + q * TPR, tagged_bits(ro.esg0[q], par), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < TPR && lane + q * TPR < DK) xwg_store(est + lane + q * TPR, ro.esg0[q]);
         }
       }
     }
-    lds_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
     if (tid_l == 0) {
       float sl = 0.f, su = 0.f;
       for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
@@ -791,14 +761,15 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
         }
         BSIG_USTAMP(1);
         if (rok) {
-          // (self-validating words: no acknowledgement, no flag -- the owners check what they load)
           const __amdgpu_buffer_rsrc_t sr = xwg_buffer(p.slabs + (int64_t)ks * B * NhP + n0);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            xwg_store4_tagged(sr, (16 * w + c16_l) * NhP + 16 * nt + 4 * g4_l, acc[nt][0], acc[nt][1], acc[nt][2],
-                              acc[nt][3], epoch & 1u);
+            xwg_store4(sr, (16 * w + c16_l) * NhP + 16 * nt + 4 * g4_l, acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
         }
       }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid_l == 0) flag_raise(p.flag_fwd, slot, epoch);
       BSIG_USTAMP(3);
       // the next minibatch's row ids (the tile itself is requested further down)
       if (t + 1 < p.n_updates) { BSIG_U_ROWID(step + 1) }
@@ -854,36 +825,16 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
         const __amdgpu_buffer_rsrc_t dr = xwg_buffer(p.d_out + n0), er = xwg_buffer(p.e_out + n0);
         constexpr int QN = NBW / 4;                // quads per row of the block
         constexpr int total = 16 * kUMT * QN;     // (rows beyond B: zeros)
-        const unsigned par = epoch & 1u;
         for (int base = 0; base < total; base += 2 * kUT) {
           f32x4 q[2], e[2];
-          // (self-validating words: re-load until every word of this thread's quads is this update's.
-          // Quads wholly beyond the head's Nh outputs are never written; of exp(pre) only the sigma
-          // columns are.)
-          for (unsigned spin = 0;; ++spin) {
-            bool good = true;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int idx = base + u * kUT + tid_l;
-              const int b = idx / QN, c4 = (idx - b * QN) * 4;
-              const bool ok = idx < total && b < B && n0 + c4 < Nh;
-              const u32x4 zero = {0u, 0u, 0u, 0u};
-              const u32x4 qb = ok ? xwg_load4_bits(dr, b * NhP + c4) : zero;
-              const u32x4 eb = ok && any_e ? xwg_load4_bits(er, b * NhP + c4) : zero;
-              good = good && (!ok || tagged_ok4(qb, par));
-              if (ok && any_e) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  const int n = n0 + c4 + j;
-                  good = good && !(n >= sg_lo && n < sg_hi && (eb[j] & 1u) != par);
-                }
-              }
-              q[u] = untagged4(qb);
-              e[u] = untagged4(eb);
-            }
-            if (good) break;
-            if (tagged_give_up(spin, flagp)) break;
-            __builtin_amdgcn_s_sleep(1);
+          for (int u = 0; u < 2; ++u) {
+            const int idx = base + u * kUT + tid_l;
+            const int b = idx / QN, c4 = (idx - b * QN) * 4;
+            const bool ok = idx < total && b < B;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            q[u] = ok ? xwg_load4(dr, b * NhP + c4) : zero;
+            e[u] = ok && any_e ? xwg_load4(er, b * NhP + c4) : zero;
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -1366,10 +1317,8 @@ int persist_reset_regions(const PersistShape& s, void* workspace, size_t workspa
                "persistent updates: workspace too small");
   char* base = reinterpret_cast<char*>(workspace);
   const size_t slab_bytes = g.slab_floats * sizeof(float);
-  // slabs, d_out / exp(pre) rows: self-validating words, a call starts from the parity of "update 0"
-  // (and the padding columns of d_out stay zero); flags and granules
-  (void)slab_bytes;
-  regions[0] = ZeroRegion{base, (g.slab_floats + 2 * g.dout_floats) * sizeof(float)};
+  // d_out / exp(pre) rows (their padding columns stay zero), flags and granules
+  regions[0] = ZeroRegion{base + slab_bytes, 2 * g.dout_floats * sizeof(float)};
   regions[1] = ZeroRegion{base + u_data_bytes(g), u_sync_bytes()};
   return BSIG_OK;
 }

@@ -97,59 +97,6 @@ __device__ __forceinline__ f32x4 xwg_load4(__amdgpu_buffer_rsrc_t r, int float_o
   return f;
 }
 
-// ---- self-validating payload words (round 6) -------------------------------------------------
-// A cross-workgroup payload used to cost three dependent memory trips: the payload's write-through
-// stores had to be ACKNOWLEDGED (s_waitcnt vmcnt(0), ~0.6 us) before a flag could be raised behind them,
-// the flag had to reach the poller, and only then did the consumer's loads start (MI355X_MICROARCH.md
-// price list: handoff-flag = 1.7-1.9 x handoff-1to1).  Here every 32-bit word of the payload carries
-// the parity of the update that wrote it in the LOWEST MANTISSA BIT (the value is rounded to nearest
-// even at bit 1 first: a relative error of 2^-24, half an ulp more than the store had anyway): the
-// consumer loads the payload itself, checks the parity of every word it got and re-issues the load
-// until all of them belong to the current update -- no acknowledgement, no flag, no second trip.  One
-// bit is enough: a location is rewritten once per update and nobody starts update t + 1 before every
-// consumer has taken update t's payload (the chain of the update orders that), so a reader can only
-// ever see the previous update's word or the current one; the regions start a call zeroed (parity of
-// update 0) and updates count from 1.  Tearing does not matter: each dword validates itself, a 16-byte
-// store is just four of them in one transaction.
-__device__ __forceinline__ unsigned tagged_bits(float v, unsigned par) {
-  const unsigned b = __float_as_uint(v);
-  return ((b + ((b >> 1) & 1u)) & ~1u) | par;
-}
-__device__ __forceinline__ float untagged(unsigned x) { return __uint_as_float(x & ~1u); }
-__device__ __forceinline__ bool tagged_ok4(u32x4 x, unsigned par) {
-  return ((((x.x ^ par) | (x.y ^ par)) | ((x.z ^ par) | (x.w ^ par))) & 1u) == 0u;
-}
-__device__ __forceinline__ void xwg_store4_tagged(__amdgpu_buffer_rsrc_t r, int float_off, float a, float b,
-                                                  float c, float d, unsigned par) {
-  const u32x4 v = {tagged_bits(a, par), tagged_bits(b, par), tagged_bits(c, par), tagged_bits(d, par)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, float_off * 4, 0, kXwgPolicy);
-}
-__device__ __forceinline__ u32x4 xwg_load4_bits(__amdgpu_buffer_rsrc_t r, int float_off) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, kXwgPolicy);
-}
-__device__ __forceinline__ f32x4 untagged4(u32x4 x) {
-  f32x4 f = {untagged(x.x), untagged(x.y), untagged(x.z), untagged(x.w)};
-  return f;
-}
-// quiet wait for ONE tagged word (every lane reads the same address: one request per round); bounded
-__device__ inline void tagged_wait_one(const float* word, unsigned par, int32_t* flag) {
-  for (unsigned spin = 0;; ++spin) {
-    const unsigned x = __hip_atomic_load(reinterpret_cast<const unsigned*>(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((x & 1u) == par) break;
-    if (spin > (1u << 17)) {
-      if (flag) atomicOr(flag, 2);
-      break;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
-// bound of a consumer's re-load loop: raises the time-out bit after ~2^16 rounds, and leaves early
-// when somebody else on the chip has (the run is lost either way)
-__device__ __forceinline__ bool tagged_give_up(unsigned spin, int32_t* flag) {
-  if (spin > (1u << 16)) { atomicOr(flag, 2); return true; }
-  return (spin & 255u) == 255u && (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2);
-}
-
 // A data-parallel rank RESIDENT across the gradient exchange (persist.h: PersistBuffers::xr_*), the
 // hand-off of one update by one workgroup whose gradients are out and acknowledged (s_waitcnt(0) +
 // barrier before the call): thread 0 counts the workgroup in, the last of the n_wg raises *ready to
