@@ -64,6 +64,7 @@ struct UArgs {
   int Nh, NhP, D, K;
   int n_blocks, k_slices, G, T, n_owner, R;
   int n_updates, xs_floats;
+  int fast_rows;                     // (A/B runs: BSIG_PERSIST_FAST_ROWS=0 keeps the shape-generic row)
   const float* feats; int64_t ld_feats; const int32_t* feat_ids;
   const float* y; int64_t ldy; const int32_t* ids;
   float* params; float* m1; float* m2; int64_t w_off, b_off;
@@ -478,6 +479,296 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
       }
     }
     if (ro.bad) atomicOr(flagp, 1);
+}
+
+
+// ---- fast row owners (round 6) -----------------------------------------------------------------
+// An owner's row used to be ONE wavefront running the shape-generic diag_row: ~1800 instruction slots at
+// one vector instruction per 4 cycles -- the row was bound by its instruction COUNT (ISA: run-time loops
+// over the sweeps, index divisions by K, ~40 LDS round trips, a reduction tree of selects, 4 300
+// v_readlane_b32 of spilled scalars in the owners' loop; profiles/r06_NOTES.md).  For a workgroup WITHOUT a
+// tile and K in {4, 8, 16} components (the lanes of a component's dimensions then sit at a stride of K
+// inside the 16-lane DPP rows, and K adjacent lanes hold the K components) the row is written again:
+//  * TWO wavefronts per row (wavefront 2r + h takes the sweeps h, h + 2, ... of row r: cfg5 one sweep
+//    each), on different SIMDs -- the workgroup has eight wavefronts and at most four rows;
+//  * the lane's elements come straight from the partial k-slice sums in LDS (no combine pass, no row
+//    image, no second barrier), its target value and jitter draws are fetched during the wait;
+//  * sums over the dimensions of a component: DPP row rotations inside the 16-lane rows, then ONE LDS
+//    exchange of 8 partial sums per component (4 DPP rows x 2 wavefronts), read back by EVERY lane;
+//    softmax, logsumexp and the logit gradients by DPP butterflies over the K adjacent lanes, computed
+//    redundantly by every lane -- no broadcast step, no second exchange;
+//  * d_out / exp(pre): the four lanes of a quad hold four adjacent columns: gathered by quad_perm, one
+//    16-byte write-through store per quad instead of five 4-byte stores per lane.
+// Same formulas, same IEEE divisions, same Philox draws per (row, lane, sweep) as diag_row_body; the
+// summation orders differ (tests: persistent == per-phase kernels / oracle at their tolerances; every
+// variant of this kernel -- resident, data-parallel, resident across the exchange -- shares this code).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// all-reduce over the K adjacent lanes of an aligned group (K = 4, 8, 16): xor 1, xor 2, mirror of 8, mirror of 16
+template <int K>
+__device__ __forceinline__ float kgroup_sum(float v) {
+  v += dpp_mov<0xB1>(v);                            // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4E>(v);                            // quad_perm:[2,3,0,1]
+  if constexpr (K >= 8) v += dpp_mov<0x141>(v);     // row_half_mirror
+  if constexpr (K >= 16) v += dpp_mov<0x140>(v);    // row_mirror
+  return v;
+}
+template <int K>
+__device__ __forceinline__ float kgroup_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  if constexpr (K >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+  if constexpr (K >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+// all-reduce over the 16 / K lanes of a DPP row that hold the same component (stride K): rotations by 8, 4
+template <int K>
+__device__ __forceinline__ float dslots_sum(float v) {
+  if constexpr (K <= 8) v += dpp_mov<0x128>(v);     // row_ror:8
+  if constexpr (K <= 4) v += dpp_mov<0x124>(v);     // row_ror:4
+  return v;
+}
+// the four values of the lane's quad
+__device__ __forceinline__ f32x4 quad_gather(float v) {
+  f32x4 q = {dpp_mov<0x00>(v), dpp_mov<0x55>(v), dpp_mov<0xAA>(v), dpp_mov<0xFF>(v)};
+  return q;
+}
+
+// Update t of the launch for the rows of this owner, every wavefront of the workgroup comes through here
+// (wavefronts 2r, 2r + 1 run row r0 + r; the others only fetch k-slices and keep the barriers).
+template <int K, int NQH>
+__device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t, int w, int lane0, int wg) {
+#pragma clang fp contract(off)
+  constexpr int GR = 64 / K;                   // dimensions per sweep
+  const int B = p.B, Nh = p.Nh, NhP = p.NhP, D = p.D, DK = D * K, R = p.R;
+  const int step = o.step0 + t;
+  const unsigned epoch = (unsigned)step + 1u;
+  const uint32_t tag = epoch * 4u;
+  const int own = o.own, r0 = o.r0;
+  float* red = o.red; float* part = o.part; float* XS = o.XS;
+  int32_t* flagp = o.flagp;
+  int lane = lane0;
+  asm volatile("" : "+v"(lane));
+  const int tid_l = 64 * w + lane;
+  const int rr = w >> 1, h = w & 1;
+  const int row = r0 + rr;
+  const bool row_wave = rr < R;                // (wavefront-uniform)
+  const bool active = row_wave && row < B;
+  const int k = lane & (K - 1), d0 = lane / K;
+  const bool jitter = p.eps_noise != 0.f;
+
+  // ---- in the wait: target values, jitter draws ----------------------------------------------------
+  float yd[NQH], eu[NQH];
+  bool valid[NQH];
+#pragma unroll
+  for (int i = 0; i < NQH; ++i) {
+    const int d = d0 + (h + 2 * i) * GR;
+    valid[i] = active && d < D;
+    yd[i] = 0.f; eu[i] = 0.f;
+  }
+  if (active) {
+    const int64_t yrow = p.ids[(int64_t)step * B + row];
+#pragma unroll
+    for (int i = 0; i < NQH; ++i)
+      if (valid[i]) yd[i] = p.y[yrow * p.ldy + d0 + (h + 2 * i) * GR];
+    if (jitter) {
+      // (diag_row_noise's draw of sweeps 0..3: counter (row * 64 + lane) * 2, output q of sweep q)
+      const uint64_t sid = o.rng_ctr0 + (uint64_t)t + (uint64_t)(p.do_eval ? u_evals_before(step, p.eval_every) - o.ev0 : 0);
+      const Philox4 ph = philox4x32_10(o.a.seed, sid, ((uint64_t)row * 64 + lane) * 2);
+#pragma unroll
+      for (int i = 0; i < NQH; ++i)
+        if (valid[i]) eu[i] = u01(h ? ph.v[2 * i + 1] : ph.v[2 * i]);
+    }
+  }
+  if (w == 0) {
+    flag_wait_one(p.flag_fwd, p.G - 1, epoch, flagp);
+    flags_wait(p.flag_fwd, p.G, epoch, lane, flagp);
+  }
+  __syncthreads();
+  BSIG_USTAMP(4);
+
+  // ---- partial sums over the k-slices -> LDS (u_rows_sum4's first half) -----------------------------
+  const int nrows = min(R, B - r0);
+  const int ncq = (Nh + 3) >> 2, Q = nrows * ncq;
+  const int SG = max(1, min(min(p.k_slices, kUT / Q), 8));
+  {
+    const __amdgpu_buffer_rsrc_t sr = xwg_buffer(p.slabs);
+    const int qc = tid_l % Q, sg = tid_l / Q;
+    if (sg < SG) {
+      const int r = qc / ncq, c4 = (qc - r * ncq) * 4;
+      const int voff = (r0 + r) * NhP + c4, zs = B * NhP;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int z0 = sg; z0 < p.k_slices; z0 += 8 * SG) {
+        f32x4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = xwg_load4(sr, voff + min(z0 + u * SG, p.k_slices - 1) * zs);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (z0 + u * SG < p.k_slices) v += q[u];
+      }
+      *reinterpret_cast<f32x4*>(part + 4 * (sg * Q + qc)) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- the lane's elements from the partial sums: pre first (its exp goes to the other owners) --------
+  // value(col) of row rr = sum over g < SG of part[4 * (g * Q + rr * ncq) + col], groups added in order
+  const float* pb = part + 4 * (active ? rr : 0) * ncq;
+  const int gs = 4 * Q;
+  auto slice_sum = [&](int col) {
+    const float* b = pb + col;
+    const float v0 = b[0], v1 = b[gs * min(1, SG - 1)], v2 = b[gs * min(2, SG - 1)], v3 = b[gs * min(3, SG - 1)];
+    float sacc = v0;
+    if (SG > 1) sacc += v1;
+    if (SG > 2) sacc += v2;
+    if (SG > 3) sacc += v3;
+    if (SG > 4) {
+      const float v4 = b[gs * 4], v5 = b[gs * min(5, SG - 1)], v6 = b[gs * min(6, SG - 1)], v7 = b[gs * min(7, SG - 1)];
+      sacc += v4;
+      if (SG > 5) sacc += v5;
+      if (SG > 6) sacc += v6;
+      if (SG > 7) sacc += v7;
+    }
+    return sacc;
+  };
+  float ev[NQH], muv[NQH], pre[NQH];
+#pragma unroll
+  for (int i = 0; i < NQH; ++i) {
+    const int e = min(lane + (h + 2 * i) * 64, DK - 1);
+    pre[i] = slice_sum(K + DK + e);
+  }
+#pragma unroll
+  for (int i = 0; i < NQH; ++i) {
+    const int e = min(lane + (h + 2 * i) * 64, DK - 1);
+    muv[i] = slice_sum(K + e);
+  }
+  const float lg_own = slice_sum(k);
+  float esum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NQH; ++i) {
+    ev[i] = valid[i] ? expf(pre[i]) : 0.f;
+    esum += ev[i];
+  }
+  esum = wave_sum_dpp(esum);
+  if (lane == 0) red[w] = esum;
+  __syncthreads();
+  if (tid_l == 0) {
+    float sx = 0.f;
+    for (int q = 0; q < 2 * R; ++q) sx += red[q];
+    granule_publish(p.gran, own, tag + 1, sx);
+  }
+  BSIG_USTAMP(5);
+  GranuleEps ge{p.gran, p.n_owner, tag + 1, lane, flagp, p.eps_noise, o.norm, {0ull, 0ull, 0ull, 0ull}};
+  float uds = 0.f, lse = 0.f;
+  bool bad = false;
+  if (row_wave) {
+    ge.issue();      // (the other owners' sums: in flight over the mixture weights)
+    // ---- mixture weights (mdnn.py:109-111), every lane its component -------------------------------
+    const float mx = kgroup_max<K>(lg_own);
+    const float e_own = expf(lg_own - mx);
+    const float s_own = e_own / kgroup_sum<K>(e_own);
+    const float c_own = fminf(fmaxf(s_own, p.min_w), 1.0f);
+    const float csum = kgroup_sum<K>(c_own);
+    const float w_own = c_own / csum;
+    const float wc = fminf(fmaxf(w_own, p.min_w), 1.0f);     // the second clamp, mdnn.py:160
+    const float lw = logf(wc);
+    const float eps = ge.get();
+    // ---- elements: sigma, z, log sigma ------------------------------------------------------------
+    float quad = 0.f, logdet = 0.f, ez[NQH], rsg[NQH];
+#pragma unroll
+    for (int i = 0; i < NQH; ++i) {
+      float sg = ev[i];
+      if (eps != 0.f) sg = __builtin_fmaf(eu[i], eps, sg);
+      else eu[i] = 0.f;
+      if (!valid[i]) sg = 1.f;
+      bad |= valid[i] && !(isfinite(muv[i]) && isfinite(sg));
+      const float z = valid[i] ? (yd[i] - muv[i]) / sg : 0.f;
+      quad += z * z;
+      logdet += logf(sg);
+      ez[i] = z; rsg[i] = sg;
+    }
+    // sums over the dimensions of each component: inside the DPP rows, then 4 rows x 2 wavefronts through LDS
+    quad = dslots_sum<K>(quad);
+    logdet = dslots_sum<K>(logdet);
+    float* xq = XS + ((active ? rr : 0) * K + k) * 8;
+    float* xl = xq + 4 * K * 8;                  // (at most 4 rows per workgroup)
+    if (active && (lane & 15) < K) { xq[4 * h + (lane >> 4)] = quad; xl[4 * h + (lane >> 4)] = logdet; }
+    lds_barrier();
+    float qs, ls;
+    {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xq), a1 = *reinterpret_cast<const f32x4*>(xq + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(xl), b1 = *reinterpret_cast<const f32x4*>(xl + 4);
+      qs = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a1[0] + a1[1]) + (a1[2] + a1[3]));
+      ls = ((b0[0] + b0[1]) + (b0[2] + b0[3])) + ((b1[0] + b1[1]) + (b1[2] + b1[3]));
+    }
+    const float logp = -0.5f * qs - ls - (float)D * kHalfLog2Pi;
+    const float lp = fminf(fmaxf(logp, -p.ll_limit), p.ll_limit);
+    const float rv = lp + lw;
+    bad |= active && !(isfinite(w_own) && isfinite(logp) && isfinite(rv));
+    // logsumexp over the components (mdnn.py:163-178)
+    const float m2 = kgroup_max<K>(rv);
+    const float se = kgroup_sum<K>(expf(rv - m2));
+    lse = m2 + logf(se);
+    const float sc = -expf(rv - lse) * p.inv_norm;
+    const float g_lp = (logp >= -p.ll_limit && logp <= p.ll_limit) ? sc : 0.f;
+    // ---- backward ----------------------------------------------------------------------------------
+    float dmu[NQH], dpre[NQH];
+#pragma unroll
+    for (int i = 0; i < NQH; ++i) {
+      const float dsg = g_lp * __builtin_fmaf(ez[i], ez[i], -1.0f) / rsg[i];
+      uds = valid[i] ? __builtin_fmaf(eu[i], dsg, uds) : uds;
+      dmu[i] = g_lp * ez[i] / rsg[i];
+      dpre[i] = dsg * ev[i];
+    }
+    const float gw = (w_own >= p.min_w && w_own <= 1.0f) ? sc / wc : 0.f;
+    const float s1 = kgroup_sum<K>(gw * w_own);
+    const float gsv = (s_own >= p.min_w && s_own <= 1.0f) ? (gw - s1) / csum : 0.f;
+    const float s2 = kgroup_sum<K>(gsv * s_own);
+    const float dlogit = s_own * (gsv - s2);
+    BSIG_USTAMP(7);
+    // ---- d_out row (without the jitter-scale term) and exp(pre), 16 bytes per quad -------------------
+    const __amdgpu_buffer_rsrc_t dr = xwg_buffer(p.d_out + (int64_t)(active ? row : 0) * NhP);
+    const __amdgpu_buffer_rsrc_t er = xwg_buffer(p.e_out + (int64_t)(active ? row : 0) * NhP);
+#pragma unroll
+    for (int i = 0; i < NQH; ++i) {
+      const f32x4 qm = quad_gather(dmu[i]), qp = quad_gather(dpre[i]), qe = quad_gather(ev[i]);
+      const int col = (lane & ~3) + (h + 2 * i) * 64;
+      if (valid[i] && (lane & 3) == 0) {
+        xwg_store4(dr, K + col, qm[0], qm[1], qm[2], qm[3]);
+        xwg_store4(dr, K + DK + col, qp[0], qp[1], qp[2], qp[3]);
+        if (jitter) xwg_store4(er, K + DK + col, qe[0], qe[1], qe[2], qe[3]);
+      }
+    }
+    {
+      const f32x4 ql = quad_gather(dlogit);
+      if (active && h == 0 && lane < K && (lane & 3) == 0) xwg_store4(dr, lane, ql[0], ql[1], ql[2], ql[3]);
+    }
+    uds = wave_sum_dpp(uds);
+    if (lane == 0) { red[32 + w] = uds; if (h == 0) red[16 + rr] = active ? lse : 0.f; }
+  } else {
+    lds_barrier();                                // (the row wavefronts' exchange of partial sums)
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid_l == 0) {
+    float sl = 0.f, su = 0.f;
+    for (int q = 0; q < R; ++q) sl += red[16 + q];
+    for (int q = 0; q < 2 * R; ++q) su += red[32 + q];
+    granule_publish(p.gran + kGranArr, own, tag + 2, su);
+    granule_publish(loss_granules(p.gran, epoch), own, tag + 3, sl);
+  }
+  BSIG_USTAMP(9);
+  if (own == 0 && w == 0) {
+    const float s = granule_gather(loss_granules(p.gran, epoch), p.n_owner, tag + 3, lane, flagp);
+    if (lane == 0) {
+      const float l = -s / (float)B;
+      p.train_loss[step] = l;
+      if (!isfinite(l)) atomicOr(flagp, 1);
+    }
+  }
+  if (bad) atomicOr(flagp, 1);
 }
 
 // The minibatch tile of update `step`, straight into the forward product's B-operand registers:
@@ -1080,7 +1371,9 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
 }
 
 // ---- a workgroup without a tile: row owner (and evaluation owner) only -------------------------
-__device__ __forceinline__ void owner_only_workgroup(const UArgs& p, float* smem, const URole& role, int NBW, bool dp) {
+// FK: components of the fast row (u_own_update_fast), 0: the shape-generic row; NQH: sweeps per wavefront
+template <int FK, int NQH>
+__device__ __forceinline__ void owner_only_loop(const UArgs& p, float* smem, const URole& role, int NBW, bool dp) {
   float* XS = smem + p.KS * kUFP + NBW * p.WP;      // (the layout of the tile workgroups)
   float* red = XS + p.xs_floats;
   const int tid = threadIdx.x, lane0 = tid & 63;
@@ -1099,7 +1392,10 @@ __device__ __forceinline__ void owner_only_workgroup(const UArgs& p, float* smem
     // round trip sits in this workgroup's wait for the forward product.)
     if (run_aborted(flagp, red, tid)) break;
     BSIG_USTAMP(0);
-    if (has_row) u_own_update(p, o, t, w, lane0, wg);
+    if (has_row) {
+      if constexpr (FK != 0) u_own_update_fast<FK, NQH>(p, o, t, w, lane0, wg);
+      else u_own_update(p, o, t, w, lane0, wg);
+    }
     if (__builtin_expect(pending_eval >= 0, 0)) {
       __syncthreads();
       if (has_erow) u_owner_eval(p, XS, red, eo, pending_eval, u_eval_stream(p, o, pending_eval, false), o.a);
@@ -1118,6 +1414,21 @@ __device__ __forceinline__ void owner_only_workgroup(const UArgs& p, float* smem
       if (has_erow) u_owner_eval(p, XS, red, eo, e, u_eval_stream(p, o, e, true), o.a);
     }
   }
+}
+// which row the owners of this launch run: workgroup-uniform, the same for every launch of a shape
+__device__ __forceinline__ int u_fast_kind(const UArgs& p) {
+  const int K = p.K;
+  if (!(K == 4 || K == 8 || K == 16) || p.fast_rows == 0) return 0;
+  const int nq = (p.D + 64 / K - 1) / (64 / K);             // sweeps of a row
+  if (p.R > 4 || nq > 4 || p.R * ((p.Nh + 3) >> 2) > kUT) return 0;
+  return nq <= 2 ? 1 : 2;                                   // sweeps per wavefront
+}
+__device__ __forceinline__ void owner_only_workgroup(const UArgs& p, float* smem, const URole& role, int NBW, bool dp) {
+  const int nqh = u_fast_kind(p);
+  if (nqh == 0) owner_only_loop<0, 0>(p, smem, role, NBW, dp);
+  else if (p.K == 4) { if (nqh == 1) owner_only_loop<4, 1>(p, smem, role, NBW, dp); else owner_only_loop<4, 2>(p, smem, role, NBW, dp); }
+  else if (p.K == 8) { if (nqh == 1) owner_only_loop<8, 1>(p, smem, role, NBW, dp); else owner_only_loop<8, 2>(p, smem, role, NBW, dp); }
+  else { if (nqh == 1) owner_only_loop<16, 1>(p, smem, role, NBW, dp); else owner_only_loop<16, 2>(p, smem, role, NBW, dp); }
 }
 
 template <bool DP, int NT, bool XR = false>
@@ -1375,6 +1686,8 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.Nh = g.Nh; p.NhP = g.NhP; p.D = s.out_dim; p.K = s.n_comp;
   p.n_blocks = g.n_blocks; p.k_slices = g.k_slices; p.G = g.G; p.T = g.T; p.n_owner = g.n_owner; p.R = g.R;
   p.n_updates = std::max(n, 0); p.xs_floats = g.xs_floats;
+  static const int fast_rows = [] { const char* e = getenv("BSIG_PERSIST_FAST_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
+  p.fast_rows = fast_rows;
   p.grads = b.grads; p.adam_pending = b.adam_pending;
   p.xr_ready = b.xr_ready; p.xr_done = b.xr_done; p.xr_base = b.xr_base;
   p.xr_count = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(b.workspace) + u_data_bytes(g) + u_sync_bytes() - 256);
