@@ -72,6 +72,7 @@ struct UArgs {
   double lr, beta1, beta2;
   float adam_eps, eps_noise, min_w, ll_limit, inv_norm;
   float* slabs; float* d_out; float* e_out; unsigned* flag_fwd; unsigned long long* gran;
+  unsigned long long* gran_rep;      // [2][8][kGranArr] replicated granules (gran_rep())
   // data-parallel ranks (one update per launch; see PersistBuffers)
   float* grads; int adam_pending; int quad_ok;
   // data-parallel rank RESIDENT across the exchange (XR instantiation; see PersistBuffers)
@@ -133,6 +134,25 @@ __device__ __forceinline__ int u_evals_before(int s, int every) { return s == 0 
     if (p.prof && threadIdx.x == 0 && t >= p.prof_t0 && t < p.prof_t0 + kUProf)  \
       p.prof[((int64_t)wg * kUProf + t - p.prof_t0) * 16 + (k)] = wall_clock64(); \
   } while (0)
+
+// ---- replicated granules (round 6) -------------------------------------------------------------------
+// A granule that EVERY consumer of the chip reads -- an owner's sum of exp(pre) (read by the row wavefronts of
+// all owners), its sum of u * dL/dsigma (read by all ~200 tile workgroups) -- sat in ONE 64-byte line: ~200
+// pollers per line and round, and the quiet stage of all of them on the SAME word (owner 0's granule, the
+// last tile's flag).  A line serves on the order of 100 accesses per us (MI355X_MICROARCH.md: a word
+// saturates at ~88 dequeues / us; the arrival-counter experiment of profiles/r06_NOTES.md): the release of the
+// tile workgroups took 0.9-1.3 us behind the last owner.  Now the producer writes EIGHT copies (lanes 0-7 of
+// its wavefront 0, one store each), a consumer reads the copy of its XCD (workgroup id mod 8: ~25 readers
+// per line), and the quiet stages wait on different words (tile workgroup i on owner i mod n_owner, owner i
+// on tile i * G / n_owner).
+// rep(arr, x): copy x of replicated array arr (0: sum exp(pre), 1: sum u dL/dsigma)
+__device__ __forceinline__ unsigned long long* gran_rep(const UArgs& p, int arr, int x) {
+  return p.gran_rep + (int64_t)(arr * 8 + x) * kGranArr;
+}
+// (all of lanes 0-7 of one wavefront come here with the same value)
+__device__ __forceinline__ void granule_publish8(const UArgs& p, int arr, int slot, uint32_t tag, float v, int lane) {
+  if (lane < 8) granule_publish(gran_rep(p, arr, lane), slot, tag, v);
+}
 
 // A row owner's sum over the k-slices: out[r * out_pitch + col] = sum_z slabs[z * zs + rowoff(r) + col]
 // for r < nrows, col < n_cols (float offsets; `slabs` workgroup-uniform), slices added in order, up
@@ -407,7 +427,7 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
     a.stream_id = rng_ctr0 + (uint64_t)t + (uint64_t)(p.do_eval ? u_evals_before(step, p.eval_every) - ev0 : 0);
     if (owner_wave) diag_row_noise(a, rg.groups, rg.k, rg.d0, row, active, lane, eu_pre);
     if (w == 0) {
-      flag_wait_one(p.flag_fwd, p.G - 1, epoch, flagp);
+      flag_wait_one(p.flag_fwd, (int)(((int64_t)own * p.G) / p.n_owner), epoch, flagp);
       flags_wait(p.flag_fwd, p.G, epoch, lane, flagp);
     }
     __syncthreads();
@@ -424,10 +444,10 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
     eacc = wave_sum_dpp(eacc);
     if (lane == 0) red[w] = eacc;
     __syncthreads();
-    if (tid_l == 0) {
+    if (tid_l < 8) {
       float sx = 0.f;
       for (int q = 0; q < kUT / 64; ++q) sx += red[q];
-      granule_publish(p.gran, own, tag + 1, sx);
+      granule_publish8(p, 0, own, tag + 1, sx, tid_l);
     }
     BSIG_USTAMP(5);
     RowOut ro;
@@ -435,7 +455,7 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
 #pragma unroll
     for (int q = 0; q < kElemsPerLane; ++q) ro.esg0[q] = 0.f;
     if (owner_wave) {
-      GranuleEps ge{p.gran, p.n_owner, tag + 1, lane, flagp, p.eps_noise, norm, {0ull, 0ull, 0ull, 0ull}};
+      GranuleEps ge{gran_rep(p, 0, wg & 7), p.n_owner, tag + 1, lane, flagp, p.eps_noise, norm, {0ull, 0ull, 0ull, 0ull}};
       diag_row_impl(a, rg, row, active, lane, tile, yv, rk, lpk, dlg, ge, ro, eu_pre);
 #ifdef BSIG_ROW_PROF
       if (p.prof && tid == 0 && t >= p.prof_t0 && t < p.prof_t0 + kUProf)
@@ -463,11 +483,11 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (tid_l == 0) {
+    if (tid_l < 8) {
       float sl = 0.f, su = 0.f;
       for (int q = 0; q < p.R; ++q) { sl += red[16 + q]; su += red[32 + q]; }
-      granule_publish(p.gran + kGranArr, own, tag + 2, su);
-      granule_publish(loss_granules(p.gran, epoch), own, tag + 3, sl);
+      granule_publish8(p, 1, own, tag + 2, su, tid_l);
+      if (tid_l == 0) granule_publish(loss_granules(p.gran, epoch), own, tag + 3, sl);
     }
     BSIG_USTAMP(9);
     if (own == 0 && w == 0) {
@@ -583,7 +603,7 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
     }
   }
   if (w == 0) {
-    flag_wait_one(p.flag_fwd, p.G - 1, epoch, flagp);
+    flag_wait_one(p.flag_fwd, (int)(((int64_t)own * p.G) / p.n_owner), epoch, flagp);
     flags_wait(p.flag_fwd, p.G, epoch, lane, flagp);
   }
   __syncthreads();
@@ -646,7 +666,7 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
     for (int g = 1; g < SG; ++g) v += *reinterpret_cast<const f32x4*>(b + gs * g);
     float es = lane < npq ? (expf(v[0]) + expf(v[1])) + (expf(v[2]) + expf(v[3])) : 0.f;
     es = wave_sum_dpp(es);
-    if (lane == 0) granule_publish(p.gran, own, tag + 1, es);
+    granule_publish8(p, 0, own, tag + 1, es, lane);
   }
   float ev[NQH], muv[NQH], pre[NQH];
 #pragma unroll
@@ -669,14 +689,14 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
     esum = wave_sum_dpp(esum);
     if (lane == 0) red[w] = esum;
     __syncthreads();
-    if (tid_l == 0) {
+    if (tid_l < 8) {
       float sx = 0.f;
       for (int q = 0; q < 2 * R; ++q) sx += red[q];
-      granule_publish(p.gran, own, tag + 1, sx);
+      granule_publish8(p, 0, own, tag + 1, sx, tid_l);
     }
   }
   BSIG_USTAMP(5);
-  GranuleEps ge{p.gran, p.n_owner, tag + 1, lane, flagp, p.eps_noise, o.norm, {0ull, 0ull, 0ull, 0ull}};
+  GranuleEps ge{gran_rep(p, 0, wg & 7), p.n_owner, tag + 1, lane, flagp, p.eps_noise, o.norm, {0ull, 0ull, 0ull, 0ull}};
   float uds = 0.f, lse = 0.f;
   bool bad = false;
   if (row_wave) {
@@ -768,12 +788,12 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
   }
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (tid_l == 0) {
+  if (tid_l < 8) {
     float sl = 0.f, su = 0.f;
     for (int q = 0; q < R; ++q) sl += red[16 + q];
     for (int q = 0; q < 2 * R; ++q) su += red[32 + q];
-    granule_publish(p.gran + kGranArr, own, tag + 2, su);
-    granule_publish(loss_granules(p.gran, epoch), own, tag + 3, sl);
+    granule_publish8(p, 1, own, tag + 2, su, tid_l);
+    if (tid_l == 0) granule_publish(loss_granules(p.gran, epoch), own, tag + 3, sl);
   }
   BSIG_USTAMP(9);
   if (own == 0 && w == 0) {
@@ -1119,8 +1139,9 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
       // jitter-scale gradient term  d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
       // is applied here, to this block's columns, while the block is loaded
       if (w == 0) {
-        granule_wait_one(p.gran + kGranArr, 0, tag + 2, flagp);
-        const float su = granule_gather(p.gran + kGranArr, p.n_owner, tag + 2, lane, flagp);
+        unsigned long long* sug = gran_rep(p, 1, wg & 7);
+        granule_wait_one(sug, slot % p.n_owner, tag + 2, flagp);
+        const float su = granule_gather(sug, p.n_owner, tag + 2, lane, flagp);
         if (lane == 0) red[62] = p.eps_noise != 0.f ? p.eps_noise / ((float)B * (float)DK) * su : 0.f;
       }
       __syncthreads();
@@ -1624,7 +1645,7 @@ static size_t u_data_bytes(const UGeom& g) {
   return round_up<size_t>((g.slab_floats + 2 * g.dout_floats + g.eval_floats) * sizeof(float), 256);
 }
 // flags, granules and (last 256 bytes) the word the tile workgroups of a resident rank count themselves in
-static size_t u_sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + 6 * kGranArr * 8 + 256; }
+static size_t u_sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + (6 + 16) * kGranArr * 8 + 256; }
 
 size_t persist_workspace_bytes(const PersistShape& s) {
   const int v = persist_variant(s);
@@ -1725,6 +1746,7 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.flag_eval = p.flag_fwd + kFlagArr;
   p.gran = reinterpret_cast<unsigned long long*>(sync + 2 * kFlagArr * sizeof(unsigned));
   p.gran_eval = p.gran + 3 * kGranArr;
+  p.gran_rep = p.gran + 6 * kGranArr;
   p.NE = g.NE; p.RE = g.RE;
   if (b.do_eval) {
     BSIG_REQUIRE(g.eval_passes > 0 && b.n_test >= 1 && b.n_test <= g.eval_passes * s.batch &&
