@@ -135,6 +135,16 @@ __device__ __forceinline__ int u_evals_before(int s, int every) { return s == 0 
       p.prof[((int64_t)wg * kUProf + t - p.prof_t0) * 16 + (k)] = wall_clock64(); \
   } while (0)
 
+// which row the owners of this launch run: workgroup-uniform, the same for every launch of a shape
+__device__ __forceinline__ int u_fast_kind(const UArgs& p) {
+  const int K = p.K;
+  if (!(K == 4 || K == 8) || p.fast_rows == 0) return 0;     // (K = 16 works too; not instantiated: compile time)
+  const int nq = (p.D + 64 / K - 1) / (64 / K);             // sweeps of a row
+  if (p.T - p.G < p.n_owner) return 0;                    // (owners that also hold a tile run the shape-generic row)
+  if (p.R > 4 || nq > 4 || p.R * ((p.Nh + 3) >> 2) > kUT) return 0;
+  return nq <= 2 ? 1 : 2;                                   // sweeps per wavefront
+}
+
 // ---- replicated granules (round 6) -------------------------------------------------------------------
 // A granule that EVERY consumer of the chip reads -- an owner's sum of exp(pre) (read by the row wavefronts of
 // all owners), its sum of u * dL/dsigma (read by all ~200 tile workgroups) -- sat in ONE 64-byte line: ~200
@@ -558,6 +568,12 @@ __device__ __forceinline__ f32x4 quad_gather(float v) {
 
 // Update t of the launch for the rows of this owner, every wavefront of the workgroup comes through here
 // (wavefronts 2r, 2r + 1 run row r0 + r; the others only fetch k-slices and keep the barriers).
+#ifdef BSIG_ROW_PROF
+#define BSIG_FSTAMP(i) do { if (p.prof && threadIdx.x == 0 && t >= p.prof_t0 && t < p.prof_t0 + kUProf) \
+    p.prof[(int64_t)256 * kUProf * 16 + ((int64_t)wg * kUProf + t - p.prof_t0) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define BSIG_FSTAMP(i)
+#endif
 template <int K, int NQH>
 __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t, int w, int lane0, int wg) {
 #pragma clang fp contract(off)
@@ -631,7 +647,9 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
       *reinterpret_cast<f32x4*>(part + 4 * (sg * Q + qc)) = v;
     }
   }
+  BSIG_FSTAMP(0);
   __syncthreads();
+  BSIG_FSTAMP(1);
 
   // ---- the lane's elements from the partial sums: pre first (its exp goes to the other owners) --------
   // value(col) of row rr = sum over g < SG of part[4 * (g * Q + rr * ncq) + col], groups added in order
@@ -654,12 +672,12 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
     return sacc;
   };
   // The workgroup's sum of exp(pre) is what the OTHER owners wait for: when the pre-activation quads of
-  // its rows fit one wavefront (cfg5: 2 rows x 32 quads) wavefront 0 adds their partial sums itself
+  // its rows fit one wavefront (cfg5: 2 rows x 32 quads) ONE wavefront adds their partial sums itself
   // (16-byte LDS reads), takes the exponentials and publishes the granule -- no second barrier, no
   // exchange of wavefront sums between the k-slice sums and the granule.
   const int pq = DK >> 2, npq = nrows * pq;
   const bool one_wave_exp = npq <= 64;
-  if (one_wave_exp && w == 0) {
+  if (one_wave_exp && w == kUT / 64 - 1) {      // (the last wavefront: no row of its own unless the workgroup has four)
     const int r = lane / pq, c4 = K + DK + 4 * (lane - r * pq);
     const float* b = part + 4 * min(r, nrows - 1) * ncq + c4;
     f32x4 v = *reinterpret_cast<const f32x4*>(b);
@@ -682,6 +700,17 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
   const float lg_own = slice_sum(k);
 #pragma unroll
   for (int i = 0; i < NQH; ++i) ev[i] = valid[i] ? expf(pre[i]) : 0.f;
+  if (jitter && row_wave) {
+    // exp(pre) of the row for the tile workgroups (they add the jitter-scale gradient term): known now,
+    // stored now -- in the wait for the other owners' sums, not behind the backward pass
+    const __amdgpu_buffer_rsrc_t er = xwg_buffer(p.e_out + (int64_t)(active ? row : 0) * NhP);
+#pragma unroll
+    for (int i = 0; i < NQH; ++i) {
+      const f32x4 qe = quad_gather(ev[i]);
+      if (valid[i] && (lane & 3) == 0)
+        xwg_store4(er, K + DK + (lane & ~3) + (h + 2 * i) * 64, qe[0], qe[1], qe[2], qe[3]);
+    }
+  }
   if (!one_wave_exp) {
     float esum = 0.f;
 #pragma unroll
@@ -710,7 +739,9 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
     const float w_own = c_own / csum;
     const float wc = fminf(fmaxf(w_own, p.min_w), 1.0f);     // the second clamp, mdnn.py:160
     const float lw = logf(wc);
+  BSIG_FSTAMP(2);
     const float eps = ge.get();
+  BSIG_FSTAMP(3);
     // ---- elements: sigma, z, log sigma ------------------------------------------------------------
     float quad = 0.f, logdet = 0.f, ez[NQH], rsg[NQH];
 #pragma unroll
@@ -731,7 +762,9 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
     float* xq = XS + ((active ? rr : 0) * K + k) * 8;
     float* xl = xq + 4 * K * 8;                  // (at most 4 rows per workgroup)
     if (active && (lane & 15) < K) { xq[4 * h + (lane >> 4)] = quad; xl[4 * h + (lane >> 4)] = logdet; }
+    BSIG_FSTAMP(4);
     lds_barrier();
+    BSIG_FSTAMP(5);
     float qs, ls;
     {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(xq), a1 = *reinterpret_cast<const f32x4*>(xq + 4);
@@ -763,41 +796,39 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
     const float gsv = (s_own >= p.min_w && s_own <= 1.0f) ? (gw - s1) / csum : 0.f;
     const float s2 = kgroup_sum<K>(gsv * s_own);
     const float dlogit = s_own * (gsv - s2);
+  BSIG_FSTAMP(6);
     BSIG_USTAMP(7);
     // ---- d_out row (without the jitter-scale term) and exp(pre), 16 bytes per quad -------------------
     const __amdgpu_buffer_rsrc_t dr = xwg_buffer(p.d_out + (int64_t)(active ? row : 0) * NhP);
-    const __amdgpu_buffer_rsrc_t er = xwg_buffer(p.e_out + (int64_t)(active ? row : 0) * NhP);
 #pragma unroll
     for (int i = 0; i < NQH; ++i) {
-      const f32x4 qm = quad_gather(dmu[i]), qp = quad_gather(dpre[i]), qe = quad_gather(ev[i]);
+      const f32x4 qm = quad_gather(dmu[i]), qp = quad_gather(dpre[i]);
       const int col = (lane & ~3) + (h + 2 * i) * 64;
       if (valid[i] && (lane & 3) == 0) {
         xwg_store4(dr, K + col, qm[0], qm[1], qm[2], qm[3]);
         xwg_store4(dr, K + DK + col, qp[0], qp[1], qp[2], qp[3]);
-        if (jitter) xwg_store4(er, K + DK + col, qe[0], qe[1], qe[2], qe[3]);
       }
     }
     {
       const f32x4 ql = quad_gather(dlogit);
       if (active && h == 0 && lane < K && (lane & 3) == 0) xwg_store4(dr, lane, ql[0], ql[1], ql[2], ql[3]);
     }
+    // Every row wavefront publishes for itself: its stores acknowledged, then ITS sum of u * dL/dsigma
+    // (slot own * 2R + wavefront; the tile workgroups add the granules of all row wavefronts in slot
+    // order) and, from the first wavefront of a row, the row's logsumexp -- no workgroup barrier and
+    // no LDS exchange between the last store and the granules the tile workgroups wait for.
     uds = wave_sum_dpp(uds);
-    if (lane == 0) { red[32 + w] = uds; if (h == 0) red[16 + rr] = active ? lse : 0.f; }
+    BSIG_FSTAMP(7);
+    __builtin_amdgcn_s_waitcnt(0);
+    BSIG_FSTAMP(8);
+    granule_publish8(p, 1, own * 2 * R + w, tag + 2, uds, lane);
+    if (h == 0 && lane == 0) granule_publish(loss_granules(p.gran, epoch), own * R + rr, tag + 3, active ? lse : 0.f);
   } else {
     lds_barrier();                                // (the row wavefronts' exchange of partial sums)
   }
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (tid_l < 8) {
-    float sl = 0.f, su = 0.f;
-    for (int q = 0; q < R; ++q) sl += red[16 + q];
-    for (int q = 0; q < 2 * R; ++q) su += red[32 + q];
-    granule_publish8(p, 1, own, tag + 2, su, tid_l);
-    if (tid_l == 0) granule_publish(loss_granules(p.gran, epoch), own, tag + 3, sl);
-  }
   BSIG_USTAMP(9);
   if (own == 0 && w == 0) {
-    const float s = granule_gather(loss_granules(p.gran, epoch), p.n_owner, tag + 3, lane, flagp);
+    const float s = granule_gather(loss_granules(p.gran, epoch), p.n_owner * R, tag + 3, lane, flagp);
     if (lane == 0) {
       const float l = -s / (float)B;
       p.train_loss[step] = l;
@@ -1139,9 +1170,11 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
       // jitter-scale gradient term  d pre += (EPS/(B*D*K)) * sum(u*dL/dsigma) * exp(pre)
       // is applied here, to this block's columns, while the block is loaded
       if (w == 0) {
+        // (fast row owners publish one granule per row wavefront, the shape-generic ones one per owner)
         unsigned long long* sug = gran_rep(p, 1, wg & 7);
-        granule_wait_one(sug, slot % p.n_owner, tag + 2, flagp);
-        const float su = granule_gather(sug, p.n_owner, tag + 2, lane, flagp);
+        const int n_su = (p.T - p.G >= p.n_owner && u_fast_kind(p) != 0) ? p.n_owner * 2 * p.R : p.n_owner;
+        granule_wait_one(sug, slot % n_su, tag + 2, flagp);
+        const float su = granule_gather(sug, n_su, tag + 2, lane, flagp);
         if (lane == 0) red[62] = p.eps_noise != 0.f ? p.eps_noise / ((float)B * (float)DK) * su : 0.f;
       }
       __syncthreads();
@@ -1451,14 +1484,6 @@ __device__ __forceinline__ void owner_only_loop(const UArgs& p, float* smem, con
       if (has_erow) u_owner_eval(p, XS, red, eo, e, u_eval_stream(p, o, e, true), o.a);
     }
   }
-}
-// which row the owners of this launch run: workgroup-uniform, the same for every launch of a shape
-__device__ __forceinline__ int u_fast_kind(const UArgs& p) {
-  const int K = p.K;
-  if (!(K == 4 || K == 8) || p.fast_rows == 0) return 0;     // (K = 16 works too; not instantiated: compile time)
-  const int nq = (p.D + 64 / K - 1) / (64 / K);             // sweeps of a row
-  if (p.R > 4 || nq > 4 || p.R * ((p.Nh + 3) >> 2) > kUT) return 0;
-  return nq <= 2 ? 1 : 2;                                   // sweeps per wavefront
 }
 __device__ __forceinline__ void owner_only_workgroup(const UArgs& p, float* smem, const URole& role, int NBW, bool dp) {
   const int nqh = u_fast_kind(p);

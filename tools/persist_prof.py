@@ -104,7 +104,19 @@ for u in range(2, 7):
 for label, _, _, _ in rows:
     print('    %-52s %6.2f' % (label, np.mean(acc[label])))
 
-if rowst.any():      # a BSIG_ROW_PROF build: stamps inside diag_row (wave 0 of the first row owner)
+if os.environ.get('FAST_ROW_STAMPS') == '1' and rowst.any():
+    g = owners[0]
+    names = ['(stamp 4 ->) k-slice loads back, partials in LDS', 'barrier', 'row image read, exp published, mixture weights',
+             'eps get', 'sigma, z, log, DPP sums, LDS write', 'barrier (partial sums of the two wavefronts)',
+             'logp, logsumexp, backward', 'quad stores, uds', 'drain (vmcnt 0)']
+    print('inside the fast row (wg %d, wavefront 0):' % g)
+    prev = st[g, 1:8, 4]
+    for i, n in enumerate(names):
+        cur = rowst[g, 1:8, i]
+        print('    %-52s %6.2f us' % (n, (cur - prev).mean()))
+        prev = cur
+    print('    %-52s %6.2f us' % ('barrier + publish (-> stamp 9)', (st[g, 1:8, 9] - prev).mean()))
+elif rowst.any():      # a BSIG_ROW_PROF build: stamps inside diag_row (wave 0 of the first row owner)
     g = owners[0]
     names = ['LDS reads issued', 'exp(pre), y - mu, noise', 'mixture weights', 'eps get (gather)', 'sigma, z, log',
              'sums over d (LDS)', 'logsumexp', 'backward']
