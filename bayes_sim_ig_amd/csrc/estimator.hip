@@ -222,7 +222,7 @@ static int forward_pass(const bsig_mdn_cfg* c, const Layout& L, const float* par
   g.c = o; g.ldc = ldo;
   g.m = (int)B; g.n = (int)L.nh; g.k = (int)L.feat_dim;
   g.epilogue = BSIG_EPI_BIAS; g.bias = params + L.head_b_off;
-  if (o == s.o) g.combine_tickets = s.tickets;   // (the scratch buffer has the padded pitch the combine stores)
+  if (o == s.o) { g.combine_tickets = s.tickets; g.combine_capacity = kWideTickets; }   // (the scratch buffer has the padded pitch the combine stores)
   if (n_sig && c->head.eps_noise != 0.f) {   // sum(exp(pre_diag)) partials for the jitter scale
     g.expsum = s.head_ws;
     g.expsum_col0 = c->head.n_comp + c->head.out_dim * c->head.n_comp;

@@ -22,6 +22,7 @@ struct GemmParams {
   // launch instead of in gemm_reduce_kernel.  >= ceil(m / 64) zeroed int32 (left zeroed); c must
   // have a pitch of at least ceil16(n) floats (every column of the padded width is stored).
   int32_t* combine_tickets = nullptr;
+  int combine_capacity = 0;            // words behind combine_tickets: the combine needs ceil(m / 64) of them
   // Row offsets resolved on the device (graph replay): logical row i of the
   // gathered / offset operand reads source index i + (dyn[0]+dyn_delta)*stride + base
   // (A: its M rows, or its contraction rows when k-major; same for B).

@@ -383,7 +383,11 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
         wp.x = p.a; wp.ldx = p.lda; wp.ids = p.a_rows; wp.n_narrow = p.m;
         wp.dyn_stride = p.a_dyn_stride; wp.dyn_base = p.a_dyn_base;
         wp.out = reinterpret_cast<float*>(workspace); wp.ld_out = wide;
-        const bool combine = p.combine_tickets && p.epilogue == BSIG_EPI_BIAS && p.ldc >= wide &&
+        // (one ticket per 64-row tile: a product of more row tiles than the caller's ticket words -- a head
+        // whose width is already a multiple of 16 keeps ldc == wide at ANY row count -- must not combine
+        // in the launch: the tickets beyond the buffer are somebody else's memory)
+        const bool combine = p.combine_tickets && ceil_div(p.m, 64) <= p.combine_capacity &&
+                             p.epilogue == BSIG_EPI_BIAS && p.ldc >= wide &&
                              (p.ldc & 3) == 0 && aligned(p.c, 16) && wp.slab < ((int64_t)1 << 31) &&
                              env_int("BSIG_GEMM_NO_COMBINE", 0) == 0;
         if (combine) {

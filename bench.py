@@ -111,12 +111,12 @@ def build_oracle(cfg, in_dim, seed, eps_noise, freqs=None):
     return oest.OracleMDNN(hidden_layers=cfg['hidden'], **kw)
 
 
-def cpu_baseline(cfg, theta, states, actions, budget_s=12.0, max_chunks=12):
-    """The oracle ("port" of the reference's PyTorch-CPU path) on a bounded
-    sample of the same pairs, same chunk protocol.  The thread count is
-    calibrated first (the update is ~2000 tiny ATen ops: more threads than a
-    handful only add synchronisation cost) and the best one is used and
-    reported as `cores`."""
+def cpu_baseline(cfg, theta, states, actions, budget_s=14.0, max_chunks=12):
+    """The oracle ("port" of the reference's PyTorch-CPU path) on a bounded sample of the same pairs,
+    same chunk protocol.  Two rates are reported: at a FIXED 16 threads (`value_16_threads`: comparable
+    from box to box -- round 5's calibrated figure swung 836 ... 1651 pairs/s with the host) and at the
+    best of 8 / 16 / 32 threads, calibrated on 20 updates each (`value`, `cores`; the update is ~2000
+    tiny ATen ops: beyond a handful of threads more of them only add synchronisation cost)."""
     from oracle import summarize as osum
     ncpu = os.cpu_count() or 1
     fn = osum.SUMMARIZERS[cfg['summarizer']]
@@ -124,47 +124,51 @@ def cpu_baseline(cfg, theta, states, actions, budget_s=12.0, max_chunks=12):
     th, st, ac = theta.cpu(), states.cpu(), actions.cpu()
     m0 = min(1000, th.shape[0])
     summ0 = fn(st[:m0], ac[:m0])
-    best_nt, best_dt = 1, float('inf')
-    for nt in (1, 2, 4, 8, 16, 32):
-        if nt > ncpu:
-            break
+    fixed = min(16, ncpu)
+    cand = sorted({min(c, ncpu) for c in (8, 16, 32)})
+    calib = {}
+    for nt in cand:
         torch.set_num_threads(nt)
         model = build_oracle(cfg, in_dim, 1234, 1e-5)
         model.run_training(summ0, th[:m0], 2, 100)            # warm
         t0 = time.perf_counter()
-        model.run_training(summ0, th[:m0], 8, 100)
-        dt = time.perf_counter() - t0
-        if dt < best_dt:
-            best_nt, best_dt = nt, dt
-        elif dt > 1.5 * best_dt:
-            break
-    torch.set_num_threads(best_nt)
-    model = build_oracle(cfg, in_dim, 1234, 1e-5)
-    # two passes over consecutive halves of the sample; the faster one is reported (a shared
-    # host can lose a factor of two for seconds at a time)
-    done, n, passes = 0, th.shape[0], []
-    for half in range(2):
-        p_done, chunks = 0, 0
+        model.run_training(summ0, th[:m0], 20, 100)
+        calib[nt] = time.perf_counter() - t0
+    best_nt = min(calib, key=calib.get)
+
+    def one_pass(nt, first, n_chunks, budget):
+        torch.set_num_threads(nt)
+        model = build_oracle(cfg, in_dim, 1234, 1e-5)
+        done, chunks = first, 0
         t0 = time.perf_counter()
-        while done < n and chunks < max_chunks // 2:
-            m = min(1000, n - done)
+        while done < th.shape[0] and chunks < n_chunks:
+            m = min(1000, th.shape[0] - done)
             summ = fn(st[done:done + m], ac[done:done + m])
             model.run_training(summ, th[done:done + m], 100, 100)
             done += m
-            p_done += m
             chunks += 1
-            if time.perf_counter() - t0 > budget_s / 2:
+            if time.perf_counter() - t0 > budget:
                 break
-        if p_done:
-            passes.append((p_done / (time.perf_counter() - t0), p_done, chunks,
-                           time.perf_counter() - t0))
-    rate, p_done, chunks, dt = max(passes)
-    return {'value': rate, 'unit': 'pairs/s', 'cores': best_nt, 'kind': 'port',
-            'sample': '%d pairs (%d chunks of the same synthetic workload, reference chunk '
-                      'protocol) in %.1f s, the faster of two such passes (%s pairs/s); torch %s '
-                      'CPU, %d threads (best of 1..32 by calibration; host has %d logical CPUs)'
-                      % (p_done, chunks, dt, ' / '.join('%.0f' % q[0] for q in passes),
-                         torch.__version__, best_nt, ncpu)}
+        dt = time.perf_counter() - t0
+        return (done - first) / dt, done - first, chunks, dt, done
+
+    # a pass at the fixed thread count, then one at the calibrated best (a second fixed pass when they
+    # coincide: the faster one counts -- a shared host can lose a factor of two for seconds at a time)
+    r_fix = one_pass(fixed, 0, max_chunks // 2, budget_s / 2)
+    r_best = one_pass(best_nt, r_fix[4], max_chunks // 2, budget_s / 2)
+    rate_fixed = max(r_fix[0], r_best[0]) if best_nt == fixed else r_fix[0]
+    rate_best = max(r_fix[0], r_best[0]) if best_nt == fixed else max(r_best[0], 0.0)
+    if best_nt != fixed and r_fix[0] > rate_best:          # (calibration noise: the fixed count won after all)
+        rate_best, best_nt = r_fix[0], fixed
+    return {'value': rate_best, 'unit': 'pairs/s', 'cores': best_nt, 'kind': 'port',
+            'value_16_threads': rate_fixed, 'threads_fixed': fixed,
+            'calibration_s_per_20_updates': {str(k): round(v, 4) for k, v in calib.items()},
+            'sample': '%d + %d pairs (%d + %d chunks of the same synthetic workload, reference chunk protocol) '
+                      'in %.1f + %.1f s: one pass at a fixed %d threads (%.0f pairs/s), one at the best of '
+                      '%s threads by a 20-update calibration (%d threads, %.0f pairs/s); torch %s CPU; host '
+                      'has %d logical CPUs'
+                      % (r_fix[1], r_best[1], r_fix[2], r_best[2], r_fix[3], r_best[3], fixed, r_fix[0],
+                         '/'.join(str(c) for c in cand), best_nt, r_best[0], torch.__version__, ncpu)}
 
 
 def nll_check(pkg, cfg, theta, states, actions, device, lazy=True, n_updates=100):
@@ -319,16 +323,15 @@ def _is_ancestor(sha):
         return None
 
 
-def pmc_traffic(kernel_substr):
-    """Per-launch HBM traffic of a kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_FETCH_SIZE.txt / *_pmc_WRITE_SIZE.txt, latest round):
-    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.  A profile carries the
-    commit it was taken on; one whose commit is not an ancestor of HEAD (a profile of other code)
-    is refused, one that cannot be checked (no git history on the box) is named as unverified."""
+def pmc_counters(kernel_substr, names):
+    """Per-launch values of rocprofv3 PMC counters of a kernel from the committed passes
+    (profiles/*_pmc_<COUNTER>.txt, latest round first).  A profile carries the commit it was taken
+    on and a hash of the kernel sources ("# csrc:", tools/csrc_hash.py): one whose commit is not an
+    ancestor of HEAD, or whose source hash is not this tree's, is a profile of OTHER code and is
+    refused.  Returns ({counter: value}, note) or (None, reason)."""
     import glob
     out = {}
-    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for ctr in names:
         # latest round first; a round commits one file per profiled config
         for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_%s.txt' % ctr)),
                            reverse=True):
@@ -342,21 +345,21 @@ def pmc_traffic(kernel_substr):
                 break
         else:
             return None, None
-    heads = {out['head_FETCH_SIZE'], out['head_WRITE_SIZE']}
+    heads = {out['head_' + ctr] for ctr in names}
     note = ''
     for h in heads:
         if h is None:
-            return None, 'refused: %s carries no commit stamp (a profile of an earlier round)' % out['src_FETCH_SIZE']
+            return None, 'refused: %s carries no commit stamp (a profile of an earlier round)' % out['src_' + names[0]]
         ok = _is_ancestor(h)
         if ok is False:
-            return None, 'refused: %s was taken on %s, not an ancestor of HEAD' % (out['src_FETCH_SIZE'], h)
+            return None, 'refused: %s was taken on %s, not an ancestor of HEAD' % (out['src_' + names[0]], h)
         note = ' (taken on %s%s)' % (h, '' if ok else ', ancestry not checkable here')
     # an ancestor is not the same code: the profile must be OF these kernel sources -- by content
     # hash where the profile carries one ("# csrc:", tools/csrc_hash.py; works without git), else
     # by asking git whether csrc changed after the profile's commit
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     from csrc_hash import csrc_hash
-    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for ctr in names:
         path = os.path.join(ROOT, 'profiles', out['src_' + ctr])
         stamp = _profile_csrc(path)
         if stamp is not None:
@@ -370,8 +373,26 @@ def pmc_traffic(kernel_substr):
                     out['src_' + ctr], out['head_' + ctr])
             if changed is None:
                 note += ' (UNVERIFIED: no source hash in the profile and no git history here)'
-    return (2.0 * out['FETCH_SIZE'] + out['WRITE_SIZE']) * 1024.0, \
-        '%s, %s%s' % (out['src_FETCH_SIZE'], out['src_WRITE_SIZE'], note)
+    return {c: out[c] for c in names}, '%s%s' % (', '.join(out['src_' + c] for c in names), note)
+
+
+def pmc_traffic(kernel_substr):
+    """Per-launch HBM traffic of a kernel: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950."""
+    vals, note = pmc_counters(kernel_substr, ('FETCH_SIZE', 'WRITE_SIZE'))
+    if vals is None:
+        return None, note
+    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, note
+
+
+def pmc_mfma_busy(kernel_substr):
+    """Fraction of the launch during which the matrix pipes were busy: SQ_VALU_MFMA_BUSY_CYCLES (summed
+    over the chip's 1024 SIMDs) / (1024 x shader cycles of the launch), the shader cycles being
+    GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8."""
+    vals, note = pmc_counters(kernel_substr, ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'))
+    if vals is None or not vals['GRBM_GUI_ACTIVE']:
+        return None, note
+    return vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * vals['GRBM_GUI_ACTIVE'] / 8.0), note
 
 
 def _event_time(fn, reps, warm=5):
@@ -489,6 +510,8 @@ def time_update_kernel(pkg, cfg, bsim, device):
         flops += 2.0 * f_in * nh * n_test * n_evals   # forward products of the evaluations
     ach = flops / (us * 1e-6) / 1e12
     traffic, tsrc = pmc_traffic('linear_head_updates_kernel') if not dp else (None, None)
+    busy, bsrc = pmc_mfma_busy('linear_head_updates_kernel') if not dp else (None, None)
+    alg_bytes = 4.0 * (f_in + cfg['d']) * (batch * float(n_updates) / len(runs) + (0 if dp else n_test * n_evals))
     geo = (C.c_int32 * 16)()
     tiling = None
     if lib.bsig_debug_persist_geometry(batch, f_in, cfg['d'], cfg['k'], n_test, geo) and geo[13] == 2:
@@ -506,7 +529,12 @@ def time_update_kernel(pkg, cfg, bsim, device):
                          'the previous update taken from the reduced gradients while the weight '
                          'tiles are loaded)' if dp else ''),
             'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
-            'traffic': traffic, 'traffic_source': tsrc, 'avg_us': us,
+            'traffic': traffic, 'traffic_source': tsrc,
+            # HBM bytes the launch needs by SURVEY.md 8(d) K6+K7: 4 (F_in + D) bytes per row visit read,
+            # no dh write (the features are leaves); traffic / this = re-read / hand-off factor
+            'algorithmic_bytes': alg_bytes,
+            'traffic_over_algorithmic': (traffic / alg_bytes) if traffic else None,
+            'mfma_busy': busy, 'mfma_busy_source': bsrc, 'avg_us': us,
             'us_per_update': us * len(runs) / n_updates,
             'us_per_update_with_exchange': loop_us,
             'exchange_in_hip_graph': DP_LOOP_US.get('graph'),
@@ -516,7 +544,7 @@ def time_update_kernel(pkg, cfg, bsim, device):
                                            % (n_test, n_evals), flops),
             'note': 'latency-bound by design of the reference protocol (minibatch 100): each update '
                     'is a chain of 4 cross-workgroup hand-offs (~1 us each) and the row owners\' work '
-                    '(k-slice sums + one wavefront per row: ~7 us) around ~7 us of fp32-MFMA work per '
+                    '(k-slice sums + two wavefronts per row: ~5 us) around ~7 us of fp32-MFMA work per '
                     'tile CU (16x16x4, head matrix tiled over 198 CUs); see DESIGN.md and '
                     'scaled_batch_mode for the MFMA-bound regime'}
 
@@ -551,7 +579,8 @@ def mdnn_update_roofline(cfg, m, us, runs, n_updates, batch, nh, dp=False, n_eva
                          ' (data-parallel rank: gradients written for the all-reduce, Adam step of '
                          'the previous update taken from the reduced gradients)' if dp else ''),
             'achieved': ach, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_TFLOPS,
-            'traffic': traffic, 'traffic_source': tsrc, 'avg_us': us,
+            'traffic': traffic, 'traffic_source': tsrc,
+            'mfma_busy': (pmc_mfma_busy(kname)[0] if not dp else None), 'avg_us': us,
             'us_per_update': us * len(runs) / n_updates,
             'algorithmic': '2*(2*I*128) + 3*(2*128*128) + 3*(2*128*Nh) = %.3e flop per row visit x %d '
                            'rows x %.1f updates = %.3e flop per launch'
@@ -808,7 +837,11 @@ def per_config_numbers(pkg, device, skip):
             continue
         cfg = dict(CONFIGS[name])
         wide = name in ('anymal_yaml', 'shadow_more')
-        n = 4_000 if wide else 10_000
+        # BASELINE.json's own sizes (cfg2 10 k, cfg3 50 k, cfg4 / cfg4b 100 k pairs; cfg5's 100 k when another
+        # config is the headline); the two reference YAMLs with a streamed first layer are not BASELINE
+        # configs: 4 000 pairs
+        n = 4_000 if wide else {'cfg2': 10_000, 'cfg3': 50_000, 'cfg4': 100_000, 'cfg4b': 100_000,
+                                'cfg5': 100_000}[name]
         theta, states, actions = synth_pairs(cfg, n, 1234, device)
         bs = build_gpu_model(pkg, cfg, device, 1234)
         np.random.seed(1234)
@@ -825,7 +858,16 @@ def per_config_numbers(pkg, device, skip):
                                                                bs.model.input_dim, n),
                      'pairs_per_s': n / dt, 'us_per_update': roof.get('us_per_update'),
                      'mfma_frac': roof.get('frac'), 'kernel': roof['kernel'].split(':')[0],
-                     'nll_rel_diff': nll['rel_diff'], 'nll_protocol': nll['protocol']}
+                     'nll_rel_diff': nll['rel_diff'], 'nll_protocol': nll['protocol'],
+                     # what the number is held against (north star: 1e-4 relative)
+                     'nll_criterion': ('direct: |hip - fp32 oracle| / |oracle| of the first chunk of THIS seed '
+                                       '(north star 1e-4).  cfg3 only: its 11802-term fp32 first-layer sums make two '
+                                       'fp32 evaluation orders of the SAME chunk differ by more than 1e-4 on some '
+                                       'seeds (the reference does not reproduce itself, SURVEY.md 0.10), so the '
+                                       '-m gpu tests assert it on six seeds through the fp64 bracket |hip - f64| <= '
+                                       '|cpu_f32 - f64| + 1e-4 |f64| and directly at 1e-4 only where the fp32 oracle '
+                                       'is itself within 0.5e-4 of fp64 -- a relaxation of the north star, named here')
+                     if name == 'cfg3' else 'direct: |hip - fp32 oracle| / |oracle| of the first chunk <= 1e-4'}
         if wide:
             # both protocols side by side: 20 updates (inside the fp32 horizon of these ill-conditioned
             # first layers) and the reference's 100 (where the oracle's own fp32 evaluation orders have
@@ -1058,6 +1100,7 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(cfg, theta[:12000], states[:12000],
                                                    actions[:12000])
                 out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+                out['speedup_vs_cpu_16_threads'] = value / out['cpu_baseline']['value_16_threads']
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

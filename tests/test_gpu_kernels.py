@@ -571,3 +571,41 @@ def test_fp32_mfma_is_a_chain_of_fmas_in_ascending_k(B, k, scale):
     B._lib.check(lib.bsig_debug_mfma_vs_fma(a.data_ptr(), b.data_ptr(), k, bad.data_ptr(), B._lib.stream()))
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
+
+
+def test_forward_of_more_row_tiles_than_combine_tickets(B):
+    """A head whose width is already a multiple of 16 (K = 16, D = 8 diagonal: Nh = 272) keeps the padded
+    output pitch at ANY row count, so a forward() of more than 64 * 1024 rows used to pass the in-launch
+    K-slice combine 1094 row tiles for 1024 ticket words (round-5 advisor finding): tickets and the
+    exp-sum partials behind them aliased.  The combine now needs ceil(m / 64) <= its ticket capacity;
+    the rows of a 70 000-row forward() must equal the same rows pushed through in two halves."""
+    torch.manual_seed(3)
+    np.random.seed(3)
+    d, k = 8, 16
+    m = B.MDRFF(input_dim=120, output_dim=d, output_lows=np.zeros(d), output_highs=np.ones(d),
+                n_gaussians=k, lr=1e-3, activation=torch.nn.Tanh, full_covariance=False,
+                n_feat=64, sigma=4.0, device=DEV)
+    assert m.pi.weight.shape[0] + m.mu.weight.shape[0] + getattr(m, 'Diag')[0].weight.shape[0] == 272
+    n = 70000
+    x = torch.randn(n, 120, generator=torch.Generator().manual_seed(4)).to(DEV)
+    old = B.MDNN.EPS_NOISE
+    B.MDNN.EPS_NOISE = 1e-5          # the jitter scale comes from the exp-sum partials the tickets aliased
+    try:
+        torch.manual_seed(9)
+        whole = [t.clone() for t in m.forward(x)[:3]]
+        halves = []
+        for lo, hi in ((0, 35000), (35000, n)):
+            torch.manual_seed(9)
+            halves.append([t.clone() for t in m.forward(x[lo:hi])[:3]])
+    finally:
+        B.MDNN.EPS_NOISE = old
+    for i, name in enumerate(('weights', 'mu')):
+        got = whole[i].cpu().numpy()
+        exp = np.concatenate([h[i].cpu().numpy() for h in halves])
+        np.testing.assert_allclose(got, exp, rtol=2e-6, atol=2e-7, err_msg=name)
+    # L_d carries the jitter u * 1e-5 * mean(exp(pre)) of ITS batch (different draws per call): compare
+    # its batch mean, which a wrong jitter scale (aliased partials) moves by orders of magnitude more
+    got = whole[2].cpu().numpy().mean()
+    exp = np.concatenate([h[2].cpu().numpy() for h in halves]).mean()
+    assert abs(got - exp) <= 1e-4 * abs(exp)
+    assert np.isfinite(whole[2].cpu().numpy()).all()
