@@ -30,12 +30,14 @@ _MODELS = {'MDNN': MDNN, 'MDRFF': MDRFF}
 
 
 class BayesSim(object):
-    NUM_TRAIN_TRAJ_PER_BATCH = 1000  # num trajs for each training batch
+    # The reference's protocol constants (bayes_sim.py:20-25), same names and values -- the chunk size a
+    # run_training call consumes, how often a chunk is swept, the SGD minibatch, the held-out share:
+    NUM_TRAIN_TRAJ_PER_BATCH = 1000  # (theta, trajectory) pairs per run_training call ("chunk")
+    NUM_TRAIN_EPOCHS = 10            # sweeps over a chunk
+    MINIBATCH_SIZE = 100             # rows per Adam update
+    NUM_GRAD_UPDATES = NUM_TRAIN_EPOCHS * NUM_TRAIN_TRAJ_PER_BATCH // MINIBATCH_SIZE   # = 100 updates per chunk
+    TEST_FRACTION = 0.2              # last 20 % of a chunk: held out (mdnn.py:206-211)
     FIT_BLOCK_CHUNKS = 32            # (not in the reference) chunks summarised / projected at once by fit()
-    NUM_TRAIN_EPOCHS = 10            # num times to go over the batch
-    MINIBATCH_SIZE = 100             # minibatch size for NN training
-    NUM_GRAD_UPDATES = NUM_TRAIN_EPOCHS * NUM_TRAIN_TRAJ_PER_BATCH // MINIBATCH_SIZE
-    TEST_FRACTION = 0.2              # fraction of dataset to use as test
     # the multi-trajectory refit of predict(): literals in the reference (bayes_sim.py:162,173-174)
     REFIT_SAMPLES = int(1e4)         # samples drawn from the per-trajectory MoGs
     REFIT_MINIBATCH = 100
@@ -197,39 +199,44 @@ class BayesSim(object):
         return logs
 
     def predict(self, states, actions, threshold=0.005):
-        """Posterior for the given real trajectories (reference
-        bayes_sim.py:116-179): the model's MoG for one trajectory; for several,
-        10^4 samples from their MoGs refitted by a fresh unconditional MDNN."""
-        xs = self._summarize(states, actions)
-        mogs = self.model.predict_MoGs(xs)
-        if self.proposal is not None:
-            for i, mog in enumerate(mogs):
-                mog.prune_negligible_components(threshold=threshold)
-                if isinstance(self.prior, pdf.Uniform):
-                    mogs[i] = mog / self.proposal
-                elif isinstance(self.prior, pdf.Gaussian):
-                    mogs[i] = (mog * self.prior) / self.proposal
-                else:
-                    raise NotImplementedError
-        if len(mogs) == 1:
-            return mogs[0]
-        mog_model = MDNN(
-            input_dim=1, output_dim=self.model.output_dim,
-            output_lows=self.model.output_lows.detach().cpu().numpy(),
-            output_highs=self.model.output_highs.detach().cpu().numpy(),
-            n_gaussians=self.model.n_gaussians, hidden_layers=(128, 128),
-            lr=self.model.lr, activation=self.model.activation,
-            full_covariance=self.model.L_size > 0, device=self.model.device)
-        tot_smpls = BayesSim.REFIT_SAMPLES
-        per_mog = int(tot_smpls / xs.shape[0])
-        smpls = np.concatenate([m.gen(n_samples=per_mog) for m in mogs], axis=0)
-        smpls = torch.from_numpy(smpls).float().to(self.model.device)
+        """Posterior for the given real trajectories (the contract of reference bayes_sim.py:116-179):
+        ONE trajectory -> the model's mixture for it (divided by the proposal when there is one);
+        SEVERAL -> REFIT_SAMPLES draws from their mixtures, refitted by a fresh unconditional MDNN
+        (input: a constant) whose single mixture is returned."""
+        summaries = self._summarize(states, actions)
+        mixtures = [self._correct_for_proposal(m, threshold) for m in self.model.predict_MoGs(summaries)]
+        return mixtures[0] if len(mixtures) == 1 else self._refit(mixtures)
+
+    def _correct_for_proposal(self, mog, threshold):
+        """bayes_sim.py:135-145: prune, then posterior = mixture x prior / proposal (a uniform prior drops out)."""
+        if self.proposal is None:
+            return mog
+        mog.prune_negligible_components(threshold=threshold)
+        if isinstance(self.prior, pdf.Uniform):
+            return mog / self.proposal
+        if isinstance(self.prior, pdf.Gaussian):
+            return (mog * self.prior) / self.proposal
+        raise NotImplementedError
+
+    def _refit(self, mixtures):
+        """bayes_sim.py:149-179: equal shares of REFIT_SAMPLES from every trajectory's mixture, REFIT_EPOCHS
+        sweeps of minibatch REFIT_MINIBATCH through the fit engine (the estimator's own hyper-parameters,
+        a [128, 128] trunk on a constant input), the fitted model's mixture at that input."""
+        src = self.model
+        refit = MDNN(input_dim=1, output_dim=src.output_dim,
+                     output_lows=src.output_lows.detach().cpu().numpy(),
+                     output_highs=src.output_highs.detach().cpu().numpy(),
+                     n_gaussians=src.n_gaussians, hidden_layers=(128, 128), lr=src.lr,
+                     activation=src.activation, full_covariance=src.L_size > 0, device=src.device)
+        share = int(BayesSim.REFIT_SAMPLES / len(mixtures))
+        draws = torch.from_numpy(np.concatenate([m.gen(n_samples=share) for m in mixtures], axis=0))
+        draws = draws.float().to(src.device)
         if MDNN.VERBOSE:
-            print(f'Fitting posterior from {len(mogs):d} mogs')
-        batch_size = BayesSim.REFIT_MINIBATCH
-        n_updates = BayesSim.REFIT_EPOCHS * tot_smpls // batch_size
-        inp = torch.zeros(smpls.shape[0], 1, device=smpls.device)
-        mog_model.run_training(inp, smpls, n_updates, batch_size)
-        fitted = mog_model.predict_MoGs(inp[0:1, :])
+            print(f'Fitting posterior from {len(mixtures):d} mogs')
+        const_in = torch.zeros(draws.shape[0], 1, device=draws.device)
+        refit.run_training(const_in, draws,
+                           BayesSim.REFIT_EPOCHS * BayesSim.REFIT_SAMPLES // BayesSim.REFIT_MINIBATCH,
+                           BayesSim.REFIT_MINIBATCH)
+        fitted = refit.predict_MoGs(const_in[0:1, :])
         assert len(fitted) == 1
         return fitted[0]

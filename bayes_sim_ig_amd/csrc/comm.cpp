@@ -111,7 +111,10 @@ struct bsig_comm {
   int world = 1, rank = 0, device = -1;
   bsig::CommXr xr;                 // resident-exchange resources (comm_xr), created on first use
   bool xr_made = false;
-  int resident_mode = -1;          // bsig_comm_set_resident: -1 policy (BSIG_DP_RESIDENT / default), 0 never, 1 always
+  int resident_mode = -1;          // bsig_comm_set_resident: -1 policy (BSIG_DP_RESIDENT, default off), 0 never, 1 always
+  bool channels_capped = false;    // world > 1: NCCL_MAX_NCHANNELS was capped before the communicator came up
+  int xr_last_slot = -1;           // ev_end slot of the last resident call not yet waited for by the host
+  int group_usable = -1;           // comm_xr_group_usable: -1 not asked yet
 };
 
 namespace bsig {
@@ -200,8 +203,36 @@ int comm_xr(bsig_comm* c, hipStream_t launch_stream, CommXr* out) {
   return BSIG_OK;
 }
 
+int comm_xr_drain(bsig_comm* c) {
+  if (!c || !c->xr_made || c->xr_last_slot < 0) return BSIG_OK;
+  BSIG_HIP(hipEventSynchronize(c->xr.ev_end[c->xr_last_slot]));
+  c->xr_last_slot = -1;
+  return BSIG_OK;
+}
+
+bool comm_resident_allowed(const bsig_comm* c) { return c && (c->world == 1 || c->channels_capped); }
+
+int comm_xr_group_usable(bsig_comm* c, hipStream_t st, bool* usable) {
+  BSIG_REQUIRE(c && c->xr_made && usable, "comm_xr_group_usable: no resident-exchange state");
+  if (c->world == 1) { *usable = c->xr.usable; return BSIG_OK; }
+  if (c->group_usable < 0) {
+    // (the second 256 bytes of `done`: nothing else uses them)
+    float* word = reinterpret_cast<float*>(reinterpret_cast<char*>(c->xr.done) + 256);
+    float v = c->xr.usable ? 1.0f : 0.0f;
+    BSIG_HIP(hipMemcpyAsync(word, &v, sizeof(v), hipMemcpyHostToDevice, st));
+    BSIG_HIP(hipStreamSynchronize(st));
+    BSIG_TRY(bsig_comm_allreduce(c, word, 1, reinterpret_cast<bsig_stream_t>(st)));
+    BSIG_HIP(hipMemcpyAsync(&v, word, sizeof(v), hipMemcpyDeviceToHost, st));
+    BSIG_HIP(hipStreamSynchronize(st));
+    c->group_usable = v > (float)c->world - 0.5f ? 1 : 0;
+  }
+  *usable = c->group_usable == 1;
+  return BSIG_OK;
+}
+
 int comm_xr_advance(bsig_comm* c, unsigned n) {
   BSIG_REQUIRE(c && c->xr_made, "comm_xr_advance: no resident-exchange state");
+  c->xr_last_slot = (int)(c->xr.calls % CommXr::kRing);
   ++c->xr.calls;
   c->xr.base += n;
   if (c->xr.base > (1u << 30)) {      // (once per ~10^9 updates) start over, with nothing in flight
@@ -248,7 +279,11 @@ extern "C" int bsig_comm_init(const void* unique_id, int world, int rank, int de
   // be resident on every rank at once, or a ring waits for a workgroup that cannot be scheduled.
   {
     const char* r = getenv("BSIG_DP_RESIDENT");
-    if (world > 1 && r && r[0] == '1') setenv("NCCL_MAX_NCHANNELS", "8", 0);
+    if (world > 1 && r && r[0] == '1') {
+      setenv("NCCL_MAX_NCHANNELS", "8", 0);
+      const char* have = getenv("NCCL_MAX_NCHANNELS");      // (a caller's own, smaller cap is as good)
+      c->channels_capped = have && atoi(have) >= 1 && atoi(have) <= 8;
+    }
   }
   int prev = 0;
   (void)hipGetDevice(&prev);

@@ -36,5 +36,19 @@ constexpr double kProbeOkUs = 100.0;
 int comm_xr(bsig_comm* c, hipStream_t launch_stream, CommXr* out);
 // ... one more call of n updates enqueued
 int comm_xr_advance(bsig_comm* c, unsigned n);
+// Host-side wait for the exchange stream's part of the LAST resident call (no-op when there is none, or
+// it has been waited for): before anything that is not a resident call writes, reduces or consumes the
+// gradient buffer on the fit's stream -- a resident launch that gave up releases its call's
+// hipStreamWaitValue32s at once, and the stale all-reduces behind them would otherwise run beside the
+// launch-per-update path's on the same communicator (round-5 advisor finding).  A HOST wait, not a
+// stream wait: profiles/r05_NOTES.md item 5.
+int comm_xr_drain(bsig_comm* c);
+// May this communicator's ranks stay resident across the exchange?  A 1-rank group: yes.  With peers only
+// when RCCL's channels were capped at init (BSIG_DP_RESIDENT=1 in the environment of bsig_comm_init:
+// comm.cpp) -- an uncapped ring waits for workgroups the resident launch leaves no CU for.
+bool comm_resident_allowed(const bsig_comm* c);
+// The probe's answer for the GROUP: usable only if every rank's exchange stream is (ranks that disagreed
+// would finish their Adam steps in different kernels).  One 4-byte all-reduce per communicator, cached.
+int comm_xr_group_usable(bsig_comm* c, hipStream_t st, bool* usable);
 
 }  // namespace bsig

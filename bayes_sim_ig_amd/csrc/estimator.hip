@@ -1291,16 +1291,28 @@ extern "C" int bsig_fit_dp_graph_status(const bsig_fit_plan* p, char* msg, size_
 // a second stream that per update waits for the kernel's "gradients are out" word, runs the
 // all-reduce and writes the word the kernel polls (fit_persistent.hip: XR; persist_mdnn_device.h:
 // xr).  No launch boundary and no W / m / v / g round trip through HBM per update.
-// Policy: BSIG_DP_RESIDENT=1 / 0 forces / forbids; unset: ON for a 1-rank group (all this pool can run:
-// cfg5 29.5 us per update against 34.8 with a launch per update, cfg3 39 against 47), OFF with peers -- RCCL's kernels would have
-// to live on the 8 CUs the launch leaves free (comm.cpp caps its channels for that case), which no one
-// has run yet.  The exchange stream is chosen by a probe (comm.h); when none is served promptly the
-// call falls back to a launch per update, and a launch whose polls time out anyway makes the fit
-// repeat on the per-phase kernels (mdnn.py), with a warning.
+// Policy (round 6: FROZEN, opt-in everywhere): BSIG_DP_RESIDENT=1 or bsig_comm_set_resident(comm, 1) asks
+// for it; unset, every rank runs one launch per update.  Round 5 had it on by default for 1-rank groups
+// (all this pool can run: cfg5 29.5 us per update against 34.8 with a launch per update, cfg3 39 against
+// 47) -- with one resident call in some 38 000 timing out for a reason nobody found, i.e. an unexplained
+// retry on a default path.  With peers it additionally needs RCCL's channels capped when the
+// communicator came up (comm.cpp: its kernels have to live on the 8 CUs the launch leaves free) and an
+// exchange stream that is served on EVERY rank (comm_xr_group_usable); no run with a peer has happened
+// yet.  The exchange stream is chosen by a probe (comm.h); when none is served promptly the call falls
+// back to a launch per update, and a launch whose polls time out anyway makes the fit repeat (mdnn.py:
+// first without the residency, then on the per-phase kernels), with a warning.
 static bool dp_resident_applies(const bsig_fit_plan* p, const bsig_comm* comm, int64_t n_updates) {
   const char* e = getenv("BSIG_DP_RESIDENT");
   const int mode = bsig_comm_resident_mode(comm);      // (bsig_comm_set_resident overrides the policy)
-  const bool want = mode >= 0 ? mode == 1 : (e ? e[0] == '1' : bsig_comm_world(comm) == 1);
+  bool want = mode >= 0 ? mode == 1 : (e && e[0] == '1');
+  if (want && !bsig::comm_resident_allowed(comm)) {
+    static bool told = false;
+    if (!told) fprintf(stderr, "bayes_sim_ig_amd: a rank with peers can stay resident across the gradient exchange only if "
+                               "BSIG_DP_RESIDENT=1 was set when its communicator was created (RCCL's channels are capped "
+                               "then): one launch per update instead\n");
+    told = true;
+    want = false;
+  }
   const char* no_ike = getenv("BSIG_NO_INKERNEL_EVAL");
   if (!(want && bsig_comm_transport(comm) == 1 && n_updates >= 1 && n_updates == p->n_updates && !p->adam_pending &&
         p->buf.n_test >= 1 && !(no_ike && no_ike[0] == '1')))
@@ -1382,7 +1394,9 @@ extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_upda
   if (resident) {      // ... and an exchange stream that is answered while a kernel runs on `stream` (comm.h)
     CommXr xr;
     BSIG_TRY(comm_xr(comm, as_stream(stream), &xr));
-    if (!xr.usable) {
+    bool usable = xr.usable;
+    BSIG_TRY(bsig::comm_xr_group_usable(comm, as_stream(stream), &usable));
+    if (!usable) {
       static bool told = false;
       if (!told) fprintf(stderr, "bayes_sim_ig_amd: BSIG_DP_RESIDENT=1, but no exchange stream of this process is served while a "
                                  "kernel runs on the fit's stream (best probe %.0f us): one launch per update instead\n",
@@ -1397,6 +1411,7 @@ extern "C" int bsig_fit_run_dp(bsig_fit_plan* p, bsig_comm* comm, int64_t n_upda
     n_evals = count_evals(n_updates);
   }
   const bool was_pending = p->adam_pending;
+  if (!resident) BSIG_TRY(bsig::comm_xr_drain(comm));     // (stale all-reduces of a resident call that gave up)
   if (!resident) BSIG_TRY(ensure_dp_graph(p, comm));
   p->adam_pending = was_pending;
   for (int64_t it = 0; it < (resident ? 0 : n_updates); ++it) {

@@ -1502,6 +1502,29 @@ __global__ __launch_bounds__(kUT) void linear_head_updates_kernel(UArgs p) {
 #endif
 }
 
+// (diagnostics / tests) occupy `blocks` CUs for `ms` milliseconds with workgroups that hold
+// `lds_bytes` of LDS each: a persistent launch behind it does not get all its workgroups resident
+__global__ void spin_kernel(long long ticks, int* sink) {
+  extern __shared__ float spin_lds[];
+  spin_lds[threadIdx.x] = 1.f;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+  if (spin_lds[threadIdx.x] == 2.f) sink[0] = 1;
+}
+int debug_spin(int blocks, size_t lds_bytes, int ms, hipStream_t st) {
+  BSIG_REQUIRE(blocks >= 1 && ms >= 0 && lds_bytes <= (size_t)kULds, "debug_spin: bad args");
+  BSIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spin_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kULds));
+  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds_bytes, 1024), st,
+                     (long long)ms * 100000LL /* 100 MHz wall clock */, (int*)nullptr);
+  BSIG_CHECK_LAUNCH("debug_spin");
+  return BSIG_OK;
+}
+
+static long long* g_prof = nullptr;
+void persist_set_profile_buffer(void* buf) { g_prof = reinterpret_cast<long long*>(buf); }
+void* persist_profile_buffer() { return g_prof; }
+
 // ---------------------------------------------------------------- host side
 struct UGeom {
   int NT, Bp, MT, FP, KS, ksteps, KB, WP, Nh, NhP, n_blocks, k_slices, G, T, n_owner, R;
@@ -1630,11 +1653,6 @@ static bool u_can_host(const UGeom& g) {
 }
 static bool u_device_can_host(const UGeom& g) { return g.NT == 1 ? u_can_host<1>(g) : u_can_host<2>(g); }
 
-static bool force_v1() {
-  static const bool v = [] { const char* e = getenv("BSIG_PERSIST_V1"); return e && e[0] == '1'; }();
-  return v;
-}
-
 // (asked on every launch: the answers -- a device query each -- are kept per shape and device)
 int persist_variant(const PersistShape& s) {
   struct Key { int dev, batch, feat_dim, out_dim, n_comp, max_test, variant; };
@@ -1650,8 +1668,9 @@ int persist_variant(const PersistShape& s) {
   }
   UGeom g;
   int v = 0;
-  if (!force_v1() && u_geom(s, &g) && u_device_can_host(g)) v = 2;
-  else if (persist_v1_supported(s)) v = 1;
+  // (2: this file's unified workgroups; 0: the per-phase kernels.  1 was fit_persistent_v1.hip -- the
+  // round-1..3 decomposition, no shipped configuration reached it, retired in round 6)
+  if (u_geom(s, &g) && u_device_can_host(g)) v = 2;
   cache[next] = Key{dev, s.batch, s.feat_dim, s.out_dim, s.n_comp, s.max_test, v};
   next = (next + 1) % 8;
   n_cache = std::min(n_cache + 1, 8);
@@ -1661,7 +1680,6 @@ int persist_variant(const PersistShape& s) {
 bool persist_supported(const PersistShape& s) { return persist_variant(s) != 0; }
 bool persist_eval_supported(const PersistShape& s) {
   const int v = persist_variant(s);
-  if (v == 1) return persist_v1_eval_supported(s);
   UGeom g;
   return v == 2 && u_geom(s, &g) && g.eval_passes > 0;
 }
@@ -1674,7 +1692,6 @@ static size_t u_sync_bytes() { return 2 * kFlagArr * sizeof(unsigned) + (6 + 16)
 
 size_t persist_workspace_bytes(const PersistShape& s) {
   const int v = persist_variant(s);
-  if (v == 1) return persist_v1_workspace_bytes(s);
   UGeom g;
   if (v != 2 || !u_geom(s, &g)) return 0;
   return u_data_bytes(g) + u_sync_bytes();
@@ -1682,7 +1699,6 @@ size_t persist_workspace_bytes(const PersistShape& s) {
 
 int persist_reset_regions(const PersistShape& s, void* workspace, size_t workspace_bytes,
                           ZeroRegion* regions) {
-  if (persist_variant(s) == 1) return persist_v1_reset_regions(s, workspace, workspace_bytes, regions);
   UGeom g;
   BSIG_REQUIRE(u_geom(s, &g), "persistent updates: shape not covered");
   BSIG_REQUIRE(workspace && workspace_bytes >= persist_workspace_bytes(s),
@@ -1724,7 +1740,6 @@ static int u_launch(const UGeom& g, const UArgs& p, bool dp, int n, bool do_eval
 
 int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyper& hy, int n,
                 hipStream_t st) {
-  if (persist_variant(s) == 1) return persist_v1_run(s, b, hy, n, st);
   UGeom g;
   BSIG_REQUIRE(u_geom(s, &g), "persistent updates: shape not covered");
   BSIG_REQUIRE(b.feats && b.y && b.ids && b.params && b.exp_avg && b.exp_avg_sq && b.state &&

@@ -63,17 +63,7 @@ int persist_reset_regions(const PersistShape& s, void* workspace, size_t workspa
 int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyper& h, int n,
                 hipStream_t st);
 
-// The round-1..3 decomposition (fit_persistent_v1.hip: 32 x 256 weight tiles on G workgroups + one
-// further workgroup per minibatch row), kept as the fallback for head matrices the 16-row tiles of
-// fit_persistent.hip cannot hold on 256 CUs, and for A/B runs (BSIG_PERSIST_V1=1)
-bool persist_v1_supported(const PersistShape& s);
-bool persist_v1_eval_supported(const PersistShape& s);
-size_t persist_v1_workspace_bytes(const PersistShape& s);
-int persist_v1_reset_regions(const PersistShape& s, void* workspace, size_t workspace_bytes,
-                             ZeroRegion* regions);
-int persist_v1_run(const PersistShape& s, const PersistBuffers& b, const PersistHyper& h, int n,
-                   hipStream_t st);
-// 2: unified workgroups (fit_persistent.hip), 1: fit_persistent_v1.hip, 0: shape not covered
+// 2: unified workgroups (fit_persistent.hip), 0: shape not covered (1 was fit_persistent_v1.hip, retired in round 6)
 int persist_variant(const PersistShape& s);
 // (diagnostics) the tiling fit_persistent.hip plans for a shape, bsig.h: bsig_debug_persist_geometry
 int persist_geometry(const PersistShape& s, int32_t* out);

@@ -515,7 +515,7 @@ def time_update_kernel(pkg, cfg, bsim, device):
     geo = (C.c_int32 * 16)()
     tiling = None
     if lib.bsig_debug_persist_geometry(batch, f_in, cfg['d'], cfg['k'], n_test, geo) and geo[13] == 2:
-        # (geo[13]: the kernel that really runs -- 1 = fit_persistent_v1.hip, which this tiling does not describe)
+        # (geo[13]: the kernel that really runs -- 2 = this tiling, 0 = the per-phase kernels)
         tiling = {'tile_rows': 16 * geo[0], 'k_slice': geo[1], 'head_blocks': geo[2], 'k_slices': geo[3],
                   'tile_workgroups': geo[4], 'workgroups': geo[5], 'row_owners': geo[6], 'rows_per_owner': geo[7],
                   'owners_that_hold_a_tile': geo[12], 'lds_bytes': geo[11]}
@@ -895,21 +895,36 @@ def per_config_numbers(pkg, device, skip):
 T0 = time.perf_counter()
 
 
+def rank_launch_command(n, argv, port):
+    """The command that runs this script as n ranks, one per GPU of this node (the form the round
+    driver uses: torch.distributed.run on 127.0.0.1; the ranks read RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* from the environment)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+            '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
 def launch_ranks(n):
     """Run this script as n ranks (one per GPU) under torch.distributed.run on
-    127.0.0.1, pass rank 0's JSON line through, return the launcher's exit code."""
+    127.0.0.1, pass rank 0's JSON line through, return the launcher's exit code.
+    Refuses, BEFORE anything touches a GPU, a rank count this node cannot seat: the ranks are started
+    as child processes (never exec'ed into from a process that has initialised the GPU), and counting
+    devices through torch does not initialise one."""
     import socket
     import subprocess
+    have = torch.cuda.device_count()
+    if n > have:
+        raise SystemExit('bench.py --gpus %d: this node shows %d GPU%s (one rank per GPU; RCCL refuses two ranks '
+                         'on a device).  Run with --gpus <= %d, or see BENCH_BACKEND=gloo BENCH_SHARE_GPU=1 for a '
+                         'functional check of the multi-rank path on one GPU.' % (n, have, '' if have == 1 else 's',
+                                                                                 max(have, 1)))
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', str(max((os.cpu_count() or n) // n, 1)))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    return subprocess.run(rank_launch_command(n, sys.argv[1:], port), env=env).returncode
 
 
 def main():
@@ -1041,7 +1056,7 @@ def main():
                 if dist is not None else 'none',
                 'hip_graph': not args.no_graph,
                 # run_training calls of this rank that ran as ONE launch, resident across the gradient
-                # exchange (BSIG_DP_RESIDENT; the default on a 1-rank group), warm-up included
+                # exchange (BSIG_DP_RESIDENT=1: opt-in since round 6), warm-up included
                 'rank_resident_calls': bsim.model._dp.resident_calls() if dist is not None else None},
             'sgd_visits_per_sec': value * 10.0,
             'heldout_nll_last_step_mean': final_test,

@@ -15,7 +15,11 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, timeout_rank=-1):
+    """timeout_rank >= 0: that rank's FIRST attempt at the call reports the persistent kernels' time-out bit
+    (bit 1 of the flag word) in its logs -- the way a resident launch whose bounded polls gave up does.
+    The logs of a call are summed over the ranks (bsig_fit_run_dp), so EVERY rank reads a non-zero flag
+    at the same call: all restore the snapshot they took at its start and repeat it together."""
     import sys
     sys.path.insert(0, ROOT)
     from bayes_sim_ig_amd import dp
@@ -47,6 +51,9 @@ def _worker(rank, world, port, out):
     flat_grad = torch.zeros_like(flat)
     lo, hi = dp.shard_bounds(b, world, rank)
     state = {'it': 0, 'loss': []}
+    import copy
+    snap = (copy.deepcopy(model.state_dict()), copy.deepcopy(opt.state_dict()))
+    attempts = 0
 
     def grad():
         rows = ids[state['it']][lo:hi]
@@ -64,15 +71,28 @@ def _worker(rank, world, port, out):
         opt.step()
         state['it'] += 1
 
-    evals = []
-    dp.run_updates(updates, {0, updates - 1}, grad,
-                   lambda: group.allreduce_sum(flat_grad), apply,
-                   lambda: evals.append(float(model.mdn_loss_fn(*model(x[:8 + 4 * rank]),
-                                                                y[:8 + 4 * rank]))))
+    while True:
+        attempts += 1
+        evals = []
+        dp.run_updates(updates, {0, updates - 1}, grad,
+                       lambda: group.allreduce_sum(flat_grad), apply,
+                       lambda: evals.append(float(model.mdn_loss_fn(*model(x[:8 + 4 * rank]),
+                                                                    y[:8 + 4 * rank]))))
+        # the call's logs travel as one packed sum over the ranks, the flag word with them
+        flag = torch.tensor([2.0 if (rank == timeout_rank and attempts == 1) else 0.0])
+        group.allreduce_sum(flag)
+        if float(flag) == 0.0:
+            break
+        # group-wide restore: every rank saw the flag, every rank goes back to the call's start
+        assert attempts == 1
+        model.load_state_dict(snap[0])
+        opt.load_state_dict(snap[1])
+        state['it'], state['loss'] = 0, []
     tl, te = group.mean_losses(torch.tensor(state['loss']), torch.tensor(evals), 8 + 4 * rank)
+    counts = group.gather_counts(8 + 4 * rank)
     if rank == 0:
         torch.save({'flat': torch.cat([p.detach().reshape(-1) for p in params]),
-                    'train': tl, 'test': te, 'evals0': evals}, out)
+                    'train': tl, 'test': te, 'evals0': evals, 'attempts': attempts, 'counts': counts}, out)
     dist.destroy_process_group()
 
 
@@ -101,6 +121,40 @@ def test_two_rank_gradient_exchange_equals_single_rank(tmp_path):
     # count-weighted held-out mean over the two shards (8 and 12 rows)
     assert res['test'].shape == (2,) and res['train'].shape == (updates,)
     assert torch.isfinite(res['test']).all()
+
+
+def test_four_ranks_unequal_eval_shards_and_a_group_wide_restore(tmp_path):
+    """world_size 4 (minibatch 16 = 4 rows per rank), held-out shards of 8 / 12 / 16 / 20 rows, and rank 2
+    reporting a persistent-kernel time-out on the first attempt: every rank must repeat the call from
+    its snapshot, and the result must be the undisturbed single-rank run."""
+    from oracle import estimators as oest
+    out = str(tmp_path / 'dp4.pt')
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(4, port, out, 2), nprocs=4, join=True)
+    res = torch.load(out)
+    assert res['attempts'] == 2 and res['counts'] == [8, 12, 16, 20]
+    gen = torch.Generator().manual_seed(0)
+    n, i, d, b, updates = 64, 12, 3, 16, 6
+    x, y = torch.randn(n, i, generator=gen), torch.rand(n, d, generator=gen)
+    ids = np.random.RandomState(1).randint(0, n, (updates, b))
+    torch.manual_seed(100)                      # rank 0's init
+    model = oest.OracleMDNN(input_dim=i, output_dim=d, output_lows=None, output_highs=None,
+                            n_gaussians=3, full_covariance=False, hidden_layers=(8,),
+                            activation=torch.nn.Tanh, lr=1e-2, eps_noise=0.0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    evals = []
+    for it in range(updates):
+        opt.zero_grad()
+        model.mdn_loss_fn(*model(x[ids[it]]), y[ids[it]]).backward()
+        opt.step()
+        if it in (0, updates - 1):
+            # the group's held-out NLL: count-weighted mean over the four shards x[:8], x[:12], x[:16], x[:20]
+            tot = sum(float(model.mdn_loss_fn(*model(x[:m]), y[:m])) * m for m in (8, 12, 16, 20))
+            evals.append(tot / 56.0)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    torch.testing.assert_close(res['flat'], flat, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(res['test'], torch.tensor(evals), rtol=1e-4, atol=1e-6)
+    assert res['train'].shape == (updates,)
 
 
 def test_shard_bounds_cover_everything():

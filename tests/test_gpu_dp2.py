@@ -110,11 +110,15 @@ def test_two_rank_fit_with_rank_local_jitter_scale(tmp_path):
         np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-6)
 
 
+RESIDENT_RETRIES = []      # (test name, attempt) of every resident fit that had to be repeated in this session
+
+
 def _fit_clean(build, fits=1, retries=1):
     """build() -> (BayesSim, theta, states, actions); its fit(s) with any time-out fallback turned into a
     retry on a fresh model (one resident call in some 38 000 has timed out on this pool without a known
-    cause: DESIGN.md 5 -- a test of what the resident path computes should not fail on that).  Returns
-    (model wrapper, logs, resident calls of the fits)."""
+    cause: DESIGN.md 5 -- a test of what the resident path computes should not fail on that).  The retry
+    is NOT silent: it is recorded in RESIDENT_RETRIES, printed, and test_resident_retries_stay_rare bounds
+    the session's count.  Returns (model wrapper, logs, resident calls of the fits)."""
     import warnings
     for attempt in range(retries + 1):
         bs, theta, states, actions, seed = build()
@@ -128,7 +132,9 @@ def _fit_clean(build, fits=1, retries=1):
                     logs += bs.fit(theta, states, actions)
             torch.cuda.synchronize()
             return bs, logs, bs.model._dp.resident_calls() - before
-        except RuntimeWarning:
+        except RuntimeWarning as w:
+            RESIDENT_RETRIES.append((os.environ.get('PYTEST_CURRENT_TEST', '?'), attempt, str(w)[:120]))
+            print('RESIDENT RETRY', RESIDENT_RETRIES[-1])
             if attempt == retries:
                 raise
 
@@ -277,3 +283,11 @@ def test_resident_rank_takes_its_adam_step_from_the_exchanged_gradients(monkeypa
     assert torch.equal(out[('0', '3')][1], out[('1', '3')][1])
     assert out[('0', '3')][0] == out[('1', '3')][0]
     assert not torch.equal(out[('1', '3')][1], out[('1', None)][1])
+
+
+def test_resident_retries_stay_rare():
+    """(runs last in this file) The resident fits above may repeat a fit whose launch timed out -- the
+    unexplained 1-in-38 000 of DESIGN.md 5.  This session's fits are a few hundred resident calls: more
+    than ONE retry would be a regression of the hand-off, not that residue."""
+    print('resident fits repeated in this session:', RESIDENT_RETRIES)
+    assert len(RESIDENT_RETRIES) <= 1, RESIDENT_RETRIES

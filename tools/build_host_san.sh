@@ -25,6 +25,11 @@ for f in "$SRC"/*.hip "$SRC"/*.cpp; do
   b=$(basename "$f"); build_one "${b%.*}" "$f"
 done
 build_one host_san_main tests/host/host_san_main.cpp
+# objects of sources that no longer exist (a retired file's object would be linked by the glob below)
+for o in "$OUT"/*.o; do
+  b=$(basename "$o" .o)
+  [ "$b" = host_san_main ] || [ -f "$SRC/$b.hip" ] || [ -f "$SRC/$b.cpp" ] || rm -f "$OUT/$b.o" "$OUT/$b.stamp"
+done
 rc=0
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
 [ $rc -eq 0 ] || { echo "host sanitizer build failed" >&2; exit 1; }

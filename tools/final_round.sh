@@ -24,14 +24,14 @@ python3 tools/gemm_scaled_sweep.py heldout 2>&1 | grep -v "amdgpu.ids" > "$OUT/$
 BSIG_PROF_T0=50 python3 tools/persist_prof.py 2>&1 | grep -v "amdgpu.ids" > "$OUT/${TAG}_cfg5_update_timeline_warm.txt"
 # a data-parallel rank on a 1-rank RCCL group: resident across the exchange (the default there) and one launch per update
 DPQ="--steps 3 --warmup 1 --no-per-config --no-largest-size --no-cpu-baseline --no-scaled-batch"
-{ echo "BENCH_FORCE_DP=1 python bench.py $DPQ  (rank resident across the exchange: the default on a 1-rank group)"
-  BSIG_DP_XR_TRACE=1 BENCH_FORCE_DP=1 python3 bench.py $DPQ 2> "$OUT/${TAG}_dp_resident_stderr.log"
+{ echo "BSIG_DP_RESIDENT=1 BENCH_FORCE_DP=1 python bench.py $DPQ  (rank resident across the exchange: opt-in since round 6)"
+  BSIG_DP_RESIDENT=1 BSIG_DP_XR_TRACE=1 BENCH_FORCE_DP=1 python3 bench.py $DPQ 2> "$OUT/${TAG}_dp_resident_stderr.log"
   grep "comm_xr:" "$OUT/${TAG}_dp_resident_stderr.log" | head -2
   grep "time-out bits" "$OUT/${TAG}_dp_resident_stderr.log" | tail -1 | sed "s/.*time-out bits so far://" | tr ' ' '\n' | grep -v "^$" | sort | uniq -c | sed "s/^/  time-out bit of the resident calls (count value): /"
   echo "BSIG_DP_RESIDENT=0 BENCH_FORCE_DP=1 python bench.py $DPQ  (one launch + all-reduce per update)"
   BSIG_DP_RESIDENT=0 BENCH_FORCE_DP=1 python3 bench.py $DPQ 2>/dev/null
-  echo "BENCH_FORCE_DP=1 python bench.py --config cfg3 --pairs 20000 $DPQ  (MDNN kernel, resident across the exchange)"
-  BENCH_FORCE_DP=1 python3 bench.py --config cfg3 --pairs 20000 $DPQ 2>/dev/null
+  echo "BSIG_DP_RESIDENT=1 BENCH_FORCE_DP=1 python bench.py --config cfg3 --pairs 20000 $DPQ  (MDNN kernel, resident across the exchange)"
+  BSIG_DP_RESIDENT=1 BENCH_FORCE_DP=1 python3 bench.py --config cfg3 --pairs 20000 $DPQ 2>/dev/null
   echo "BSIG_DP_RESIDENT=0 BENCH_FORCE_DP=1 python bench.py --config cfg3 --pairs 20000 $DPQ  (MDNN kernel: one launch + all-reduce per update)"
   BSIG_DP_RESIDENT=0 BENCH_FORCE_DP=1 python3 bench.py --config cfg3 --pairs 20000 $DPQ 2>/dev/null
 } > "$OUT/${TAG}_dp_1rank.txt"

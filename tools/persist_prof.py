@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Phase breakdown of the persistent update kernel of the linear heads from its wall-clock
 stamps (bsig_debug_persist_profile): one cfg5-shaped chunk.  fit_persistent.hip (unified
-workgroups: every workgroup holds a weight tile, the first B also own a minibatch row), or
-fit_persistent_v1.hip with BSIG_PERSIST_V1=1 (tile workgroups + row-owner workgroups)."""
+workgroups: tile workgroups, row owners on CUs of their own where the chip has them)."""
 import ctypes as C
 import os
 import sys
@@ -33,7 +32,7 @@ lib.bsig_debug_persist_profile(None)
 raw = buf.cpu().numpy().reshape(2, 256, 8, 16).astype(np.float64) / 100.0   # 100 MHz -> us
 st, rowst = raw[0], raw[1]
 live = [g for g in range(256) if st[g, 1, 0] > 0]
-v1 = os.environ.get('BSIG_PERSIST_V1') == '1'
+v1 = False      # (fit_persistent_v1.hip was retired in round 6)
 
 
 def phases(g, table):
