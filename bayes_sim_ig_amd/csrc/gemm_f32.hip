@@ -257,13 +257,14 @@ static bool plan_gemm_large(int64_t m, int64_t n, int64_t k, size_t ws_bytes, Ge
   return true;
 }
 
-static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
+// lean_ok: gemm_lean_kernel will run this product (both operands move as aligned 16-byte items)
+static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes, bool lean_ok) {
   GemmPlan pl;
   if (env_int("BSIG_GEMM_TILE", -1) < 0 && env_int("BSIG_GEMM_SPLITS", 0) <= 0 &&
       env_int("BSIG_GEMM_NO_LARGE_PLAN", 0) == 0 && plan_gemm_large(m, n, k, ws_bytes, &pl))
     return pl;
   const int64_t t128 = ceil_div<int64_t>(m, 128) * ceil_div<int64_t>(n, 128);
-  int64_t tiles, target;
+  int64_t tiles, target, min_splits = 1;
   const int64_t t12864 = ceil_div<int64_t>(m, 128) * ceil_div<int64_t>(n, 64);
   if (m >= 256 && n >= 128 && t128 >= 192) {
     pl.tile = TILE_128; tiles = t128; target = 256;
@@ -273,7 +274,11 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
     // tiling is the fastest of the sweep (profiles/r05_rff_chunk_sweep.txt: 1000 rows = 16 x 32 = 512
     // workgroups, two per CU, 90 us against 97 for 128 x 64 tiles in two K halves; 800 rows 95 = 95).
     // (round 2-4, gemm_mfma_kernel: 128x64 tiles in two k-halves, 101-104 us against 118-135.)
-    pl.tile = TILE_64; tiles = ceil_div<int64_t>(m, 64) * ceil_div<int64_t>(n, 64); target = 0;
+    // That measurement holds for the LEAN kernel only: operands that are not 16-byte aligned still run
+    // gemm_mfma_kernel, where unsplit 64 x 64 tiles measured 118-135 us against 101-104 for the old plan
+    // -- they keep 128 x 64 tiles in two K halves (round-5 advisor finding).
+    if (lean_ok) { pl.tile = TILE_64; tiles = ceil_div<int64_t>(m, 64) * ceil_div<int64_t>(n, 64); target = 0; }
+    else { pl.tile = TILE_128x64; tiles = t12864; target = 0; min_splits = 2; }
   } else if (m <= 128 && n >= 64) {
     pl.tile = TILE_128x32; tiles = ceil_div<int64_t>(n, 32); target = 512;
   } else {
@@ -292,6 +297,7 @@ static GemmPlan plan_gemm(int64_t m, int64_t n, int64_t k, size_t ws_bytes) {
     if (splits > max_by_k) splits = max_by_k;
     if (splits > 64) splits = 64;
   }
+  if (forced_tile < 0 && splits < min_splits && k / (4 * BK) >= min_splits) splits = min_splits;
   const int forced = env_int("BSIG_GEMM_SPLITS", 0);
   if (forced > 0) splits = forced;
   const int64_t max_by_ws = (int64_t)(ws_bytes / (sizeof(float) * (size_t)(m * n)));
@@ -419,9 +425,6 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
     if (rc != BSIG_EUNSUPPORTED) return rc;
   }
   BSIG_REQUIRE(p.bias_g_n <= 1, "gemm: partial bias sums outside the whole-width gradient path");
-  const GemmPlan pl = plan_gemm(p.m, p.n, p.k, workspace ? workspace_bytes : 0);
-  p.splits = pl.splits; p.k_chunk = pl.k_chunk;
-  p.partial = reinterpret_cast<float*>(workspace);
   // a device-resolved row offset changes the alignment of nothing: offsets are whole rows
   {
     static const int xcd = [] { const char* e = getenv("BSIG_GEMM_XCD"); return e ? atoi(e) : 1; }();
@@ -430,11 +433,16 @@ int gemm_run(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t 
   p.a_unal = unaligned_quads(p.a, p.lda, p.a_kmajor, p.k);
   p.b_unal = unaligned_quads(p.b, p.ldb, p.b_kmajor, p.k);
   const int avec = p.a_unal ? 4 : pick_vec(p.a, p.lda), bvec = p.b_unal ? 4 : pick_vec(p.b, p.ldb);
-  int rc = BSIG_EUNSUPPORTED;
   // the lean main loop (gemm_lean.h: bit-identical, no vector-ALU work in the K loop) wherever
   // both operands move as aligned 16-byte items
   const int lean = env_int("BSIG_GEMM_LEAN", 1);   // (read per call: tests compare the two kernels)
-  if (lean && avec == 4 && bvec == 4 && !p.a_unal && !p.b_unal) {
+  const bool lean_ok = avec == 4 && bvec == 4 && !p.a_unal && !p.b_unal;
+  // (the plan does not depend on BSIG_GEMM_LEAN: the two kernels are compared on the SAME plan)
+  const GemmPlan pl = plan_gemm(p.m, p.n, p.k, workspace ? workspace_bytes : 0, lean_ok);
+  p.splits = pl.splits; p.k_chunk = pl.k_chunk;
+  p.partial = reinterpret_cast<float*>(workspace);
+  int rc = BSIG_EUNSUPPORTED;
+  if (lean && lean_ok) {
     const bool akm = p.a_kmajor != 0, bkm = p.b_kmajor != 0;
     switch (pl.tile) {
       case TILE_64: rc = launch_lean_64(p, akm, bkm, st); break;
@@ -515,7 +523,7 @@ using namespace bsig;
 extern "C" size_t bsig_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
   size_t need = (size_t)64 * (size_t)m * (size_t)n * sizeof(float) <= ((size_t)256 << 20)
                     ? (size_t)64 * (size_t)m * (size_t)n * sizeof(float)
-                    : plan_gemm(m, n, k, (size_t)1 << 40).splits * (size_t)m * (size_t)n * sizeof(float);
+                    : plan_gemm(m, n, k, (size_t)1 << 40, false).splits * (size_t)m * (size_t)n * sizeof(float);
   // the whole-width products (gemm_wide.h): up to 8 K slices of slabs at the padded head width
   if (m >= 2048 && gemm_wide_covers((int)n))
     need = std::max(need, (size_t)8 * (size_t)m * (size_t)round_up<int64_t>(n, 16) * sizeof(float));
