@@ -135,14 +135,17 @@ __device__ __forceinline__ int u_evals_before(int s, int every) { return s == 0 
       p.prof[((int64_t)wg * kUProf + t - p.prof_t0) * 16 + (k)] = wall_clock64(); \
   } while (0)
 
-// which row the owners of this launch run: workgroup-uniform, the same for every launch of a shape
+// which row the owners of this launch run: workgroup-uniform, the same for every launch of a shape.
+// 0: the shape-generic row; else KP * 8 + NQH (u_own_update_fast<KP, NQH>).
 __device__ __forceinline__ int u_fast_kind(const UArgs& p) {
   const int K = p.K;
-  if (!(K == 4 || K == 8) || p.fast_rows == 0) return 0;     // (K = 16 works too; not instantiated: compile time)
-  const int nq = (p.D + 64 / K - 1) / (64 / K);             // sweeps of a row
+  if (K > 16 || p.fast_rows == 0) return 0;
   if (p.T - p.G < p.n_owner) return 0;                    // (owners that also hold a tile run the shape-generic row)
-  if (p.R > 4 || nq > 4 || p.R * ((p.Nh + 3) >> 2) > kUT) return 0;
-  return nq <= 2 ? 1 : 2;                                   // sweeps per wavefront
+  const int KP = K <= 4 ? 4 : (K <= 8 ? 8 : 16);
+  const int nq = (p.D + 64 / KP - 1) / (64 / KP);         // sweeps of a row
+  if (p.R > 4 || nq > 8 || p.R * ((p.Nh + 3) >> 2) > kUT) return 0;
+  const int nqh = nq <= 2 ? 1 : (nq <= 4 ? 2 : 4);        // sweeps per wavefront
+  return KP * 8 + nqh;
 }
 
 // ---- replicated granules (round 6) -------------------------------------------------------------------
@@ -532,40 +535,6 @@ __device__ __forceinline__ void u_own_update(const UArgs& p, UOwn& o, int t, int
 // Same formulas, same IEEE divisions, same Philox draws per (row, lane, sweep) as diag_row_body; the
 // summation orders differ (tests: persistent == per-phase kernels / oracle at their tolerances; every
 // variant of this kernel -- resident, data-parallel, resident across the exchange -- shares this code).
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-// all-reduce over the K adjacent lanes of an aligned group (K = 4, 8, 16): xor 1, xor 2, mirror of 8, mirror of 16
-template <int K>
-__device__ __forceinline__ float kgroup_sum(float v) {
-  v += dpp_mov<0xB1>(v);                            // quad_perm:[1,0,3,2]
-  v += dpp_mov<0x4E>(v);                            // quad_perm:[2,3,0,1]
-  if constexpr (K >= 8) v += dpp_mov<0x141>(v);     // row_half_mirror
-  if constexpr (K >= 16) v += dpp_mov<0x140>(v);    // row_mirror
-  return v;
-}
-template <int K>
-__device__ __forceinline__ float kgroup_max(float v) {
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  if constexpr (K >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
-  if constexpr (K >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
-  return v;
-}
-// all-reduce over the 16 / K lanes of a DPP row that hold the same component (stride K): rotations by 8, 4
-template <int K>
-__device__ __forceinline__ float dslots_sum(float v) {
-  if constexpr (K <= 8) v += dpp_mov<0x128>(v);     // row_ror:8
-  if constexpr (K <= 4) v += dpp_mov<0x124>(v);     // row_ror:4
-  return v;
-}
-// the four values of the lane's quad
-__device__ __forceinline__ f32x4 quad_gather(float v) {
-  f32x4 q = {dpp_mov<0x00>(v), dpp_mov<0x55>(v), dpp_mov<0xAA>(v), dpp_mov<0xFF>(v)};
-  return q;
-}
-
 // Update t of the launch for the rows of this owner, every wavefront of the workgroup comes through here
 // (wavefronts 2r, 2r + 1 run row r0 + r; the others only fetch k-slices and keep the barriers).
 #ifdef BSIG_ROW_PROF
@@ -574,10 +543,16 @@ __device__ __forceinline__ f32x4 quad_gather(float v) {
 #else
 #define BSIG_FSTAMP(i)
 #endif
-template <int K, int NQH>
+// KP: the component count padded to a power of two (4, 8, 16): lane = d-slot * KP + k, the lanes k >= K of
+// a group idle (K = 5 -> 8, K = 10 -> 16: the reference YAMLs' 10 components) -- they enter the butterflies
+// with the neutral element.  K == KP (`exact`: K a multiple of 4): the quad stores and the one-wavefront
+// exp(pre) sum; else 4-byte stores and the sum through the wavefronts' partial sums.
+template <int KP, int NQH>
 __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t, int w, int lane0, int wg) {
 #pragma clang fp contract(off)
-  constexpr int GR = 64 / K;                   // dimensions per sweep
+  constexpr int GR = 64 / KP;                  // dimensions per sweep
+  const int K = p.K;
+  const bool exact = K == KP;
   const int B = p.B, Nh = p.Nh, NhP = p.NhP, D = p.D, DK = D * K, R = p.R;
   const int step = o.step0 + t;
   const unsigned epoch = (unsigned)step + 1u;
@@ -592,16 +567,19 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
   const int row = r0 + rr;
   const bool row_wave = rr < R;                // (wavefront-uniform)
   const bool active = row_wave && row < B;
-  const int k = lane & (K - 1), d0 = lane / K;
+  const int k = lane & (KP - 1), d0 = lane / KP;
+  const bool kok = k < K;
   const bool jitter = p.eps_noise != 0.f;
 
-  // ---- in the wait: target values, jitter draws ----------------------------------------------------
+  // ---- in the wait: target values, jitter draws, the elements' columns ------------------------------
   float yd[NQH], eu[NQH];
   bool valid[NQH];
+  int ecol[NQH];                               // element (d, k) of sweep h + 2 i: d * K + k
 #pragma unroll
   for (int i = 0; i < NQH; ++i) {
     const int d = d0 + (h + 2 * i) * GR;
-    valid[i] = active && d < D;
+    valid[i] = active && kok && d < D;
+    ecol[i] = min(d, D - 1) * K + min(k, K - 1);
     yd[i] = 0.f; eu[i] = 0.f;
   }
   if (active) {
@@ -610,12 +588,27 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
     for (int i = 0; i < NQH; ++i)
       if (valid[i]) yd[i] = p.y[yrow * p.ldy + d0 + (h + 2 * i) * GR];
     if (jitter) {
-      // (diag_row_noise's draw of sweeps 0..3: counter (row * 64 + lane) * 2, output q of sweep q)
+      // the draw of element (d, k) is diag_row_noise's: the generic row's lane of the element is
+      // (d % G) * K + k with G = 64 / K dimension slots, its sweep q = d / G; counter (row * 64 + lane) * 2
+      // + (q >> 2), output q & 3.  (exact, NQH <= 2: the lanes and sweeps coincide -- one call)
       const uint64_t sid = o.rng_ctr0 + (uint64_t)t + (uint64_t)(p.do_eval ? u_evals_before(step, p.eval_every) - o.ev0 : 0);
-      const Philox4 ph = philox4x32_10(o.a.seed, sid, ((uint64_t)row * 64 + lane) * 2);
+      if (exact && NQH <= 2) {
+        const Philox4 ph = philox4x32_10(o.a.seed, sid, ((uint64_t)row * 64 + lane) * 2);
 #pragma unroll
-      for (int i = 0; i < NQH; ++i)
-        if (valid[i]) eu[i] = u01(h ? ph.v[2 * i + 1] : ph.v[2 * i]);
+        for (int i = 0; i < NQH; ++i)
+          if (valid[i]) eu[i] = u01(h ? ph.v[(2 * i + 1) & 3] : ph.v[(2 * i) & 3]);
+      } else {
+        const int G = 64 / K;
+#pragma unroll
+        for (int i = 0; i < NQH; ++i) {
+          if (valid[i]) {
+            const int d = d0 + (h + 2 * i) * GR, q = d / G, gl = (d - q * G) * K + k;
+            const Philox4 ph = philox4x32_10(o.a.seed, sid, ((uint64_t)row * 64 + gl) * 2 + (q >> 2));
+            const int oi = q & 3;
+            eu[i] = u01(oi == 0 ? ph.v[0] : (oi == 1 ? ph.v[1] : (oi == 2 ? ph.v[2] : ph.v[3])));
+          }
+        }
+      }
     }
   }
   if (w == 0) {
@@ -676,7 +669,7 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
   // (16-byte LDS reads), takes the exponentials and publishes the granule -- no second barrier, no
   // exchange of wavefront sums between the k-slice sums and the granule.
   const int pq = DK >> 2, npq = nrows * pq;
-  const bool one_wave_exp = npq <= 64;
+  const bool one_wave_exp = exact && npq <= 64;
   if (one_wave_exp && w == kUT / 64 - 1) {      // (the last wavefront: no row of its own unless the workgroup has four)
     const int r = lane / pq, c4 = K + DK + 4 * (lane - r * pq);
     const float* b = part + 4 * min(r, nrows - 1) * ncq + c4;
@@ -688,16 +681,10 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
   }
   float ev[NQH], muv[NQH], pre[NQH];
 #pragma unroll
-  for (int i = 0; i < NQH; ++i) {
-    const int e = min(lane + (h + 2 * i) * 64, DK - 1);
-    pre[i] = slice_sum(K + DK + e);
-  }
+  for (int i = 0; i < NQH; ++i) pre[i] = slice_sum(K + DK + ecol[i]);
 #pragma unroll
-  for (int i = 0; i < NQH; ++i) {
-    const int e = min(lane + (h + 2 * i) * 64, DK - 1);
-    muv[i] = slice_sum(K + e);
-  }
-  const float lg_own = slice_sum(k);
+  for (int i = 0; i < NQH; ++i) muv[i] = slice_sum(K + ecol[i]);
+  const float lg_own = slice_sum(min(k, K - 1));
 #pragma unroll
   for (int i = 0; i < NQH; ++i) ev[i] = valid[i] ? expf(pre[i]) : 0.f;
   if (jitter && row_wave) {
@@ -707,8 +694,11 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
 #pragma unroll
     for (int i = 0; i < NQH; ++i) {
       const f32x4 qe = quad_gather(ev[i]);
-      if (valid[i] && (lane & 3) == 0)
-        xwg_store4(er, K + DK + (lane & ~3) + (h + 2 * i) * 64, qe[0], qe[1], qe[2], qe[3]);
+      if (exact) {
+        if (valid[i] && (lane & 3) == 0) xwg_store4(er, K + DK + ecol[i], qe[0], qe[1], qe[2], qe[3]);
+      } else if (valid[i]) {
+        xwg_store(p.e_out + (int64_t)row * NhP + K + DK + ecol[i], ev[i]);
+      }
     }
   }
   if (!one_wave_exp) {
@@ -730,88 +720,35 @@ __device__ __forceinline__ void u_own_update_fast(const UArgs& p, UOwn& o, int t
   bool bad = false;
   if (row_wave) {
     ge.issue();      // (the other owners' sums: in flight over the mixture weights)
-    // ---- mixture weights (mdnn.py:109-111), every lane its component -------------------------------
-    const float mx = kgroup_max<K>(lg_own);
-    const float e_own = expf(lg_own - mx);
-    const float s_own = e_own / kgroup_sum<K>(e_own);
-    const float c_own = fminf(fmaxf(s_own, p.min_w), 1.0f);
-    const float csum = kgroup_sum<K>(c_own);
-    const float w_own = c_own / csum;
-    const float wc = fminf(fmaxf(w_own, p.min_w), 1.0f);     // the second clamp, mdnn.py:160
-    const float lw = logf(wc);
-  BSIG_FSTAMP(2);
-    const float eps = ge.get();
-  BSIG_FSTAMP(3);
-    // ---- elements: sigma, z, log sigma ------------------------------------------------------------
-    float quad = 0.f, logdet = 0.f, ez[NQH], rsg[NQH];
-#pragma unroll
-    for (int i = 0; i < NQH; ++i) {
-      float sg = ev[i];
-      if (eps != 0.f) sg = __builtin_fmaf(eu[i], eps, sg);
-      else eu[i] = 0.f;
-      if (!valid[i]) sg = 1.f;
-      bad |= valid[i] && !(isfinite(muv[i]) && isfinite(sg));
-      const float z = valid[i] ? (yd[i] - muv[i]) / sg : 0.f;
-      quad += z * z;
-      logdet += logf(sg);
-      ez[i] = z; rsg[i] = sg;
-    }
-    // sums over the dimensions of each component: inside the DPP rows, then 4 rows x 2 wavefronts through LDS
-    quad = dslots_sum<K>(quad);
-    logdet = dslots_sum<K>(logdet);
-    float* xq = XS + ((active ? rr : 0) * K + k) * 8;
-    float* xl = xq + 4 * K * 8;                  // (at most 4 rows per workgroup)
-    if (active && (lane & 15) < K) { xq[4 * h + (lane >> 4)] = quad; xl[4 * h + (lane >> 4)] = logdet; }
-    BSIG_FSTAMP(4);
-    lds_barrier();
-    BSIG_FSTAMP(5);
-    float qs, ls;
-    {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xq), a1 = *reinterpret_cast<const f32x4*>(xq + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(xl), b1 = *reinterpret_cast<const f32x4*>(xl + 4);
-      qs = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a1[0] + a1[1]) + (a1[2] + a1[3]));
-      ls = ((b0[0] + b0[1]) + (b0[2] + b0[3])) + ((b1[0] + b1[1]) + (b1[2] + b1[3]));
-    }
-    const float logp = -0.5f * qs - ls - (float)D * kHalfLog2Pi;
-    const float lp = fminf(fmaxf(logp, -p.ll_limit), p.ll_limit);
-    const float rv = lp + lw;
-    bad |= active && !(isfinite(w_own) && isfinite(logp) && isfinite(rv));
-    // logsumexp over the components (mdnn.py:163-178)
-    const float m2 = kgroup_max<K>(rv);
-    const float se = kgroup_sum<K>(expf(rv - m2));
-    lse = m2 + logf(se);
-    const float sc = -expf(rv - lse) * p.inv_norm;
-    const float g_lp = (logp >= -p.ll_limit && logp <= p.ll_limit) ? sc : 0.f;
-    // ---- backward ----------------------------------------------------------------------------------
-    float dmu[NQH], dpre[NQH];
-#pragma unroll
-    for (int i = 0; i < NQH; ++i) {
-      const float dsg = g_lp * __builtin_fmaf(ez[i], ez[i], -1.0f) / rsg[i];
-      uds = valid[i] ? __builtin_fmaf(eu[i], dsg, uds) : uds;
-      dmu[i] = g_lp * ez[i] / rsg[i];
-      dpre[i] = dsg * ev[i];
-    }
-    const float gw = (w_own >= p.min_w && w_own <= 1.0f) ? sc / wc : 0.f;
-    const float s1 = kgroup_sum<K>(gw * w_own);
-    const float gsv = (s_own >= p.min_w && s_own <= 1.0f) ? (gw - s1) / csum : 0.f;
-    const float s2 = kgroup_sum<K>(gsv * s_own);
-    const float dlogit = s_own * (gsv - s2);
+    float dmu[NQH], dpre[NQH], dlogit;
+    float* xq = XS + ((active ? rr : 0) * KP + k) * 8;      // the pair's exchange: [row][k][8] quad | + 4 KP 8: logdet
+    diag_row_fast_core<KP, NQH>(K, D, active, kok, valid, muv, yd, eu, ev, lg_own, p.min_w, p.ll_limit, p.inv_norm,
+                                xq, xq + 4 * KP * 8, h, lane, ge, [] { lds_barrier(); }, dmu, dpre, dlogit, lse, uds, bad);
   BSIG_FSTAMP(6);
     BSIG_USTAMP(7);
     // ---- d_out row (without the jitter-scale term) and exp(pre), 16 bytes per quad -------------------
     const __amdgpu_buffer_rsrc_t dr = xwg_buffer(p.d_out + (int64_t)(active ? row : 0) * NhP);
+    float* drow = p.d_out + (int64_t)(active ? row : 0) * NhP;
 #pragma unroll
     for (int i = 0; i < NQH; ++i) {
       const f32x4 qm = quad_gather(dmu[i]), qp = quad_gather(dpre[i]);
-      const int col = (lane & ~3) + (h + 2 * i) * 64;
-      if (valid[i] && (lane & 3) == 0) {
-        xwg_store4(dr, K + col, qm[0], qm[1], qm[2], qm[3]);
-        xwg_store4(dr, K + DK + col, qp[0], qp[1], qp[2], qp[3]);
+      if (exact) {
+        if (valid[i] && (lane & 3) == 0) {
+          xwg_store4(dr, K + ecol[i], qm[0], qm[1], qm[2], qm[3]);
+          xwg_store4(dr, K + DK + ecol[i], qp[0], qp[1], qp[2], qp[3]);
+        }
+      } else if (valid[i]) {
+        xwg_store(drow + K + ecol[i], dmu[i]);
+        xwg_store(drow + K + DK + ecol[i], dpre[i]);
       }
     }
     {
       const f32x4 ql = quad_gather(dlogit);
-      if (active && h == 0 && lane < K && (lane & 3) == 0) xwg_store4(dr, lane, ql[0], ql[1], ql[2], ql[3]);
+      if (exact) {
+        if (active && h == 0 && lane < K && (lane & 3) == 0) xwg_store4(dr, lane, ql[0], ql[1], ql[2], ql[3]);
+      } else if (active && h == 0 && lane < KP && kok) {
+        xwg_store(drow + k, dlogit);
+      }
     }
     // Every row wavefront publishes for itself: its stores acknowledged, then ITS sum of u * dL/dsigma
     // (slot own * 2R + wavefront; the tile workgroups add the granules of all row wavefronts in slot
@@ -1441,9 +1378,7 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
 }
 
 // ---- a workgroup without a tile: row owner (and evaluation owner) only -------------------------
-// FK: components of the fast row (u_own_update_fast), 0: the shape-generic row; NQH: sweeps per wavefront
-template <int FK, int NQH>
-__device__ __forceinline__ void owner_only_loop(const UArgs& p, float* smem, const URole& role, int NBW, bool dp) {
+__device__ __forceinline__ void owner_only_workgroup(const UArgs& p, float* smem, const URole& role, int NBW, bool dp) {
   float* XS = smem + p.KS * kUFP + NBW * p.WP;      // (the layout of the tile workgroups)
   float* red = XS + p.xs_floats;
   const int tid = threadIdx.x, lane0 = tid & 63;
@@ -1455,6 +1390,7 @@ __device__ __forceinline__ void owner_only_loop(const UArgs& p, float* smem, con
   const bool has_row = role.owner < p.n_owner;
   const int eo = (role.owner - p.n_owner + p.T) % p.T;
   const bool has_erow = p.do_eval && eo < p.NE;
+  const int fk = u_fast_kind(p);                    // (one loop, the row picked per update: the evaluation code once)
   int pending_eval = -1;
   for (int t = 0; t < p.n_updates; ++t) {
     const int step = o.step0 + t;
@@ -1463,8 +1399,18 @@ __device__ __forceinline__ void owner_only_loop(const UArgs& p, float* smem, con
     if (run_aborted(flagp, red, tid)) break;
     BSIG_USTAMP(0);
     if (has_row) {
-      if constexpr (FK != 0) u_own_update_fast<FK, NQH>(p, o, t, w, lane0, wg);
-      else u_own_update(p, o, t, w, lane0, wg);
+      switch (fk) {
+        case 4 * 8 + 1: u_own_update_fast<4, 1>(p, o, t, w, lane0, wg); break;
+        case 4 * 8 + 2: u_own_update_fast<4, 2>(p, o, t, w, lane0, wg); break;
+        case 4 * 8 + 4: u_own_update_fast<4, 4>(p, o, t, w, lane0, wg); break;
+        case 8 * 8 + 1: u_own_update_fast<8, 1>(p, o, t, w, lane0, wg); break;
+        case 8 * 8 + 2: u_own_update_fast<8, 2>(p, o, t, w, lane0, wg); break;
+        case 8 * 8 + 4: u_own_update_fast<8, 4>(p, o, t, w, lane0, wg); break;
+        case 16 * 8 + 1: u_own_update_fast<16, 1>(p, o, t, w, lane0, wg); break;
+        case 16 * 8 + 2: u_own_update_fast<16, 2>(p, o, t, w, lane0, wg); break;
+        case 16 * 8 + 4: u_own_update_fast<16, 4>(p, o, t, w, lane0, wg); break;
+        default: u_own_update(p, o, t, w, lane0, wg); break;
+      }
     }
     if (__builtin_expect(pending_eval >= 0, 0)) {
       __syncthreads();
@@ -1484,12 +1430,6 @@ __device__ __forceinline__ void owner_only_loop(const UArgs& p, float* smem, con
       if (has_erow) u_owner_eval(p, XS, red, eo, e, u_eval_stream(p, o, e, true), o.a);
     }
   }
-}
-__device__ __forceinline__ void owner_only_workgroup(const UArgs& p, float* smem, const URole& role, int NBW, bool dp) {
-  const int nqh = u_fast_kind(p);
-  if (nqh == 0) owner_only_loop<0, 0>(p, smem, role, NBW, dp);
-  else if (p.K == 4) { if (nqh == 1) owner_only_loop<4, 1>(p, smem, role, NBW, dp); else owner_only_loop<4, 2>(p, smem, role, NBW, dp); }
-  else { if (nqh == 1) owner_only_loop<8, 1>(p, smem, role, NBW, dp); else owner_only_loop<8, 2>(p, smem, role, NBW, dp); }
 }
 
 template <bool DP, int NT, bool XR = false>

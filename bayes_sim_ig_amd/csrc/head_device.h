@@ -5,6 +5,7 @@
 
 namespace bsig {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr int kSigMax = 4096;       // capacity of the exp(pre) partial-sum array
 constexpr int kSigBlocks = 512;     // blocks of the stand-alone sigma0_sum kernel
@@ -530,6 +531,124 @@ __device__ __forceinline__ void diag_row_capped(const HeadArgs& a, int row, bool
   diag_row_impl<NQCAP>(a, rg, row, active, lane, tile, yv, rk, lpk, dlg, e, out, nullptr);
 }
 #endif
+
+// ---- diagonal covariance: the FAST row of the persistent kernels' owners (round 6) -------------------
+// One row on TWO wavefronts (wavefront h in {0, 1} takes the sweeps h, h + 2, ...), lane = d-slot * KP + k
+// with the component count padded to KP in {4, 8, 16} (the lanes k >= K of a group idle and enter the
+// butterflies with the neutral element): the lanes of a component's dimensions sit at a stride of KP inside
+// the 16-lane DPP rows, and KP adjacent lanes hold the components.  Sums over the dimensions: DPP row
+// rotations, then ONE exchange through LDS (xq / xl: 8 floats per component -- 4 DPP rows x 2 wavefronts
+// --, `bar()` a barrier both wavefronts pass), read back by EVERY lane; mixture weights, logsumexp and
+// the logit gradients by DPP butterflies over the KP adjacent lanes, redundantly in every lane: no
+// broadcast step, no second exchange.  Same formulas and IEEE divisions as diag_row_body; the summation
+// orders differ.  In: per sweep i of this wavefront valid / mu / y / jitter draw u / exp(pre); the
+// lane's component's logit.  Out: d mu, d pre (without the jitter-scale term) per sweep, the component's
+// logit gradient, the row's logsumexp, this wavefront's lanes' partial sums of u * dL/dsigma.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// all-reduce over the K adjacent lanes of an aligned group (K = 4, 8, 16): xor 1, xor 2, mirror of 8, mirror of 16
+template <int K>
+__device__ __forceinline__ float kgroup_sum(float v) {
+  v += dpp_mov<0xB1>(v);                            // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4E>(v);                            // quad_perm:[2,3,0,1]
+  if constexpr (K >= 8) v += dpp_mov<0x141>(v);     // row_half_mirror
+  if constexpr (K >= 16) v += dpp_mov<0x140>(v);    // row_mirror
+  return v;
+}
+template <int K>
+__device__ __forceinline__ float kgroup_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  if constexpr (K >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+  if constexpr (K >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+// all-reduce over the 16 / K lanes of a DPP row that hold the same component (stride K): rotations by 8, 4
+template <int K>
+__device__ __forceinline__ float dslots_sum(float v) {
+  if constexpr (K <= 8) v += dpp_mov<0x128>(v);     // row_ror:8
+  if constexpr (K <= 4) v += dpp_mov<0x124>(v);     // row_ror:4
+  return v;
+}
+// the four values of the lane's quad
+__device__ __forceinline__ f32x4 quad_gather(float v) {
+  f32x4 q = {dpp_mov<0x00>(v), dpp_mov<0x55>(v), dpp_mov<0xAA>(v), dpp_mov<0xFF>(v)};
+  return q;
+}
+
+// (Contraction of multiplies and adds is off, as in diag_row_body.)
+template <int KP, int NQH, typename Eps, typename Bar>
+__device__ __forceinline__ void diag_row_fast_core(int K, int D, bool active, bool kok, const bool (&valid)[NQH],
+                                                   const float (&muv)[NQH], const float (&yd)[NQH], float (&eu)[NQH],
+                                                   const float (&ev)[NQH], float lg_own, float min_w, float ll_limit,
+                                                   float inv_norm, float* xq, float* xl, int h, int lane,
+                                                   Eps& eps_src, Bar&& bar, float (&dmu)[NQH], float (&dpre)[NQH],
+                                                   float& dlogit, float& lse, float& uds, bool& bad) {
+#pragma clang fp contract(off)
+  (void)K;
+  // ---- mixture weights (mdnn.py:109-111), every lane its component -------------------------------
+  const float mx = kgroup_max<KP>(kok ? lg_own : -INFINITY);
+  const float e_own = kok ? expf(lg_own - mx) : 0.f;
+  const float s_own = e_own / kgroup_sum<KP>(e_own);
+  const float c_own = kok ? fminf(fmaxf(s_own, min_w), 1.0f) : 0.f;
+  const float csum = kgroup_sum<KP>(c_own);
+  const float w_own = c_own / csum;
+  const float wc = fminf(fmaxf(w_own, min_w), 1.0f);     // the second clamp, mdnn.py:160
+  const float lw = logf(wc);
+  const float eps = eps_src.get();
+  // ---- elements: sigma, z, log sigma ------------------------------------------------------------
+  float quad = 0.f, logdet = 0.f, ez[NQH], rsg[NQH];
+#pragma unroll
+  for (int i = 0; i < NQH; ++i) {
+    float sg = ev[i];
+    if (eps != 0.f) sg = __builtin_fmaf(eu[i], eps, sg);
+    else eu[i] = 0.f;
+    if (!valid[i]) sg = 1.f;
+    bad |= valid[i] && !(isfinite(muv[i]) && isfinite(sg));
+    const float z = valid[i] ? (yd[i] - muv[i]) / sg : 0.f;
+    quad += z * z;
+    logdet += logf(sg);
+    ez[i] = z; rsg[i] = sg;
+  }
+  // sums over the dimensions of each component: inside the DPP rows, then 4 rows x 2 wavefronts through LDS
+  quad = dslots_sum<KP>(quad);
+  logdet = dslots_sum<KP>(logdet);
+  if (active && (lane & 15) < KP) { xq[4 * h + (lane >> 4)] = quad; xl[4 * h + (lane >> 4)] = logdet; }
+  bar();
+  float qs, ls;
+  {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xq), a1 = *reinterpret_cast<const f32x4*>(xq + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(xl), b1 = *reinterpret_cast<const f32x4*>(xl + 4);
+    qs = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a1[0] + a1[1]) + (a1[2] + a1[3]));
+    ls = ((b0[0] + b0[1]) + (b0[2] + b0[3])) + ((b1[0] + b1[1]) + (b1[2] + b1[3]));
+  }
+  const float logp = -0.5f * qs - ls - (float)D * kHalfLog2Pi;
+  const float lp = fminf(fmaxf(logp, -ll_limit), ll_limit);
+  const float rv = lp + lw;
+  bad |= active && kok && !(isfinite(w_own) && isfinite(logp) && isfinite(rv));
+  // logsumexp over the components (mdnn.py:163-178)
+  const float m2 = kgroup_max<KP>(kok ? rv : -INFINITY);
+  const float se = kgroup_sum<KP>(kok ? expf(rv - m2) : 0.f);
+  lse = m2 + logf(se);
+  const float sc = -expf(rv - lse) * inv_norm;
+  const float g_lp = (logp >= -ll_limit && logp <= ll_limit) ? sc : 0.f;
+  // ---- backward ----------------------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < NQH; ++i) {
+    const float dsg = g_lp * __builtin_fmaf(ez[i], ez[i], -1.0f) / rsg[i];
+    uds = valid[i] ? __builtin_fmaf(eu[i], dsg, uds) : uds;
+    dmu[i] = g_lp * ez[i] / rsg[i];
+    dpre[i] = dsg * ev[i];
+  }
+  const float gw = (kok && w_own >= min_w && w_own <= 1.0f) ? sc / wc : 0.f;
+  const float s1 = kgroup_sum<KP>(gw * w_own);
+  const float gsv = (kok && s_own >= min_w && s_own <= 1.0f) ? (gw - s1) / csum : 0.f;
+  const float s2 = kgroup_sum<KP>(gsv * s_own);
+  dlogit = s_own * (gsv - s2);
+
+}
 
 // jitter draw of element (row, d, k) for the thread-per-component kernels (full covariance)
 __device__ inline float jitter_u(const HeadArgs& a, int row, int d, int k) {
