@@ -304,6 +304,10 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
                ((reinterpret_cast<uintptr_t>(b.params) | reinterpret_cast<uintptr_t>(b.exp_avg) |
                  reinterpret_cast<uintptr_t>(b.exp_avg_sq) | reinterpret_cast<uintptr_t>(b.grads)) & 7) == 0) ? 1 : 0;
   p.wh_off = b.wh_off; p.bh_off = b.bh_off;
+  {
+    static const int fast_rows = [] { const char* e = getenv("BSIG_MDNN_FAST_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
+    p.fast_rows = fast_rows;
+  }
   p.state = b.state; p.train_loss = b.train_loss;
   p.lr = hy.lr; p.beta1 = hy.beta1; p.beta2 = hy.beta2;
   p.adam_eps = hy.adam_eps; p.eps_noise = hy.eps_noise; p.min_w = hy.min_weight;

@@ -77,6 +77,7 @@ struct MdnnArgs {
   // *xr_done and take their Adam step from the reduced `grads`
   unsigned* xr_ready; const unsigned* xr_done; unsigned* xr_count; unsigned xr_base;
   int pair_ok;                       // rows of W1 are 8-byte aligned pairs (w1_off, I even)
+  int fast_rows;                     // (A/B runs: BSIG_MDNN_FAST_ROWS=0 keeps the shape-generic row)
   // held-out evaluations inside the launch (mdnn.py:235-242; do_eval), as in
   // fit_persistent.hip: the tile workgroups form the held-out rows' first-layer products
   // while they wait for the row owners of the NEXT update (their LDS still holds the
@@ -1228,6 +1229,51 @@ __device__ __forceinline__ void heads_fma_chain(const float* H2s, const float* W
   }
 }
 
+// The row-wise phase of an owner on the lean two-wavefront row (head_device.h: diag_row_fast_core): the
+// lane's elements from the head-output row image `tile` (Os), the target from `yv`; writes the gradients of
+// ITS elements (without the jitter-scale term) back into the image, the logit gradients from wavefront 0.
+// ro: lse, this wavefront's lanes' partial sums of u dL/dsigma, esg0[i] = exp(pre) of sweep hw + 2 i.
+// `xch`: the pair's exchange, [KP][8] floats (+ 4 KP 8: the log-determinants).
+template <int KP, int NQH, typename Eps>
+__device__ __forceinline__ void mdnn_fast_row(const MdnnArgs& p, int K, int D, bool active, int lane, int hw,
+                                              float* tile, const float* yv, float* xch, const float* eu_pre,
+                                              Eps& ge, RowOut& ro) {
+  constexpr int GR = 64 / KP;
+  const int DK = D * K;
+  const int k = lane & (KP - 1), d0 = lane / KP;
+  const bool kok = k < K;
+  bool valid[NQH];
+  float muv[NQH], yd[NQH], eu[NQH], ev[NQH], dmu[NQH], dpre[NQH];
+  int ecol[NQH];
+#pragma unroll
+  for (int i = 0; i < NQH; ++i) {
+    const int d = d0 + (hw + 2 * i) * GR;
+    valid[i] = active && kok && d < D;
+    ecol[i] = min(d, D - 1) * K + min(k, K - 1);
+    ev[i] = tile[K + DK + ecol[i]];
+    muv[i] = tile[K + ecol[i]];
+    yd[i] = yv[min(d, D - 1)];
+    eu[i] = eu_pre[i];
+  }
+  const float lg_own = tile[min(k, K - 1)];
+  ge.issue();
+#pragma unroll
+  for (int i = 0; i < NQH; ++i) ev[i] = valid[i] ? expf(ev[i]) : 0.f;
+  float dlogit = 0.f, lse = 0.f, uds = 0.f;
+  bool bad = false;
+  float* xq = xch + k * 8;
+  diag_row_fast_core<KP, NQH>(K, D, active, kok, valid, muv, yd, eu, ev, lg_own, p.min_w, p.ll_limit, p.inv_norm,
+                              xq, xq + 4 * KP * 8, hw, lane, ge, [] { lds_barrier(); }, dmu, dpre, dlogit, lse, uds, bad);
+#pragma unroll
+  for (int i = 0; i < NQH; ++i) {
+    ro.esg0[i] = ev[i];
+    if (valid[i]) { tile[K + ecol[i]] = dmu[i]; tile[K + DK + ecol[i]] = dpre[i]; }
+  }
+  if (active && hw == 0 && lane < KP && kok) tile[k] = dlogit;
+  __builtin_amdgcn_wave_barrier();
+  ro.lse = lse; ro.uds = uds; ro.bad = bad;
+}
+
 template <bool DP, bool WIDE, bool FULL, int MR = kMR>
 __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* smem) {
   const int Nh = p.Nh, Nh16 = p.Nh16, D = p.D, K = p.K, DK = D * K, B = p.B;
@@ -1236,6 +1282,19 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   // rows of a 16-row MFMA result this owner keeps (lanes g == 0 hold result rows 0..3: with fewer than
   // four rows per owner the others repeat its rows -- `rowA` wraps -- and belong to nobody here)
   constexpr int RQ = MR < 4 ? MR : 4;
+  // FAST (round 6): the row-wise phase on two wavefronts per row with the lean row of head_device.h
+  // (diag_row_fast_core: component count padded to 4 / 8 / 16 lanes, DPP reductions) -- diagonal
+  // covariance, at most four rows per owner (eight wavefronts), K <= 16, at most 8 sweeps; the pairs'
+  // exchange lives where the k-slice sums' partial quads were (free since h1).  fk = KP * 8 + sweeps per
+  // wavefront, 0: the shape-generic row (BSIG_MDNN_FAST_ROWS=0).
+  constexpr bool PAIR = !FULL && MR <= 4;
+  int fk = 0;
+  if constexpr (PAIR) {
+    if (K <= 16 && p.fast_rows) {
+      const int KPr = K <= 4 ? 4 : (K <= 8 ? 8 : 16), nq = (D + 64 / KPr - 1) / (64 / KPr);
+      if (nq <= 8) fk = KPr * 8 + (nq <= 2 ? 1 : (nq <= 4 ? 2 : 4));
+    }
+  }
   float* Whs = smem;                         // [Nh16][128], element (n, i) at n*128 + (i ^ 4(n & 15))
   float* H1s = Whs + (WIDE ? 0 : Nh16 * kMH);   // [MR][kMHP]  (wide heads: no head matrix here)
   float* H2s = H1s + MR * kMHP;             // [MR][kMHP]  h2, later dz2 in place
@@ -1484,10 +1543,15 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     asm volatile("" : "+v"(c16), "+v"(g), "+v"(tid));
     asm volatile("" : "+s"(w));
     const int lane = tid & 63, rowA = c16 & (MR - 1);
-    const int row = r0 + w;
-    const bool active = w < MR && row < B;
-    float* tile = Os + (w & (MR - 1)) * po;
-    float* yv = wsc + (w & (MR - 1)) * per_wave;
+    // (fast rows: wavefronts 2r, 2r + 1 run row r0 + r in the row-wise phase; else wavefront w runs row r0 + w.
+    // The target row is loaded by wavefront r < MR either way: `yrow_w`.)
+    const bool fast = PAIR && fk != 0;
+    const int rw = fast ? w >> 1 : w, hw = fast ? w & 1 : 0;
+    const bool row_wave = w < (fast ? 2 * MR : MR);
+    const int row = r0 + rw;
+    const bool active = row_wave && row < B;
+    float* tile = Os + (rw & (MR - 1)) * po;
+    float* yv = wsc + (rw & (MR - 1)) * per_wave;
     float* rk = yv + D;
     float* lpk = rk + K;
     float* dlg = lpk + K;
@@ -1499,9 +1563,10 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
     // ---- weights of this update (written by the small-weight workgroups) ---------
     // (first update of a launch, and the only one of a data-parallel launch: flag_pack above)
     // (wide heads: the owners only need W2 / b2 -- the first four small-weight workgroups)
-    if (active) {      // target row: two dependent loads, issued before the wait instead of after the weights
-      const int64_t yrow = p.ids[(int64_t)step * B + row];
-      for (int j = lane; j < D; j += 64) yv[j] = p.y[yrow * p.ldy + j];
+    if (w < MR && r0 + w < B) {      // target row: two dependent loads, issued before the wait instead of after the weights
+      const int64_t yrow = p.ids[(int64_t)step * B + r0 + w];
+      float* yw = wsc + w * per_wave;
+      for (int j = lane; j < D; j += 64) yw[j] = p.y[yrow * p.ldy + j];
     }
     // one jitter stream per update and per evaluation, in program order; the row's draws do not depend
     // on the forward product: taken here, in the wait
@@ -1509,7 +1574,24 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
                   (uint64_t)(p.do_eval ? mdnn_evals_before(step, p.eval_every) - ev0 : 0);
     float eu_pre[kElemsPerLane];
     if constexpr (!FULL) {
-      if (w < MR) diag_row_noise(a, rg0.groups, rg0.k, rg0.d0, row, active, lane, eu_pre);
+      if (fast) {
+        // the draw of element (d, k) is diag_row_noise's (the generic row's lane (d % G) * K + k, sweep d / G);
+        // eu_pre[i]: sweep hw + 2 i of this wavefront in the padded lane geometry
+        const int KPr = fk >> 3, GRr = 64 / KPr, kk = lane & (KPr - 1), dd0 = lane / KPr, G = rg0.groups;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int d = dd0 + (hw + 2 * i) * GRr;
+          eu_pre[i] = 0.f;
+          if (active && kk < K && d < D && a.eps_noise != 0.f && i < (fk & 7)) {
+            const int q = d / G, gl = (d - q * G) * K + kk;
+            const Philox4 ph = philox4x32_10(a.seed, a.stream_id, ((uint64_t)row * 64 + gl) * 2 + (q >> 2));
+            const int oi = q & 3;
+            eu_pre[i] = u01(oi == 0 ? ph.v[0] : (oi == 1 ? ph.v[1] : (oi == 2 ? ph.v[2] : ph.v[3])));
+          }
+        }
+      } else if (w < MR) {
+        diag_row_noise(a, rg0.groups, rg0.k, rg0.d0, row, active, lane, eu_pre);
+      }
     }
     if (!DP && t > 0 && w == 0)
       flags_wait(p.flag_small, WIDE ? kMH / kMNB : p.n_small, epoch - 1u, lane, flagp);
@@ -1709,16 +1791,34 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
       // (lane geometry from before the loop, jitter draws from the wait, the jitter-scale gather issued
       // ahead of the arithmetic that does not need it: head_device.h)
       GranuleEps ge{p.gran, p.n_owner, tag + 1, lane, flagp, p.eps_noise, norm, {0ull, 0ull, 0ull, 0ull}};
-      diag_row_impl(a, rg0, row, active, lane, tile, yv, rk, lpk, dlg, ge, ro, eu_pre);
+      if (fast) {
+        if (row_wave) {
+          switch (fk) {
+            case 4 * 8 + 1: mdnn_fast_row<4, 1>(p, K, D, active, lane, hw, tile, yv, part4 + (rw & (MR - 1)) * 4 * 8, eu_pre, ge, ro); break;
+            case 4 * 8 + 2: mdnn_fast_row<4, 2>(p, K, D, active, lane, hw, tile, yv, part4 + (rw & (MR - 1)) * 4 * 8, eu_pre, ge, ro); break;
+            case 4 * 8 + 4: mdnn_fast_row<4, 4>(p, K, D, active, lane, hw, tile, yv, part4 + (rw & (MR - 1)) * 4 * 8, eu_pre, ge, ro); break;
+            case 8 * 8 + 1: mdnn_fast_row<8, 1>(p, K, D, active, lane, hw, tile, yv, part4 + (rw & (MR - 1)) * 8 * 8, eu_pre, ge, ro); break;
+            case 8 * 8 + 2: mdnn_fast_row<8, 2>(p, K, D, active, lane, hw, tile, yv, part4 + (rw & (MR - 1)) * 8 * 8, eu_pre, ge, ro); break;
+            case 8 * 8 + 4: mdnn_fast_row<8, 4>(p, K, D, active, lane, hw, tile, yv, part4 + (rw & (MR - 1)) * 8 * 8, eu_pre, ge, ro); break;
+            case 16 * 8 + 1: mdnn_fast_row<16, 1>(p, K, D, active, lane, hw, tile, yv, part4 + (rw & (MR - 1)) * 16 * 8, eu_pre, ge, ro); break;
+            case 16 * 8 + 2: mdnn_fast_row<16, 2>(p, K, D, active, lane, hw, tile, yv, part4 + (rw & (MR - 1)) * 16 * 8, eu_pre, ge, ro); break;
+            default: mdnn_fast_row<16, 4>(p, K, D, active, lane, hw, tile, yv, part4 + (rw & (MR - 1)) * 16 * 8, eu_pre, ge, ro); break;
+          }
+        } else {
+          lds_barrier();                     // (the row wavefronts' exchange of partial sums)
+        }
+      } else {
+        diag_row_impl(a, rg0, row, active, lane, tile, yv, rk, lpk, dlg, ge, ro, eu_pre);
+      }
     }
     {
       const float uds_w = wave_sum_dpp(ro.uds);
-      if (lane == 0) { red[16 + w] = active ? ro.lse : 0.f; red[32 + w] = uds_w; }
+      if (lane == 0) { red[16 + w] = active && hw == 0 ? ro.lse : 0.f; red[32 + w] = uds_w; }
     }
     lds_barrier();
     if (tid == 0) {
       float sl = 0.f, su = 0.f;
-      for (int q = 0; q < MR; ++q) { sl += red[16 + q]; su += red[32 + q]; }
+      for (int q = 0; q < (fast ? 2 * MR : MR); ++q) { sl += red[16 + q]; su += red[32 + q]; }
       granule_publish(p.gran + kGranArr, o, tag + 2, su);
       granule_publish(loss_granules(p.gran, epoch), o, tag + 3, sl);
     }
@@ -1743,6 +1843,24 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
           if (c != 0.f)
             for (int j = lane; j < DK; j += 64) tile[K + DK + j] += c * sg0[j];
         } else {
+          if (fast) {
+            // (each wavefront of the pair: the elements of ITS sweeps -- the ones it wrote -- and their
+            // d_out columns; the logit gradients are already in the row image, wavefront 0 stores them)
+            const int KPr = fk >> 3, GRr = 64 / KPr, kk = lane & (KPr - 1), dd0 = lane / KPr;
+            float* dst = p.d_out + (int64_t)row * p.NhP;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int d = dd0 + (hw + 2 * i) * GRr;
+              if (i < (fk & 7) && kk < K && d < D) {
+                const int e = d * K + kk;
+                const float dp = tile[K + DK + e] + c * ro.esg0[i];
+                tile[K + DK + e] = dp;
+                xwg_store(dst + K + DK + e, dp);
+                xwg_store(dst + K + e, tile[K + e]);
+              }
+            }
+            if (hw == 0 && lane < K) xwg_store(dst + lane, tile[lane]);
+          } else {
           const int groups = 64 / K, TPR = groups * K;
           const int k = lane % K, d0 = lane / K;
           if (c != 0.f && lane < TPR) {
@@ -1752,12 +1870,15 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
               if (d < D) tile[K + DK + d * K + k] += c * ro.esg0[q];
             }
           }
+          }
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
-        __builtin_amdgcn_wave_barrier();
-        float* dst = p.d_out + (int64_t)row * p.NhP;
-        for (int j = lane; j < Nh; j += 64) xwg_store(dst + j, tile[j]);
+        if (!fast) {
+          __builtin_amdgcn_wave_barrier();
+          for (int j = lane; j < K; j += 64) tile[j] = dlg[j];
+          __builtin_amdgcn_wave_barrier();
+          float* dst = p.d_out + (int64_t)row * p.NhP;
+          for (int j = lane; j < Nh; j += 64) xwg_store(dst + j, tile[j]);
+        }
       }
     }
     if (ro.bad) atomicOr(flagp, 1);
