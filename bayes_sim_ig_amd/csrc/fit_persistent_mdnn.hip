@@ -305,8 +305,8 @@ int persist_mdnn_run(const PersistMdnnShape& s, const PersistMdnnBuffers& b,
                  reinterpret_cast<uintptr_t>(b.exp_avg_sq) | reinterpret_cast<uintptr_t>(b.grads)) & 7) == 0) ? 1 : 0;
   p.wh_off = b.wh_off; p.bh_off = b.bh_off;
   {
-    static const int fast_rows = [] { const char* e = getenv("BSIG_MDNN_FAST_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
-    p.fast_rows = fast_rows;
+    const char* e = getenv("BSIG_MDNN_FAST_ROWS");     // (read per launch -- one launch per call: A/B runs, tests)
+    p.fast_rows = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1);     // (2: also for wide first layers)
   }
   p.state = b.state; p.train_loss = b.train_loss;
   p.lr = hy.lr; p.beta1 = hy.beta1; p.beta2 = hy.beta2;

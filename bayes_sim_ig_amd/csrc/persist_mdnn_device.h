@@ -25,6 +25,7 @@ constexpr int kMR = 4;              // minibatch rows per owner workgroup (power
 constexpr int kStreamMR = 8;        // ... of a plan with a streamed first layer
 constexpr int kMPbuf = 33;
 constexpr int kMLdsLimit = 160 * 1024;
+constexpr int kFastRowsMaxInput = 4096;   // (mdnn_owner_workgroup: fast rows)
 
 struct MdnnArgs {
   int B, FR, I, Nh, Nh16, NhP, D, K;
@@ -1290,7 +1291,12 @@ __device__ __forceinline__ void mdnn_owner_workgroup(const MdnnArgs& p, float* s
   constexpr bool PAIR = !FULL && MR <= 4;
   int fk = 0;
   if constexpr (PAIR) {
-    if (K <= 16 && p.fast_rows) {
+    // (first layers wider than kFastRowsMaxInput inputs keep the shape-generic row: they amplify an ulp of the
+    // row arithmetic to ~1e-4 of held-out NLL within a chunk -- cfg3 I = 11802, cfg4b I = 11154: on their
+    // ill-conditioned seeds ANY change of summation order moves the result by more than the north-star
+    // tolerance, the reference's own fp32 path included (profiles/r06_NOTES.md) -- and the agreement of
+    // round 5's row with the reference on six seeds each is what their parity tests pinned)
+    if (K <= 16 && p.fast_rows && (p.I <= kFastRowsMaxInput || p.fast_rows == 2)) {
       const int KPr = K <= 4 ? 4 : (K <= 8 ? 8 : 16), nq = (D + 64 / KPr - 1) / (64 / KPr);
       if (nq <= 8) fk = KPr * 8 + (nq <= 2 ? 1 : (nq <= 4 ? 2 : 4));
     }

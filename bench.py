@@ -867,7 +867,12 @@ def per_config_numbers(pkg, device, skip):
                                        '-m gpu tests assert it on six seeds through the fp64 bracket |hip - f64| <= '
                                        '|cpu_f32 - f64| + 1e-4 |f64| and directly at 1e-4 only where the fp32 oracle '
                                        'is itself within 0.5e-4 of fp64 -- a relaxation of the north star, named here')
-                     if name == 'cfg3' else 'direct: |hip - fp32 oracle| / |oracle| of the first chunk <= 1e-4'}
+                     if name == 'cfg3' else
+                     ('direct: |hip - fp32 oracle| / |oracle| of the first chunk of THIS seed (north star 1e-4).  cfg4b '
+                      '(I = 11154) has one ill-conditioned seed of six on which the reference\'s fp32 path is itself '
+                      '3e-4 off its fp64 self: the -m gpu tests hold it to 2 x the spread of two fp32 evaluation orders '
+                      'of the reference + 1e-4, and directly to 1e-4 on the other five -- a relaxation, named here')
+                     if name == 'cfg4b' else 'direct: |hip - fp32 oracle| / |oracle| of the first chunk <= 1e-4'}
         if wide:
             # both protocols side by side: 20 updates (inside the fp32 horizon of these ill-conditioned
             # first layers) and the reference's 100 (where the oracle's own fp32 evaluation orders have

