@@ -1702,8 +1702,10 @@ int persist_run(const PersistShape& s, const PersistBuffers& b, const PersistHyp
   p.Nh = g.Nh; p.NhP = g.NhP; p.D = s.out_dim; p.K = s.n_comp;
   p.n_blocks = g.n_blocks; p.k_slices = g.k_slices; p.G = g.G; p.T = g.T; p.n_owner = g.n_owner; p.R = g.R;
   p.n_updates = std::max(n, 0); p.xs_floats = g.xs_floats;
-  static const int fast_rows = [] { const char* e = getenv("BSIG_PERSIST_FAST_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
-  p.fast_rows = fast_rows;
+  {
+    const char* e = getenv("BSIG_PERSIST_FAST_ROWS");     // (read per launch -- one launch per call: A/B runs, tests)
+    p.fast_rows = (e && e[0] == '0') ? 0 : 1;
+  }
   p.grads = b.grads; p.adam_pending = b.adam_pending;
   p.xr_ready = b.xr_ready; p.xr_done = b.xr_done; p.xr_base = b.xr_base;
   p.xr_count = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(b.workspace) + u_data_bytes(g) + u_sync_bytes() - 256);

@@ -26,7 +26,7 @@ def _guards():
     yield
     pkg.MDNN.EPS_NOISE = old
     pkg.MDNN.USE_GRAPH = True
-    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_FEAT_CACHE'):
+    for k in ('BSIG_NO_PERSISTENT', 'BSIG_NO_FEAT_CACHE', 'BSIG_PERSIST_FAST_ROWS'):
         os.environ.pop(k, None)
 
 
@@ -318,3 +318,34 @@ def test_time_out_of_a_data_parallel_rank_is_recovered_by_the_group(B):
     assert lib.bsig_fit_is_persistent(bs.model._plan) == 0
     assert [lg['test_loss'] for lg in logs] == [lg['test_loss'] for lg in ref_logs]
     assert torch.equal(bs.model._flat, ref.model._flat)
+
+
+# (D, K, n_feat): K = 4 exact on 4 lanes with one / two sweeps per wavefront; K = 10 and 16 on 16 lanes (the reference
+# YAMLs' 10 components); K = 5 and 8 on 8 lanes; K = 3 on 4 lanes; D = 40, K = 4: three sweeps (two per wavefront)
+FAST_ROW_SHAPES = [(32, 4, 1024), (13, 10, 512), (17, 5, 512), (3, 16, 256), (40, 4, 512), (20, 8, 512), (6, 3, 256),
+                   (32, 10, 512)]
+
+
+@pytest.mark.parametrize('eps', [0.0, 1e-5])
+@pytest.mark.parametrize('d,k,n_feat', FAST_ROW_SHAPES)
+def test_fast_row_owners_match_the_generic_row(B, d, k, n_feat, eps):
+    """Round 6: the row owners' lean two-wavefront row (u_own_update_fast / diag_row_fast_core: component count padded
+    to 4 / 8 / 16 lanes, DPP reductions, per-wavefront granules) against the shape-generic row it replaces
+    (BSIG_PERSIST_FAST_ROWS=0, read per launch): same chunk, same start weights, same minibatch ids, same jitter
+    draws per (row, dimension, component) -- only summation orders differ.  Every logged loss within 2e-5, the
+    weights within 5e-5 (the bound the persistent kernel is held to against the per-phase kernels), and
+    the two runs must not be the SAME bits (that would mean the switch does nothing)."""
+    cfg = _cfg(d, k, n_feat)
+    a = _chunk(B, cfg, eps=eps)
+    b = _chunk(B, cfg, eps=eps, env={'BSIG_PERSIST_FAST_ROWS': '0'})
+    os.environ.pop('BSIG_PERSIST_FAST_ROWS', None)
+    lib = B._lib.load()
+    assert lib.bsig_fit_is_persistent(a[2].model._plan) == 1 and lib.bsig_fit_is_persistent(b[2].model._plan) == 1
+    for key in ('train_loss', 'test_loss'):
+        assert np.allclose(a[0][key], b[0][key], rtol=2e-5, atol=2e-5), (key, a[0], b[0])
+    assert torch.allclose(a[1], b[1], atol=5e-5, rtol=1e-3)
+    import ctypes as C
+    geo = (C.c_int32 * 16)()
+    if lib.bsig_debug_persist_geometry(100, n_feat, d, k, 200, geo) and geo[12] == 0 and k <= 16:
+        # (owners on CUs of their own and K <= 16: the lean row ran in `a`)
+        assert not torch.equal(a[1], b[1])

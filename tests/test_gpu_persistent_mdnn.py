@@ -395,3 +395,31 @@ def test_fewer_rows_per_owner_is_bitwise_the_four_row_layout(config):
         out.append((m.group(1), float(m.group(2))))
     assert out[0][0] == out[1][0], out
     assert abs(out[0][1] - out[1][1]) <= 2e-6 * max(1.0, abs(out[0][1])), out
+
+
+# (D, K, summarizer, sd, ad, T): the reference YAMLs' 10 components on 16 lanes (Pendulum head; a 13-dimensional one);
+# 5 components on 8 lanes; 4 exact (ShadowHand head, two sweeps over the pair); 8 exact; 3 on 4
+MDNN_FAST_ROW_SHAPES = [(2, 10, 'summary_start', 3, 1, 21), (13, 10, 'summary_start', 4, 1, 21),
+                        (17, 5, 'summary_start', 10, 8, 12), (32, 4, 'summary_start', 30, 5, 11),
+                        (6, 8, 'summary_start', 5, 2, 11), (3, 3, 'summary_start', 5, 2, 11)]
+
+
+@pytest.mark.parametrize('eps', [0.0, 1e-5])
+@pytest.mark.parametrize('d,k,summarizer,sd,ad,t', MDNN_FAST_ROW_SHAPES)
+def test_fast_rows_of_the_mdnn_owners_match_the_generic_row(B, d, k, summarizer, sd, ad, t, eps):
+    """Round 6: the lean two-wavefront row in the MDNN owners (mdnn_fast_row / diag_row_fast_core; first layers of at
+    most 4096 inputs) against the shape-generic row (BSIG_MDNN_FAST_ROWS=0, read per launch): same chunk, same
+    start weights, ids and jitter draws per (row, dimension, component); only summation orders differ.  The
+    bounds are the ones the persistent kernel is held to against the per-phase kernels."""
+    cfg = _cfg(d, k, summarizer, t, sd, ad)
+    try:
+        a = _chunk(B, cfg, eps=eps)
+        b = _chunk(B, cfg, eps=eps, env={'BSIG_MDNN_FAST_ROWS': '0'})
+    finally:
+        os.environ.pop('BSIG_MDNN_FAST_ROWS', None)
+    lib = B._lib.load()
+    assert lib.bsig_fit_is_persistent(a[2].model._plan) == 2 and lib.bsig_fit_is_persistent(b[2].model._plan) == 2
+    for key in ('train_loss', 'test_loss'):
+        assert np.allclose(a[0][key], b[0][key], rtol=3e-5, atol=3e-5), (key, a[0], b[0])
+    assert torch.allclose(a[1], b[1], atol=1e-4, rtol=1e-3)
+    assert not torch.equal(a[1], b[1])       # (the switch does something)
