@@ -855,7 +855,7 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int v = 0; v < 4; ++v) { Mr[jj][nt][v] = 0.f; Vr[jj][nt][v] = 0.f; }
-  float bw[NT], bm[NT], bv[NT];                // biases of the block and their moments: wave 7, lanes < 16
+  float bw[NT], bm[NT], bv[NT];                // biases of the block and their moments: 16-row block nt on wave 8 - NT + nt, lanes < 16
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { bw[nt] = 0.f; bm[nt] = 0.f; bv[nt] = 0.f; }
   if (has_tile) {
@@ -954,9 +954,10 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
           for (int v = 0; v < 4; ++v)
             if (w + 8 * jj < p.KB) Wl[(16 * nt + 4 * g4 + v) * WP + 16 * (w + 8 * jj) + c16] = Wv[jj][nt][v];
     }
-    if (ks == 0 && w == 7 && g4 == 0) {
+    if (ks == 0 && w >= 8 - NT && g4 == 0) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        if (w != 8 - NT + nt) continue;
         const int n = n0 + 16 * nt + c16;
         if (n < Nh) {
           bw[nt] = p.params[p.b_off + n];
@@ -1151,33 +1152,6 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
       }
       __syncthreads();
       BSIG_USTAMP(11);
-      if (ks == 0 && w == 7) {
-        // biases of this block: sums of the d_out^T rows (lane (c16, g4) takes a quarter of the
-        // minibatch, the quarters combine by butterfly shuffles), Adam on lanes < 16
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          float g = 0.f;
-          const float* xp = XS + (16 * nt + c16_l) * FP + 4 * g4_l;
-#pragma unroll
-          for (int S = 0; S < kUMT; ++S) {
-            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp + 16 * S);
-            g += (x4[0] + x4[1]) + (x4[2] + x4[3]);
-          }
-          g += __shfl_xor(g, 16, 64);
-          g += __shfl_xor(g, 32, 64);
-          if (g4_l == 0) {
-            const int n = n0 + 16 * nt + c16_l;
-            if (DP) {
-              if (n < Nh) p.grads[p.b_off + n] = g;
-            } else if constexpr (XR) {
-              if (n < Nh) xwg_store(p.grads + p.b_off + n, g);      // (Adam behind the exchange, below)
-            } else {
-              bw[nt] = adam_bias(g, bm[nt], bv[nt], bw[nt], a0, a1, ak);
-              biasl[16 * nt + c16_l] = bw[nt];
-            }
-          }
-        }
-      }
       const int n4 = (B + 3) >> 2;
       // (XR) gradient tile <-> p.grads: byte offset of this lane's 16 bytes in block 0 of tile 0
       // (blocks [0, xr_kb) of this k-slice hold columns < Fdim; in the last of them, when Fdim is not a
@@ -1193,34 +1167,64 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
       for (int jj = 0; jj < MAXBLK; ++jj) {
         const int j = w + 8 * jj;
         if (j < p.KB) {            // (wavefront-uniform; no run-time bound inside)
-          f32x4 acc[NT], b4[kUMT];
-          const float* bp = Ft + (16 * j + c16_l) * FP + 4 * g4_l;
+          f32x4 acc[NT];
+          // the block's weights: requested in front of the products, not one by one between the Adam steps
+          // (eight LDS round trips in a row, each waited for: the compiler cannot tell the addresses apart)
+          [[maybe_unused]] float wv[NT][4];
+          if constexpr (!DP && !XR) {
 #pragma unroll
-          for (int S = 0; S < kUMT; ++S) b4[S] = *reinterpret_cast<const f32x4*>(bp + 16 * S);
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) wv[nt][v] = Wl[(16 * nt + 4 * g4_l + v) * WP + 16 * j + c16_l];
+          }
+          const float* bp = Ft + (16 * j + c16_l) * FP + 4 * g4_l;
           // Groups of 4 minibatch rows: n4 = ceil(B / 4) MFMAs per accumulator would do; the reference's
           // minibatch of 100 rows (n4 = 25: 6 steps and one MFMA) has its own straight-line variant, any
           // other size runs all 7 steps (the padding rows are zeros) -- a test per step costs more than
           // the three MFMAs it saves (every step its own basic block: 4.0 -> 4.6 us for the phase).
+          // The NT accumulators advance TOGETHER, step by step: one F^T quad and NT d_out^T quads feed
+          // 4 NT MFMAs, the quads of the next step are in flight meanwhile (accumulator after accumulator
+          // the seven F^T quads had to stay in registers across the first chain and the scheduler, short of
+          // registers, waited for every pair of reads right in front of its four MFMAs).  Each accumulator
+          // still sums its steps in the same order.
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            f32x4 a4[kUMT];
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = zero;
+          f32x4 qa[2][NT], qb[2];
+          qb[0] = *reinterpret_cast<const f32x4*>(bp);
 #pragma unroll
-            for (int S = 0; S < kUMT; ++S) a4[S] = *reinterpret_cast<const f32x4*>(ap + nt * 16 * FP + 16 * S);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            acc[nt] = zero;
+          for (int nt = 0; nt < NT; ++nt) qa[0][nt] = *reinterpret_cast<const f32x4*>(ap + nt * 16 * FP);
 #pragma unroll
-            for (int S = 0; S < kUMT - 1; ++S) {
-              acc[nt] = umfma(a4[S][0], b4[S][0], acc[nt]);
-              acc[nt] = umfma(a4[S][1], b4[S][1], acc[nt]);
-              acc[nt] = umfma(a4[S][2], b4[S][2], acc[nt]);
-              acc[nt] = umfma(a4[S][3], b4[S][3], acc[nt]);
+          for (int S = 0; S < kUMT; ++S) {
+            if (S + 1 < kUMT) {
+              qb[(S + 1) & 1] = *reinterpret_cast<const f32x4*>(bp + 16 * (S + 1));
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                qa[(S + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(ap + nt * 16 * FP + 16 * (S + 1));
             }
-            acc[nt] = umfma(a4[kUMT - 1][0], b4[kUMT - 1][0], acc[nt]);
-            if (n4 != 4 * (kUMT - 1) + 1) {
-              acc[nt] = umfma(a4[kUMT - 1][1], b4[kUMT - 1][1], acc[nt]);
-              acc[nt] = umfma(a4[kUMT - 1][2], b4[kUMT - 1][2], acc[nt]);
-              acc[nt] = umfma(a4[kUMT - 1][3], b4[kUMT - 1][3], acc[nt]);
+            __builtin_amdgcn_sched_barrier(0);      // (pinned: the reads of step S + 1 in front of the MFMAs of step S)
+            const f32x4 b = qb[S & 1];
+            if (S < kUMT - 1) {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = umfma(qa[S & 1][nt][0], b[0], acc[nt]);
+                acc[nt] = umfma(qa[S & 1][nt][1], b[1], acc[nt]);
+                acc[nt] = umfma(qa[S & 1][nt][2], b[2], acc[nt]);
+                acc[nt] = umfma(qa[S & 1][nt][3], b[3], acc[nt]);
+              }
+            } else {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[nt] = umfma(qa[S & 1][nt][0], b[0], acc[nt]);
+              if (n4 != 4 * (kUMT - 1) + 1) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                  acc[nt] = umfma(qa[S & 1][nt][1], b[1], acc[nt]);
+                  acc[nt] = umfma(qa[S & 1][nt][2], b[2], acc[nt]);
+                  acc[nt] = umfma(qa[S & 1][nt][3], b[3], acc[nt]);
+                }
+              }
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
           if (DP) {
             // this rank's share of the gradient: summed over the ranks by the caller
@@ -1250,10 +1254,46 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-              for (int v = 0; v < 4; ++v) {
-                float* wp = Wl + (16 * nt + 4 * g4_l + v) * WP + 16 * j + c16_l;
-                *wp = adam_weight(acc[nt][v], Mr[jj][nt][v], Vr[jj][nt][v], *wp, a0, a1, ak);
-              }
+              for (int v = 0; v < 4; ++v)
+                wv[nt][v] = adam_weight(acc[nt][v], Mr[jj][nt][v], Vr[jj][nt][v], wv[nt][v], a0, a1, ak);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) Wl[(16 * nt + 4 * g4_l + v) * WP + 16 * j + c16_l] = wv[nt][v];
+          }
+        }
+      }
+      if (ks == 0 && w >= 8 - NT) {
+        // biases of this block: sums of the d_out^T rows (lane (c16, g4) takes a quarter of the
+        // minibatch, the quarters combine by butterfly shuffles), Adam on lanes < 16; 16-row block nt
+        // on wavefront 8 - NT + nt.  BEHIND the wavefront's block of the product (wavefronts 4 .. 7 have
+        // one block where 0 .. 3 have two: in front of it, all on wavefront 7, the sums put the k-slice-0
+        // workgroups 0.5 us behind the others, and the owners wait for the last forward flag of the
+        // chip), and with the seven reads of a sum in flight together (the scheduler, short of
+        // registers, had serialized them: 14 LDS round trips).
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (w != 8 - NT + nt) continue;
+          const float* xp = XS + (16 * nt + c16_l) * FP + 4 * g4_l;
+          f32x4 x4[kUMT];
+#pragma unroll
+          for (int S = 0; S < kUMT; ++S) x4[S] = *reinterpret_cast<const f32x4*>(xp + 16 * S);
+          __builtin_amdgcn_sched_barrier(0);
+          float g = 0.f;
+#pragma unroll
+          for (int S = 0; S < kUMT; ++S) g += (x4[S][0] + x4[S][1]) + (x4[S][2] + x4[S][3]);
+          g += __shfl_xor(g, 16, 64);
+          g += __shfl_xor(g, 32, 64);
+          if (g4_l == 0) {
+            const int n = n0 + 16 * nt + c16_l;
+            if (DP) {
+              if (n < Nh) p.grads[p.b_off + n] = g;
+            } else if constexpr (XR) {
+              if (n < Nh) xwg_store(p.grads + p.b_off + n, g);      // (Adam behind the exchange, below)
+            } else {
+              bw[nt] = adam_bias(g, bm[nt], bv[nt], bw[nt], a0, a1, ak);
+              biasl[16 * nt + c16_l] = bw[nt];
+            }
           }
         }
       }
@@ -1269,9 +1309,10 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
         // loop-carried register alive on one more path: 300 bytes of scratch per lane, 58 us per update)
         (void)run_aborted(flagp, red, tid);
         BSIG_USTAMP(14);
-        if (ks == 0 && w == 7 && g4_l == 0) {
+        if (ks == 0 && w >= 8 - NT && g4_l == 0) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
+            if (w != 8 - NT + nt) continue;
             const int n = n0 + 16 * nt + c16_l;
             const float g = n < Nh ? xwg_load(p.grads + p.b_off + n) : 0.f;
             bw[nt] = adam_bias(g, bm[nt], bv[nt], bw[nt], a0, a1, ak);
@@ -1347,9 +1388,10 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
             p.m1[off] = Mr[jj][nt][v]; p.m2[off] = Vr[jj][nt][v];
           }
         }
-    if (ks == 0 && w == 7 && g4 == 0) {
+    if (ks == 0 && w >= 8 - NT && g4 == 0) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        if (w != 8 - NT + nt) continue;
         const int n = n0 + 16 * nt + c16;
         if (n < Nh) { p.params[p.b_off + n] = bw[nt]; p.m1[p.b_off + n] = bm[nt]; p.m2[p.b_off + n] = bv[nt]; }
       }
