@@ -1254,8 +1254,9 @@ __device__ __forceinline__ void unified_workgroup(const UArgs& p, float* smem, c
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-              for (int v = 0; v < 4; ++v)
-                wv[nt][v] = adam_weight(acc[nt][v], Mr[jj][nt][v], Vr[jj][nt][v], wv[nt][v], a0, a1, ak);
+              for (int v = 0; v < 4; v += 2)
+                adam_weight2(acc[nt][v], acc[nt][v + 1], Mr[jj][nt][v], Mr[jj][nt][v + 1], Vr[jj][nt][v], Vr[jj][nt][v + 1],
+                             wv[nt][v], wv[nt][v + 1], a0, a1, ak);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll

@@ -30,6 +30,23 @@ __device__ __forceinline__ float adam_weight(float g, float& m, float& v, float 
   const float r = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_sqrtf(v), a1, k.eps));
   return __builtin_fmaf(-a0, m * r, w);
 }
+// Two elements at a time on the packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma: one issue slot
+// for both): the same operations, rounded the same way, as adam_weight on each -- bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void adam_weight2(float g0, float g1, float& m0, float& m1, float& v0, float& v1,
+                                             float& w0, float& w1, float a0, float a1, const AdamK& k) {
+  const f32x2 g = {g0, g1};
+  f32x2 m = {m0, m1}, v = {v0, v1}, w = {w0, w1};
+  const f32x2 ob1 = {k.ob1, k.ob1}, ob2 = {k.ob2, k.ob2}, b2f = {k.b2f, k.b2f}, a1v = {a1, a1}, eps = {k.eps, k.eps},
+              na0 = {-a0, -a0};
+  m = __builtin_elementwise_fma(g - m, ob1, m);
+  v = __builtin_elementwise_fma(ob2 * g, g, v * b2f);
+  const f32x2 sq = {__builtin_amdgcn_sqrtf(v[0]), __builtin_amdgcn_sqrtf(v[1])};
+  const f32x2 d = __builtin_elementwise_fma(sq, a1v, eps);
+  const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  w = __builtin_elementwise_fma(na0, m * r, w);
+  m0 = m[0]; m1 = m[1]; v0 = v[0]; v1 = v[1]; w0 = w[0]; w1 = w[1];
+}
 __device__ __forceinline__ float adam_bias(float g, float& m, float& v, float w, float a0,
                                            float a1, const AdamK& k) {
   m = __builtin_fmaf(g - m, k.ob1, m);
