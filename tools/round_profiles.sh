@@ -29,6 +29,7 @@ run_stats() {   # name, program, args...
   sed -i "1i # head: $HEADSHA\n# csrc: $CSRC" $OUT/${TAG}_${name}_kernel_stats.txt
   if [ "$prog" = bench.py ]; then
     python3 $R/tools/chunk_timeline.py "$db" $OUT/${TAG}_${name}_chunk_timeline.txt > /dev/null 2>&1 || true
+    [ -f $OUT/${TAG}_${name}_chunk_timeline.txt ] && sed -i "1i # head: $HEADSHA\n# csrc: $CSRC" $OUT/${TAG}_${name}_chunk_timeline.txt
   fi
 }
 run_pmc() {     # name, counter, program, args...
